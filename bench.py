@@ -1,0 +1,206 @@
+#!/usr/bin/env python3
+"""Headline benchmark: train images/sec of the 256x256 VAE-CycleGAN step (BASELINE.json).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A "step" is one `CycleVAEGAN.training_step` (generator update + discriminator update) on one
+synthetic batch per rank; batches are generated on the device before the timed region.  Rank 0
+prints ONE JSON line.  `roofline` is measured live with HIP events around every launch of the
+dominant kernel family during extra instrumented steps (ops.PROFILE); `cpu_baseline` times the
+oracle's CPU restatement of the same step on a bounded sample (rank 0, N=1 only).
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+FP32_MFMA_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs @ 2.4 GHz
+WORKLOADS = {
+    "cyclevaegan": "cyclevaegan unpaired, 3x256x256 synthetic summer<->winter, per-GPU batch 8, latent 64 (BASELINE.json configs[3]/[4])",
+    "vae": "vae latent 1024, 3x256x256 synthetic, batch 16 (BASELINE.json configs[2])",
+    "autoencoder": "autoencoder, 3x256x256 synthetic, batch 16 (BASELINE.json configs[1])",
+}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="cyclevaegan", choices=list(WORKLOADS))
+    ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default: 8 cyclevaegan, 16 ae/vae)")
+    ap.add_argument("--size", type=int, default=256)
+    ap.add_argument("--latent", type=int, default=None)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    pkg = importlib.import_module("vae-cyclegan-implementation_amd")
+    ops, N = pkg.ops, pkg.Networks
+    pkg._native.lib()                      # fail loudly if the HIP extension is missing
+
+    wl = args.workload
+    B = args.batch or (8 if wl == "cyclevaegan" else 16)
+    S = args.size
+    latent = args.latent or (1024 if wl == "vae" else 64)
+    torch.manual_seed(1234)                # identical random-init replicas on every rank
+    if wl == "cyclevaegan":
+        model = N.CycleVAEGAN(latent_dim=latent, paired=False)
+    elif wl == "vae":
+        model = N.VariationalAutoencoder(latent_dim=latent)
+    else:
+        model = N.Autoencoder()
+    model = model.to(dev).train()
+    model.configure_optimizers(lr=2e-4)
+    model.configure_loss(lambda_kl=1e-5, lambda_gan=1.0, lambda_identity=5.0, lambda_cycle=10.0, lambda_recon=1.0)
+    red = None
+    if world > 1:
+        red = pkg.parallel.attach(model)
+        pkg.parallel.broadcast_parameters(model)
+    ops.manual_seed(4321 + rank)
+
+    # synthetic batches resident in HBM: x, y ~ U[0,1), distinct per rank and per pool slot
+    pool = []
+    nquads = (B * 3 * S * S + 3) // 4
+    for i in range(4):
+        base = ((rank * 4 + i) * 2) * nquads
+        x = ops.to_nhwc(ops.rand_uniform((B, 3, S, S), dev, seed=1234, offset=base))
+        y = ops.to_nhwc(ops.rand_uniform((B, 3, S, S), dev, seed=1234, offset=base + nquads))
+        pool.append({"x": x, "y": y if wl == "cyclevaegan" else x})
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        model.training_step(pool[i % len(pool)])
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        last = model.training_step(pool[i % len(pool)])
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = tt.item()
+    bad = [k for k, v in last.items() if v != v or abs(v) == float("inf")]
+    if bad:
+        raise SystemExit(f"non-finite metrics after the timed steps: {bad}")
+    ms_per_step = elapsed / args.steps * 1e3
+    images_per_s = B * world * args.steps / elapsed
+
+    out = {
+        "metric": "train images/sec (256x256 VAE-CycleGAN step)" if wl == "cyclevaegan" else f"train images/sec ({wl} step)",
+        "value": round(images_per_s, 3), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": WORKLOADS[wl] if (S == 256) else f"{wl} {S}x{S} batch {B}", "per_gpu_batch": B, "global_batch": B * world,
+                   "image_size": S, "latent_dim": latent, "parallelism": f"dp{world}", "init": "random (reference init statistics)"},
+    }
+
+    if rank == 0 and not args.no_roofline:
+        out.update(measure_roofline(pkg, model, pool, wl, B, S, latent, ms_per_step))
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(pkg, wl, S, latent)
+    if world > 1:
+        dist.barrier()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def measure_roofline(pkg, model, pool, wl, B, S, latent, ms_per_step):
+    """HIP events around every conv launch of two extra steps; the dominant family's algorithmic
+    FLOPs / its summed launch time, against the fp32 MFMA peak."""
+    ops = pkg.ops
+    ops.PROFILE = []
+    for i in range(2):
+        model.training_step(pool[i % len(pool)])
+    torch.cuda.synchronize()
+    recs, ops.PROFILE = ops.PROFILE, None
+    fam = {}
+    for name, flops, e0, e1 in recs:
+        f = fam.setdefault(name, [0.0, 0.0, 0])
+        f[0] += flops
+        f[1] += e0.elapsed_time(e1) * 1e-3
+        f[2] += 1
+    conv = {k: v for k, v in fam.items() if k.startswith("conv_")}
+    dom = max(conv, key=lambda k: conv[k][1])
+    flops, secs, n = conv[dom]
+    ach = flops / secs / 1e12
+    kernels = {k: {"launches_per_step": v[2] // 2, "ms_per_step": round(v[1] / 2 * 1e3, 3),
+                   "tflops": round(v[0] / max(v[1], 1e-12) / 1e12, 2) if v[0] else None} for k, v in sorted(fam.items())}
+    # necessary conv FLOPs of one step: fwd + bwd-data + bwd-weight, nothing redundant
+    step_flops = sum(v[0] for v in conv.values()) / 2
+    return {
+        "roofline": {"bound": "mfma", "kernel": dom, "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                     "launches": n // 2, "avg_launch_ms": round(secs / n * 1e3, 4)},
+        "step_conv_tflops": round(step_flops / (ms_per_step * 1e-3) / 1e12, 2),
+        "step_conv_frac_of_peak": round(step_flops / (ms_per_step * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
+        "kernels": kernels,
+    }
+
+
+def cpu_baseline(pkg, wl, S, latent):
+    """The oracle's CPU restatement of the same step on this box's host cores: one timed step at batch 1
+    (after one untimed step), i.e. a bounded ~10-30 s sample of the workload."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    oracle = importlib.import_module("vcg_oracle")
+    cores = min(os.cpu_count() or 1, 32)
+    torch.set_num_threads(cores)
+    Nn = pkg.Networks
+    torch.manual_seed(1234)
+    if wl == "cyclevaegan":
+        model = Nn.CycleVAEGAN(latent_dim=latent, paired=False)
+    elif wl == "vae":
+        model = Nn.VariationalAutoencoder(latent_dim=latent)
+    else:
+        model = Nn.Autoencoder()
+    P = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    del model
+    b = 1
+    x, y = (torch.from_numpy(a) for a in pkg.synth.batch(b, S, 1234))
+    times = []
+    state = {}
+    for it in range(2):
+        t0 = time.perf_counter()
+        if wl == "cyclevaegan":
+            eps = [torch.from_numpy(e) for e in pkg.synth.eps_list(6, (b, latent, S // 16, S // 16), 4321, step=it)]
+            oracle.cyclevaegan_step(P, state, x, y, eps, 2e-4, False)
+        elif wl == "vae":
+            eps = torch.from_numpy(pkg.synth.eps_list(1, (b, latent, S // 16, S // 16), 4321, step=it)[0])
+            oracle.vae_step(P, state, x, x, eps, 2e-4)
+        else:
+            oracle.autoencoder_step(P, state, x, x, 2e-4)
+        times.append(time.perf_counter() - t0)
+    return {"value": round(b / times[-1], 4), "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": f"oracle (functional PyTorch fp32 CPU restatement) {wl} step, batch {b}, {S}x{S}, second of two steps, {times[-1]:.1f} s"}
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,149 @@
+/*
+ * vcg.h — C ABI of libvcg.so, the MI355X (gfx950) native kernels behind the
+ * VAE-CycleGAN training step.
+ *
+ * The reference (Baverne/VAE-CYCLEGAN-Implementation) has no FFI of its own:
+ * every op below replaces a torch call site inside Networks.py / Losses.py.
+ * The citation after each entry point is the reference line it replaces.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller (torch's caching
+ *     allocator); the library never allocates, frees or synchronises;
+ *   - activations are fp32 NHWC with a channel pitch that is a multiple of 4
+ *     (3-channel images are stored with pitch 4, pad channel == 0);
+ *   - conv weights live in the reference's OIHW layout (state_dict parity) and
+ *     are repacked once per optimizer step into the GEMM layout Wf[K][Cout];
+ *   - all launches go to `stream` (a hipStream_t passed as void*);
+ *   - return 0 on success, negative on error; vcg_last_error() has the text.
+ *     Nothing throws across this boundary.
+ */
+#ifndef VCG_H
+#define VCG_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VCG_ABI_VERSION 1
+
+/* conv descriptor: int32[16] ------------------------------------------------ */
+enum {
+  VCG_CD_N = 0,      /* batch */
+  VCG_CD_H = 1,      /* physical input height */
+  VCG_CD_W = 2,      /* physical input width */
+  VCG_CD_CIN = 3,    /* physical input channel pitch (multiple of 4) */
+  VCG_CD_COUT = 4,   /* physical output channel pitch (multiple of 4) */
+  VCG_CD_KH = 5,
+  VCG_CD_KW = 6,
+  VCG_CD_STRIDE = 7, /* 1 or 2 */
+  VCG_CD_PAD = 8,
+  VCG_CD_REFLECT = 9, /* 1 = padding_mode='reflect', 0 = zeros */
+  VCG_CD_UPS = 10,   /* 1, or 2 = nn.PixelUnshuffle(2) folded into the gather */
+  VCG_CD_ACT = 11,   /* epilogue activation: VCG_ACT_* */
+  VCG_CD_CIN_LOGICAL = 12, /* channels of the physical input that carry data (3 for images) */
+  VCG_CD_COUT_LOGICAL = 13,
+  VCG_CD_LEN = 16
+};
+
+enum { VCG_ACT_NONE = 0, VCG_ACT_RELU = 1, VCG_ACT_LEAKY02 = 2 };
+
+int vcg_abi_version(void);
+const char* vcg_last_error(void);
+
+/* layout ------------------------------------------------------------------- */
+/* x.to(channels-last); images get channel pitch P (pad channels zeroed).     */
+int vcg_nchw_to_nhwc(const float* src, float* dst, int N, int C, int H, int W, int P, void* stream);
+int vcg_nhwc_to_nchw(const float* src, float* dst, int N, int C, int H, int W, int P, void* stream);
+int vcg_fill(float* dst, float value, size_t n, void* stream);
+
+/* nn.Conv2d(padding_mode='reflect') — Networks.py:60,87,101,104,122,136,145 -- */
+/* OIHW -> Wf[K][Cout], K ordered (kh,kw,i,j,c) so PixelUnshuffle (Networks.py:86)
+   needs no data movement.                                                      */
+int vcg_pack_weight(const float* w_oihw, float* wf, const int32_t* cd, void* stream);
+/* y = act(conv(x) + bias): implicit GEMM on v_mfma_f32_32x32x2_f32.          */
+int vcg_conv_fwd(const float* x, const float* wf, const float* bias, float* y,
+                 const int32_t* cd, void* stream);
+/* dx = conv^T(dy) including the adjoint of the reflect padding.              */
+int vcg_conv_dgrad(const float* dy, const float* wf, float* dx, const int32_t* cd, void* stream);
+/* gw_oihw += x^T dy (split-K slabs in ws, deterministic reduce); gbias += sum(dy).
+   gbias may be NULL.                                                         */
+size_t vcg_conv_wgrad_workspace(const int32_t* cd);
+int vcg_conv_wgrad(const float* x, const float* dy, float* gw_oihw, float* gbias,
+                   const int32_t* cd, void* ws, size_t ws_bytes, void* stream);
+
+/* nn.InstanceNorm2d(eps=1e-5, affine=False) — Networks.py:61,88,102,105,123 -- */
+size_t vcg_in_workspace(int N, int HW, int C);
+int vcg_in_stats(const float* t, float* mean, float* rstd, int N, int HW, int C, float eps,
+                 void* ws, size_t ws_bytes, void* stream);
+/* out = post_act((t-mean)*rstd) [+ residual]; shuffle=1 stores through
+   nn.PixelShuffle(2) (Networks.py:121): out is (N,2H,2W,C/4).                */
+int vcg_in_apply(const float* t, const float* mean, const float* rstd, const float* residual,
+                 float* out, int N, int H, int W, int C, int post_act, int shuffle, void* stream);
+/* dt = epi_act'(t) * IN-backward(post_act'(.) * g); g is in `out` layout.   */
+int vcg_in_bwd(const float* g, const float* t, const float* mean, const float* rstd, float* dt,
+               int N, int H, int W, int C, int epi_act, int post_act, int shuffle,
+               void* ws, size_t ws_bytes, void* stream);
+/* nn.PixelShuffle(2) — Networks.py:121 — as a copy: (N,H,W,C) -> (N,2H,2W,C/4); inverse=1 is its backward */
+int vcg_pixel_shuffle(const float* src, float* dst, int N, int H, int W, int C, int inverse, void* stream);
+/* dt = g * act'(t) where t is the activation OUTPUT (blocks without a norm). */
+int vcg_act_bwd(const float* g, const float* t, float* dt, size_t n, int act, void* stream);
+
+/* VariationalEncoderBlock.forward — Networks.py:219-227 -------------------- */
+/* lvc = clamp(lv,-10,10); z = mu + eps*exp(0.5*lvc). eps==NULL: eps is drawn
+   on device (Philox4x32-10 + Box-Muller, (seed, offset)) and written to eps_out. */
+int vcg_reparam_fwd(const float* mu, const float* lv, const float* eps, float* eps_out,
+                    float* z, float* lvc, size_t n, uint64_t seed, uint64_t offset, void* stream);
+/* dmu = gz ; dlv = (gz*eps*0.5*exp(0.5*lvc) + glvc) * [-10<=lv<=10]; glvc may be NULL */
+int vcg_reparam_bwd(const float* gz, const float* glvc, const float* eps, const float* lv,
+                    float* dmu, float* dlv, size_t n, void* stream);
+int vcg_randn(float* out, size_t n, uint64_t seed, uint64_t offset, void* stream);
+int vcg_rand_uniform(float* out, size_t n, uint64_t seed, uint64_t offset, void* stream);
+
+/* Losses.py ---------------------------------------------------------------- */
+size_t vcg_reduce_workspace(size_t n);
+/* nn.L1Loss — Losses.py:21-24,34-39,53-65: out[0] = sum|a-b| / n_logical     */
+int vcg_l1_fwd(const float* a, const float* b, float* out, size_t n_phys, size_t n_logical,
+               void* ws, size_t ws_bytes, void* stream);
+/* ga = sign(a-b) * gout[0] / n_logical ; gb (optional) = -ga                 */
+int vcg_l1_bwd(const float* a, const float* b, const float* gout, float* ga, float* gb,
+               size_t n_phys, size_t n_logical, void* stream);
+/* nn.MSELoss vs a constant — Losses.py:78-83,97-102: out[0]=mean((d-c)^2), out[1]=mean(d) */
+int vcg_mse_const_fwd(const float* d, float target, float* out, size_t n, void* stream);
+int vcg_mse_const_bwd(const float* d, float target, const float* gout, float* gd, size_t n, void* stream);
+/* KLDivergenceLoss — Losses.py:115-121                                       */
+int vcg_kl_fwd(const float* mu, const float* lv, float* out, size_t n,
+               void* ws, size_t ws_bytes, void* stream);
+int vcg_kl_bwd(const float* mu, const float* lv, const float* gout, float* gmu, float* glv,
+               size_t n, void* stream);
+/* out[0] = sum_i w[i]*(*s[i]) ; the composite loss lines Networks.py:941,2012-2018 */
+int vcg_lincomb_fwd(const float* const* s, const float* w, int count, float* out, void* stream);
+
+/* spectral_norm(nn.Conv2d(512,1,16)) — Networks.py:248 ---------------------- */
+/* one power iteration exactly as torch.nn.utils.spectral_norm in train mode:
+   v<-normalize(W^T u), u<-normalize(W v), sigma=u.(W v); wsn (NHWC-K order) = W/sigma */
+int vcg_sn_prepare(const float* w_orig_oihw, float* u, float* v, float* sigma, float* wsn_k,
+                   int C, int KH, int KW, int update_uv, void* ws, size_t ws_bytes, void* stream);
+/* out[n] = <x[n,:], wsn_k> + bias[0]                                          */
+int vcg_fullmap_fwd(const float* x, const float* wsn_k, const float* bias, float* out,
+                    int N, size_t K, void* stream);
+/* dx[n,:] = g[n]*wsn_k (dx may be NULL)                                       */
+int vcg_fullmap_dgrad(const float* g, const float* wsn_k, float* dx, int N, size_t K, void* stream);
+/* gw_orig_oihw += d(W/sigma)^T applied to (sum_n g[n] x[n,:]); gbias[0] += sum g */
+int vcg_fullmap_wgrad(const float* g, const float* x, const float* wsn_k, const float* sigma,
+                      const float* u, const float* v, float* gw_orig_oihw, float* gbias,
+                      int N, int C, int KH, int KW, void* ws, size_t ws_bytes, void* stream);
+
+/* torch.optim.Adam.step — call sites Networks.py:312,894,1928-1935 ---------- */
+/* single-tensor torch formula on one flat buffer:
+   m += (1-b1)(g-m); v = b2 v + (1-b2) g^2; p -= step_size * m / (sqrt(v)/bc2_sqrt + eps) */
+int vcg_adam_step(float* p, const float* g, float* m, float* v, size_t n,
+                  float step_size, float beta1, float beta2, float eps, float bc2_sqrt,
+                  float grad_scale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VCG_H */

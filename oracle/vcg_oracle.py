@@ -1,0 +1,320 @@
+"""ORACLE — test infrastructure, not product code.
+
+A CPU restatement, in plain functional fp32 PyTorch, of the reference's training-step hot path
+(Baverne/VAE-CYCLEGAN-Implementation: Networks.py, Losses.py, and torch.optim.Adam as called from
+them).  Each function cites the reference lines it follows.  Only `tests/`,
+`__graft_entry__.smoke()` and the `cpu_baseline` leg of `bench.py` may import this module; the
+product (`vae-cyclegan-implementation_amd/`) never does.
+
+Pinning: the reference has no tests or golden vectors of its own, so this oracle is
+pinned against outputs of the reference itself, produced in the build container by
+`tests/golden/make_golden.py` (which imports /root/reference) and committed as
+`tests/golden/*.npz`; `tests/test_oracle_golden.py` checks the oracle against them.
+
+Parameters are a flat dict {state_dict name: tensor}, NCHW / OIHW exactly as the reference's
+state_dict, so fixtures and checkpoints map one to one.
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+IN_EPS = 1e-5
+
+
+# ----------------------------------------------------------------------------- atoms
+def reflect_conv(x, w, b, stride=1, pad=1):
+    """nn.Conv2d(..., padding_mode='reflect')  — Networks.py:60,87,101,104,122,136,145"""
+    if pad > 0:
+        x = F.pad(x, (pad, pad, pad, pad), mode="reflect")
+    return F.conv2d(x, w, b, stride=stride)
+
+
+def instance_norm(x):
+    """nn.InstanceNorm2d(C): eps 1e-5, biased variance, no affine, no running stats — Networks.py:61.
+    Calls the functional the reference's module calls, so the CPU numerics are the reference's
+    (torch's CPU kernel accumulates the statistics and the backward reductions in double; a
+    hand-written fp32 mean/var differs from it by up to 1e-2 in the gradients of near-dead
+    channels, where rstd reaches 1/sqrt(eps) = 316)."""
+    return F.instance_norm(x, None, None, None, None, True, 0.1, IN_EPS)
+
+
+def _act(x, name):
+    if name == "ReLU":
+        return F.relu(x)
+    if name == "LeakyReLU":
+        return F.leaky_relu(x, 0.2)
+    if name == "Identity":
+        return x
+    raise NotImplementedError(name)
+
+
+def casb(x, P, pre, stride=1, pad=3, activation="ReLU", use_norm=True):
+    """CaSb.forward: conv -> [IN] -> act — Networks.py:76-81"""
+    x = reflect_conv(x, P[pre + "conv.weight"], P[pre + "conv.bias"], stride, pad)
+    if use_norm:
+        x = instance_norm(x)
+    return _act(x, activation)
+
+
+def d_block(x, P, pre):
+    """D.forward: PixelUnshuffle(2) -> conv3x3 -> ReLU -> IN — Networks.py:91-96"""
+    x = F.pixel_unshuffle(x, 2)
+    x = reflect_conv(x, P[pre + "conv.weight"], P[pre + "conv.bias"])
+    return instance_norm(F.relu(x))
+
+
+def r_block(x, P, pre):
+    """R.forward: conv -> ReLU -> IN -> conv -> IN -> + x — Networks.py:108-116"""
+    h = reflect_conv(x, P[pre + "conv1.weight"], P[pre + "conv1.bias"])
+    h = instance_norm(F.relu(h))
+    h = reflect_conv(h, P[pre + "conv2.weight"], P[pre + "conv2.bias"])
+    return instance_norm(h) + x
+
+
+def u_block(x, P, pre):
+    """U.forward: PixelShuffle(2) -> conv3x3 -> ReLU -> IN — Networks.py:126-131"""
+    x = F.pixel_shuffle(x, 2)
+    x = reflect_conv(x, P[pre + "conv.weight"], P[pre + "conv.bias"])
+    return instance_norm(F.relu(x))
+
+
+def s_conv(x, P, pre):
+    """S.forward / L.forward: bare conv3x3 — Networks.py:138-140, 147-149"""
+    return reflect_conv(x, P[pre + "conv.weight"], P[pre + "conv.bias"])
+
+
+# ----------------------------------------------------------------------------- molecules
+def encoder(x, P, pre):
+    """Encoder — Networks.py:158-163"""
+    x = casb(x, P, pre + "model.0.", 1, 3, "ReLU", True)
+    for i in (1, 2, 3, 4):
+        x = d_block(x, P, pre + f"model.{i}.")
+    return r_block(x, P, pre + "model.5.")
+
+
+def decoder(x, P, pre):
+    """Decoder — Networks.py:187-192"""
+    x = r_block(x, P, pre + "model.0.")
+    for i in (1, 2, 3, 4):
+        x = u_block(x, P, pre + f"model.{i}.")
+    return casb(x, P, pre + "model.5.", 1, 3, "Identity", False)
+
+
+def variational_encoder_block(x, P, pre, eps):
+    """VariationalEncoderBlock.forward — Networks.py:219-227 (eps replaces torch.randn_like at :225)"""
+    mu = s_conv(x, P, pre + "muConv.")
+    logvar = s_conv(s_conv(x, P, pre + "logvarConv.0."), P, pre + "logvarConv.1.")
+    logvar = torch.clamp(logvar, min=-10, max=10)
+    std = torch.exp(0.5 * logvar)
+    return mu + eps * std, mu, logvar
+
+
+def autoencoder_forward(x, P, pre=""):
+    """Autoencoder.forward — Networks.py:302-305"""
+    return decoder(encoder(x, P, pre + "encoder."), P, pre + "decoder.")
+
+
+def vae_forward(x, P, pre, eps):
+    """VariationalAutoencoder.forward — Networks.py:885-890"""
+    enc = encoder(x, P, pre + "encoder.")
+    z, mu, logvar = variational_encoder_block(enc, P, pre + "variational_encoder_block.", eps)
+    dec = s_conv(z, P, pre + "variational_decoder_block.conv.")
+    return decoder(dec, P, pre + "decoder."), mu, logvar
+
+
+def spectral_norm_weight(P, pre, training=True):
+    """torch.nn.utils.spectral_norm's compute_weight (one power iteration, eps 1e-12) on
+    nn.Conv2d(512, 1, 16) — Networks.py:248.  Returns (W/sigma, u_new, v_new)."""
+    w = P[pre + "weight_orig"]
+    u, v = P[pre + "weight_u"], P[pre + "weight_v"]
+    wm = w.reshape(w.shape[0], -1)
+    if training:
+        with torch.no_grad():
+            v = F.normalize(torch.mv(wm.detach().t(), u), dim=0, eps=1e-12)
+            u = F.normalize(torch.mv(wm.detach(), v), dim=0, eps=1e-12)
+    sigma = torch.dot(u, torch.mv(wm, v))
+    return w / sigma, u, v
+
+
+def discriminator(x, P, pre, training=True, sn_state=None):
+    """Discriminator.forward — Networks.py:244-248, :267-269"""
+    x = casb(x, P, pre + "model.0.", 2, 1, "LeakyReLU", False)
+    for i in (1, 2, 3):
+        x = casb(x, P, pre + f"model.{i}.", 2, 1, "LeakyReLU", True)
+    w, u, v = spectral_norm_weight(P, pre + "model.4.", training)
+    if sn_state is not None:
+        sn_state[pre + "model.4.weight_u"] = u.detach()
+        sn_state[pre + "model.4.weight_v"] = v.detach()
+    return F.conv2d(x, w, P[pre + "model.4.bias"]).view(-1, 1).squeeze(1)
+
+
+# ----------------------------------------------------------------------------- losses
+def l1(a, b):
+    """nn.L1Loss() — Losses.py:21-24"""
+    return (a - b).abs().mean()
+
+
+def cycle_loss(x, y, FGx, GFy):
+    """CycleConsistencyLoss.forward — Losses.py:36-39"""
+    return l1(FGx, x) + l1(GFy, y)
+
+
+def identity_loss(x, y, Fx, Gy):
+    """IdentityLoss.forward — Losses.py:55-65"""
+    return l1(Fx, x) + l1(Gy, y)
+
+
+def gan_loss_generator(d_real, d_fake):
+    """GANLossGenerator.forward — Losses.py:78-83"""
+    real = (d_real ** 2).mean()
+    fake = ((d_fake - 1.0) ** 2).mean()
+    return real + fake, real, fake
+
+
+def gan_loss_discriminator(d_real, d_fake):
+    """GANLossDiscriminator.forward — Losses.py:97-102"""
+    real = ((d_real - 1.0) ** 2).mean()
+    fake = (d_fake ** 2).mean()
+    return real + fake, real, fake
+
+
+def kl_loss(mu, logvar):
+    """KLDivergenceLoss.forward — Losses.py:115-121"""
+    logvar = torch.clamp(logvar, min=-10, max=10)
+    return -0.5 * torch.mean(1 + logvar - mu.pow(2) - logvar.exp())
+
+
+# ----------------------------------------------------------------------------- optimizer
+def adam_update(P, grads, state, names, lr, betas=(0.5, 0.999), eps=1e-8):
+    """torch.optim.Adam.step (single-tensor path, no weight decay / amsgrad) for the named parameters;
+    call sites Networks.py:312, 894, 1928-1935, steps at :377, :946, :2022, :2044."""
+    b1, b2 = betas
+    state["step"] = state.get("step", 0) + 1
+    t = state["step"]
+    bc1 = 1 - b1 ** t
+    bc2 = 1 - b2 ** t
+    step_size = lr / bc1
+    bc2_sqrt = math.sqrt(bc2)
+    with torch.no_grad():
+        for n in names:
+            g = grads.get(n)
+            if g is None:
+                continue
+            m = state.setdefault("exp_avg", {}).setdefault(n, torch.zeros_like(P[n]))
+            v = state.setdefault("exp_avg_sq", {}).setdefault(n, torch.zeros_like(P[n]))
+            m.lerp_(g, 1 - b1)
+            v.mul_(b2).addcmul_(g, g, value=1 - b2)
+            denom = (v.sqrt() / bc2_sqrt).add_(eps)
+            P[n] = P[n] - step_size * (m / denom)
+
+
+def _leaf_params(P, names):
+    Q = dict(P)
+    for n in names:
+        Q[n] = P[n].detach().clone().requires_grad_(True)
+    return Q
+
+
+def _grads(loss, Q, names):
+    gs = torch.autograd.grad(loss, [Q[n] for n in names], allow_unused=True)
+    return {n: g for n, g in zip(names, gs)}
+
+
+def trainable_names(P, prefixes=("",)):
+    return [n for n in P if not (n.endswith("weight_u") or n.endswith("weight_v")) and any(n.startswith(p) for p in prefixes)]
+
+
+# ----------------------------------------------------------------------------- training steps
+def autoencoder_step(P, state, x, y, lr):
+    """Autoencoder.training_step — Networks.py:334-384.  Returns (metrics, output, grads)."""
+    names = trainable_names(P)
+    Q = _leaf_params(P, names)
+    out = autoencoder_forward(x, Q)
+    loss = l1(out, y)
+    grads = _grads(loss, Q, names)
+    adam_update(P, grads, state, names, lr)
+    v = loss.item()
+    return {"G_loss": v, "loss_trans": v, "total_loss": v}, out.detach(), grads
+
+
+def vae_step(P, state, x, y, eps, lr, lambda_kl=1e-5):
+    """VariationalAutoencoder.training_step — Networks.py:918-953"""
+    names = trainable_names(P)
+    Q = _leaf_params(P, names)
+    out, mu, logvar = vae_forward(x, Q, "", eps)
+    loss_trans = l1(out, y)
+    loss_kl = kl_loss(mu, logvar)
+    G_loss = loss_trans + lambda_kl * loss_kl
+    grads = _grads(G_loss, Q, names)
+    adam_update(P, grads, state, names, lr)
+    return ({"G_loss": G_loss.item(), "loss_trans": loss_trans.item(), "loss_kl": loss_kl.item()},
+            {"Gx": out.detach(), "mu": mu.detach(), "logvar": logvar.detach()}, grads)
+
+
+def cyclevaegan_step(P, state, x, y, eps6, lr, paired=False, lambda_cycle=10.0, lambda_gan=1.0, lambda_kl=1e-5,
+                     lambda_identity=5.0):
+    """CycleVAEGAN.training_step — Networks.py:1973-2078, with forward :1909-1924 (six VAE forwards in the
+    reference's order, so eps6[i] is the i-th randn_like draw) and the discriminator re-forward :2028-2035.
+    `state` holds {"G": adam state, "D": adam state}.  Spectral-norm u/v in P are updated in place
+    (torch does so in every training-mode forward)."""
+    g_names = trainable_names(P, ("F.", "G."))
+    d_names = trainable_names(P, ("DX.", "DY."))
+    Q = _leaf_params(P, g_names + d_names)
+    sn = {}
+    Gx, mu_x, lv_x = vae_forward(x, Q, "G.", eps6[0])
+    Gy, _, _ = vae_forward(y, Q, "G.", eps6[1])
+    FGx, mu_FGx, lv_FGx = vae_forward(Gx, Q, "F.", eps6[2])
+    Fy, mu_y, lv_y = vae_forward(y, Q, "F.", eps6[3])
+    Fx, _, _ = vae_forward(x, Q, "F.", eps6[4])
+    GFy, mu_GFy, lv_GFy = vae_forward(Fy, Q, "G.", eps6[5])
+
+    def run_d(inp, pre):
+        out = discriminator(inp, Q, pre, True, sn)
+        Q[pre + "model.4.weight_u"], Q[pre + "model.4.weight_v"] = sn[pre + "model.4.weight_u"], sn[pre + "model.4.weight_v"]
+        return out
+
+    DYGx = run_d(Gx, "DY.")
+    DXFy = run_d(Fy, "DX.")
+    DXx = run_d(x, "DX.")
+    DYy = run_d(y, "DY.")
+    loss_cycle = cycle_loss(x, y, FGx, GFy)
+    _, g_x_real, g_x_fake = gan_loss_generator(DXx, DXFy)
+    _, g_y_real, g_y_fake = gan_loss_generator(DYy, DYGx)
+    loss_gan_g_fake = g_x_fake + g_y_fake
+    loss_kl = kl_loss(mu_x, lv_x) + kl_loss(mu_FGx, lv_FGx) + kl_loss(mu_y, lv_y) + kl_loss(mu_GFy, lv_GFy)
+    G_loss = lambda_cycle * loss_cycle + lambda_gan * loss_gan_g_fake + lambda_kl * loss_kl
+    if paired:
+        loss_identity = identity_loss(x, y, Fx, Gy)
+        G_loss = G_loss + lambda_identity * loss_identity
+    g_grads = _grads(G_loss, Q, g_names)
+    adam_update(P, g_grads, state.setdefault("G", {}), g_names, lr)
+
+    DYGx_d = run_d(Gx.detach(), "DY.")
+    DXFy_d = run_d(Fy.detach(), "DX.")
+    DXx_d = run_d(x, "DX.")
+    DYy_d = run_d(y, "DY.")
+    d_x, d_x_real, d_x_fake = gan_loss_discriminator(DXx_d, DXFy_d)
+    d_y, d_y_real, d_y_fake = gan_loss_discriminator(DYy_d, DYGx_d)
+    D_loss = d_x + d_y
+    d_grads = _grads(D_loss, Q, d_names)
+    adam_update(P, d_grads, state.setdefault("D", {}), d_names, lr)
+    for k, v in sn.items():
+        P[k] = v
+
+    m = {
+        "total_loss": G_loss.item() + D_loss.item(), "G_loss": G_loss.item(), "D_loss": D_loss.item(),
+        "D_loss_x_real": d_x_real.item(), "D_loss_x_fake": d_x_fake.item(),
+        "D_loss_y_real": d_y_real.item(), "D_loss_y_fake": d_y_fake.item(),
+        "loss_cycle": loss_cycle.item(), "loss_gan_g": loss_gan_g_fake.item(),
+        "loss_gan_g_x_real": g_x_real.item(), "loss_gan_g_x_fake": g_x_fake.item(),
+        "loss_gan_g_y_real": g_y_real.item(), "loss_gan_g_y_fake": g_y_fake.item(),
+        "loss_kl": loss_kl.item(),
+        "d_x_real_mean": DXx_d.mean().item(), "d_x_fake_mean": DXFy_d.mean().item(),
+        "d_y_real_mean": DYy_d.mean().item(), "d_y_fake_mean": DYGx_d.mean().item(),
+    }
+    if paired:
+        m["loss_identity"] = loss_identity.item()
+    outs = {"Gx": Gx.detach(), "FGx": FGx.detach(), "Fy": Fy.detach(), "GFy": GFy.detach(),
+            "mu_x": mu_x.detach(), "logvar_x": lv_x.detach()}
+    return m, outs, g_grads, d_grads

@@ -1,0 +1,328 @@
+"""GPU: the HIP path (through the C ABI) against the golden fixtures of the reference and against the
+oracle on the same seeded inputs.  Tolerance: 1e-3 relative, fp32 (BASELINE.json north_star); atom-sized
+cases are held to 1e-4 L2 so indexing errors at tile/border positions cannot hide."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import (SEED, assert_checksum, assert_close, check_step_state, in_cancelled_bias)
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+from cases import ATOM_BIAS_STD, ATOM_CASES, DISC_BIAS_STD, LAMBDAS, LR, STEP_BIAS_STD  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+def load_synth(pkg, module, key, bias_std, seed=SEED):
+    shapes = {f"{key}.{k}": tuple(v.shape) for k, v in module.state_dict().items()}
+    sd = pkg.synth.state_dict_like(shapes, seed, bias_std=bias_std)
+    module.load_state_dict({k[len(key) + 1:]: torch.from_numpy(v) for k, v in sd.items()})
+    return {k[len(key) + 1:]: torch.from_numpy(v) for k, v in sd.items()}
+
+
+def nchw(t):
+    return t.detach().cpu().contiguous()
+
+
+def run_module(mod, x_np, g_np, device, **fw):
+    mod = mod.to(device)
+    x = torch.from_numpy(x_np).to(device).requires_grad_(True)
+    y = mod(x, **fw)
+    y.backward(torch.from_numpy(g_np).to(device))
+    grads = {n: p.grad.detach().cpu() for n, p in mod.named_parameters()}
+    return nchw(y), nchw(x.grad), grads
+
+
+# ------------------------------------------------------------------ atoms vs the reference's own outputs
+@pytest.mark.parametrize("name", list(ATOM_CASES))
+def test_atoms_match_reference_golden(name, pkg, device, atoms_golden):
+    cls, args, kwargs, xshape, scale = ATOM_CASES[name]
+    mod = getattr(pkg.Networks, cls)(*args, **kwargs)
+    load_synth(pkg, mod, name, ATOM_BIAS_STD)
+    x = pkg.synth.normal(xshape, SEED, name + "/x") * scale
+    yref = atoms_golden[name + "/y"]
+    g = pkg.synth.normal(yref.shape, SEED, name + "/g")
+    y, dx, grads = run_module(mod, x, g, device)
+    assert_close(y, yref, name + " y")
+    assert_close(dx, atoms_golden[name + "/dx"], name + " dx")
+    for k, v in grads.items():
+        ref = atoms_golden[name + "/d." + k]
+        if cls == "CaSb" and kwargs.get("use_norm", True) and k.endswith("bias") or k.endswith("conv2.bias"):
+            assert np.abs(v.numpy()).max() < 1e-3
+            continue
+        assert_close(v, ref, f"{name} d{k}")
+
+
+def test_u_block_with_shuffled_store_matches_reference(pkg, device, atoms_golden):
+    """U -> U hand-off: this block stores through the next block's PixelShuffle."""
+    name = "u_shuf"
+    cls, args, kwargs, xshape, scale = ATOM_CASES[name]
+    mod = pkg.Networks.U(*args)
+    load_synth(pkg, mod, name, ATOM_BIAS_STD)
+    x = pkg.synth.normal(xshape, SEED, name + "/x")
+    yref = torch.from_numpy(atoms_golden[name + "/y"])
+    g = torch.from_numpy(pkg.synth.normal(tuple(yref.shape), SEED, name + "/g"))
+    y, dx, grads = run_module(mod, x, F.pixel_shuffle(g, 2).numpy(), device, shuffle_out=True)
+    assert_close(y, F.pixel_shuffle(yref, 2), "shuffled y")
+    assert_close(dx, atoms_golden[name + "/dx"], "dx")
+    assert_close(grads["conv.weight"], atoms_golden[name + "/d.conv.weight"], "dW")
+    assert_close(grads["conv.bias"], atoms_golden[name + "/d.conv.bias"], "db")
+
+
+def test_vae_bottleneck_matches_reference_golden(pkg, device, atoms_golden):
+    name = "veb"
+    mod = pkg.Networks.VariationalEncoderBlock(16, 8)
+    load_synth(pkg, mod, name, ATOM_BIAS_STD)
+    mod = mod.to(device)
+    x = torch.from_numpy(pkg.synth.normal((2, 16, 4, 6), SEED, name + "/x") * 6.0).to(device).requires_grad_(True)
+    eps = torch.from_numpy(pkg.synth.normal((2, 8, 4, 6), SEED, name + "/eps")).to(device)
+    pkg.ops.inject_eps([eps])
+    z, mu, lv = mod(x)
+    gz, gm, gl = (torch.from_numpy(pkg.synth.normal(tuple(z.shape), SEED, name + "/" + s)).to(device) for s in ("gz", "gm", "gl"))
+    torch.autograd.backward([z, mu, lv], [gz, gm, gl])
+    assert_close(nchw(z), atoms_golden[name + "/z"], "z")
+    assert_close(nchw(mu), atoms_golden[name + "/mu"], "mu")
+    assert_close(nchw(lv), atoms_golden[name + "/logvar"], "logvar")
+    assert_close(nchw(x.grad), atoms_golden[name + "/dx"], "dx")
+    for k, p in mod.named_parameters():
+        assert_close(p.grad, atoms_golden[name + "/d." + k], "d" + k)
+
+
+def test_losses_match_reference_golden(pkg, device, atoms_golden):
+    G, L = atoms_golden, pkg.Losses
+    a = torch.from_numpy(pkg.synth.normal((2, 3, 8, 8), SEED, "loss/a")).to(device).requires_grad_(True)
+    b = torch.from_numpy(pkg.synth.normal((2, 3, 8, 8), SEED, "loss/b")).to(device)
+    l = L.TranslationLoss()(a, b)
+    l.backward()
+    assert abs(l.item() - G["loss/l1"][0]) <= 1e-5 * abs(G["loss/l1"][0])
+    assert_close(nchw(a.grad), G["loss/l1_da"], "l1 grad", l2=1e-6, mx=1e-5)
+    mu = torch.from_numpy(pkg.synth.normal((2, 8, 4, 4), SEED, "loss/mu")).to(device).requires_grad_(True)
+    lv = torch.from_numpy(pkg.synth.normal((2, 8, 4, 4), SEED, "loss/lv") * 8.0).to(device).requires_grad_(True)
+    k = L.KLDivergenceLoss()(mu, lv)
+    k.backward()
+    assert abs(k.item() - G["loss/kl"][0]) <= 1e-5 * abs(G["loss/kl"][0])
+    assert_close(nchw(mu.grad), G["loss/kl_dmu"], "kl dmu", l2=1e-5, mx=1e-5)
+    assert_close(nchw(lv.grad), G["loss/kl_dlv"], "kl dlv", l2=1e-5, mx=1e-5)
+    for cls, tag in ((L.GANLossGenerator, "gan_g"), (L.GANLossDiscriminator, "gan_d")):
+        d1 = torch.from_numpy(pkg.synth.normal((5,), SEED, "loss/d1")).to(device).requires_grad_(True)
+        d2 = torch.from_numpy(pkg.synth.normal((5,), SEED, "loss/d2")).to(device).requires_grad_(True)
+        tot, real, fake = cls()(d1, d2)
+        tot.backward()
+        np.testing.assert_allclose([tot.item(), real.item(), fake.item()], G["loss/" + tag], rtol=1e-5)
+        assert_close(d1.grad, G[f"loss/{tag}_d1"], tag + " d1", l2=1e-5, mx=1e-5)
+        assert_close(d2.grad, G[f"loss/{tag}_d2"], tag + " d2", l2=1e-5, mx=1e-5)
+
+
+def test_discriminator_matches_reference_golden(pkg, device, atoms_golden):
+    name = "disc"
+    mod = pkg.Networks.Discriminator()
+    load_synth(pkg, mod, name, DISC_BIAS_STD)
+    mod = mod.to(device).train()
+    x = torch.from_numpy(pkg.synth.uniform((2, 3, 256, 256), SEED, name + "/x")).to(device).requires_grad_(True)
+    o = mod(x)
+    assert tuple(o.shape) == (2,)
+    o.backward(torch.from_numpy(pkg.synth.normal((2,), SEED, name + "/g")).to(device))
+    assert_close(o, atoms_golden[name + "/y"], "D(x)", l2=1e-4, mx=1e-4)
+    dx = nchw(x.grad)
+    assert_close(dx[:, :, ::32, ::32], atoms_golden[name + "/dx_slice"], "dx slice", l2=1e-3, mx=1e-3)
+    assert_checksum(dx, atoms_golden[name + "/dx_ck"], "dx")
+    for n, p in mod.named_parameters():
+        if in_cancelled_bias(name + "." + n):
+            continue
+        assert_checksum(p.grad, atoms_golden[name + "/dck." + n], "d" + n)
+    sd = mod.state_dict()
+    np.testing.assert_allclose(sd["model.4.weight_u"].cpu().numpy(), atoms_golden[name + "/u"], rtol=1e-5)
+    assert_checksum(sd["model.4.weight_v"], atoms_golden[name + "/v_ck"], "v", tol=1e-4)
+
+
+# ------------------------------------------------------------------ conv blocks vs the oracle, more shapes
+ORACLE_CONV_CASES = [
+    # (cls, args, kwargs, xshape) — sizes the CPU oracle finishes in well under a second each
+    ("S", (64, 128), {}, (2, 64, 20, 12)),            # several K tiles, M tail (480 rows)
+    ("S", (32, 64), {}, (1, 32, 33, 17)),             # odd spatial sizes
+    ("D", (32, 64), {}, (2, 32, 16, 16)),             # unshuffle gather, K = 1152
+    ("D", (64, 128), {}, (1, 64, 32, 24)),
+    ("U", (128, 64), {}, (2, 128, 8, 8)),             # cin 32: the smallest real decoder conv
+    ("R", (64,), {}, (2, 64, 8, 8)),
+    ("S", (1024, 64), {}, (1, 1024, 16, 16)),         # the latent convs: K = 9216
+    ("S", (64, 1024), {}, (1, 64, 16, 16)),
+    ("CaSb", (3, 64, 7), {}, (1, 3, 40, 24)),         # encoder stem at full width
+    ("CaSb", (64, 3, 7), {"activation": "Identity", "use_norm": False}, (1, 64, 24, 40)),
+    ("CaSb", (64, 128, 4), {"stride": 2, "padding": 1, "activation": "LeakyReLU"}, (2, 64, 16, 24)),
+    ("CaSb", (3, 64, 4), {"stride": 2, "padding": 1, "activation": "LeakyReLU", "use_norm": False}, (2, 3, 32, 32)),
+    ("S", (8, 8), {}, (1, 8, 2, 2)),                  # smallest legal map for reflect pad 1
+    ("D", (8, 8), {}, (3, 8, 4, 4)),                  # bottleneck of a 64x64 input: 2x2 output maps
+]
+
+
+def _oracle_atom(oracle, cls, kwargs, x, P, pre):
+    if cls == "CaSb":
+        return oracle.casb(x, P, pre, kwargs.get("stride", 1), kwargs.get("padding", 3),
+                           kwargs.get("activation", "ReLU"), kwargs.get("use_norm", True))
+    return {"D": oracle.d_block, "U": oracle.u_block, "S": oracle.s_conv, "R": oracle.r_block}[cls](x, P, pre)
+
+
+@pytest.mark.parametrize("case", range(len(ORACLE_CONV_CASES)))
+def test_conv_blocks_match_oracle(case, pkg, oracle, device):
+    cls, args, kwargs, xshape = ORACLE_CONV_CASES[case]
+    key = f"oc{case}"
+    mod = getattr(pkg.Networks, cls)(*args, **kwargs)
+    P = load_synth(pkg, mod, key, ATOM_BIAS_STD, seed=SEED + 1)
+    P = {f"{key}.{k}": v.clone().requires_grad_(True) for k, v in P.items()}
+    x = pkg.synth.normal(xshape, SEED + 1, key + "/x")
+    xo = torch.from_numpy(x).requires_grad_(True)
+    yo = _oracle_atom(oracle, cls, kwargs, xo, P, key + ".")
+    g = pkg.synth.normal(tuple(yo.shape), SEED + 1, key + "/g")
+    yo.backward(torch.from_numpy(g))
+    y, dx, grads = run_module(mod, x, g, device)
+    assert_close(y, yo, f"{cls}{args} y")
+    assert_close(dx, xo.grad, f"{cls}{args} dx")
+    for k, v in grads.items():
+        ref = P[f"{key}.{k}"].grad
+        if ref.abs().max() < 1e-4 * max(1.0, yo.abs().max().item()):      # IN-cancelled bias: analytically zero
+            assert v.abs().max() < 1e-2
+            continue
+        assert_close(v, ref, f"{cls}{args} d{k}")
+
+
+def test_layout_round_trip_and_views(pkg, device):
+    ops = pkg.ops
+    for c in (3, 8):
+        x = torch.from_numpy(pkg.synth.normal((2, c, 5, 7), SEED, f"layout{c}")).to(device)
+        v = ops.to_nhwc(x)
+        assert tuple(v.shape) == tuple(x.shape) and ops.is_nhwc_view(v)
+        assert torch.equal(v.contiguous(), x)                       # logical view reads back the same values
+        assert ops.to_nhwc(v) is v                                  # already laid out: zero copy
+        assert torch.equal(ops.to_nchw_contiguous(v), x)
+        if c == 3:
+            assert ops.phys_of(v)[..., 3].abs().max().item() == 0.0    # pad channel is zero
+
+
+def test_device_rng_moments_and_reproducibility(pkg, device):
+    a = pkg.ops.randn((1 << 20,), device, seed=7, offset=0)
+    b = pkg.ops.randn((1 << 20,), device, seed=7, offset=0)
+    c = pkg.ops.randn((1 << 20,), device, seed=8, offset=0)
+    assert torch.equal(a, b) and not torch.equal(a, c)
+    assert abs(a.mean().item()) < 5e-3 and abs(a.std().item() - 1.0) < 5e-3
+    assert abs((a ** 4).mean().item() - 3.0) < 0.05
+    u = pkg.ops.rand_uniform((1 << 20,), device, seed=9)
+    assert 0.0 <= u.min().item() and u.max().item() < 1.0 and abs(u.mean().item() - 0.5) < 2e-3
+
+
+def test_fused_adam_matches_oracle_formula(pkg, oracle, device):
+    shapes = {"a.weight": (5, 3, 3, 3), "a.bias": (5,), "b.weight": (7, 5, 1, 1)}
+    sd = pkg.synth.state_dict_like(shapes, SEED, bias_std=0.1)
+    params = [torch.nn.Parameter(torch.from_numpy(v).to(device)) for v in sd.values()]
+    opt = pkg.optim.FusedAdam(params, lr=2e-4, betas=(0.5, 0.999))
+    P = {k: torch.from_numpy(v).clone() for k, v in sd.items()}
+    state = {}
+    for step in range(3):
+        grads = {k: torch.from_numpy(pkg.synth.normal(s, SEED, f"adam/{step}/{k}")) for k, s in shapes.items()}
+        opt.zero_grad()
+        for p, k in zip(params, shapes):
+            p.grad.copy_(grads[k].to(device))
+        opt.step()
+        oracle.adam_update(P, grads, state, list(shapes), 2e-4)
+    for p, k in zip(params, shapes):
+        assert_close(p.detach(), P[k], k, l2=1e-6, mx=1e-6)
+    st = opt.state_dict()
+    assert set(st["state"][0]) == {"step", "exp_avg", "exp_avg_sq"} and float(st["state"][0]["step"]) == 3.0
+    ref = torch.optim.Adam([torch.nn.Parameter(torch.zeros(s)) for s in shapes.values()], lr=2e-4, betas=(0.5, 0.999))
+    assert set(ref.state_dict()["param_groups"][0]) <= set(st["param_groups"][0])
+
+
+# ------------------------------------------------------------------ training steps vs the reference's own numbers
+def _check_metrics(got, ref, what, tol=1e-3):
+    assert list(got) == list(ref), f"{what}: metric keys/order {list(got)} vs {list(ref)}"
+    for k, v in ref.items():
+        assert abs(got[k] - v) <= tol * max(abs(v), 1e-6), f"{what}: {k} = {got[k]!r}, reference {v!r}"
+
+
+def _check_state(model, key, steps_golden, snap="@step1"):
+    params = {n: v for n, v in model.state_dict().items()}
+    grads = {n: p.grad for n, p in model.named_parameters()}
+    check_step_state(params, grads, key, steps_golden, LR, snap=snap)
+
+
+def test_autoencoder_steps_match_reference_golden(pkg, device, steps_golden, steps_meta):
+    key = "ae64"
+    model = pkg.Networks.Autoencoder()
+    load_synth(pkg, model, key, STEP_BIAS_STD)
+    model = model.to(device).train()
+    model.configure_optimizers(lr=LR)
+    model.configure_loss(**LAMBDAS)
+    for step in range(2):
+        x, _ = pkg.synth.batch(2, 64, SEED, step=step)
+        xb = torch.from_numpy(x).to(device)
+        if step == 0:
+            with torch.no_grad():
+                assert_close(nchw(model(xb))[:, :, ::4, ::4], steps_golden[key + "/out0"], "AE out", l2=1e-3)
+        m = model.training_step({"x": xb, "y": xb})
+        _check_metrics(m, steps_meta[key][step], f"{key} step {step}")
+        if step == 0:
+            _check_state(model, key, steps_golden)
+
+
+def test_vae_steps_match_reference_golden(pkg, device, steps_golden, steps_meta):
+    key = "vae64"
+    model = pkg.Networks.VariationalAutoencoder(latent_dim=64)
+    load_synth(pkg, model, key, STEP_BIAS_STD)
+    model = model.to(device).train()
+    model.configure_optimizers(lr=LR)
+    model.configure_loss(**LAMBDAS)
+    for step in range(2):
+        x, _ = pkg.synth.batch(2, 64, SEED, step=step)
+        xb = torch.from_numpy(x).to(device)
+        eps = [torch.from_numpy(e) for e in pkg.synth.eps_list(1, (2, 64, 4, 4), SEED, step=step)]
+        if step == 0:
+            with torch.no_grad():
+                pkg.ops.inject_eps(eps)
+                o, mu, lv = model(xb)
+            assert_close(nchw(o)[:, :, ::4, ::4], steps_golden[key + "/out0"], "VAE out", l2=1e-3)
+            assert_close(nchw(mu), steps_golden[key + "/mu0"], "mu", l2=1e-3)
+            assert_close(nchw(lv), steps_golden[key + "/logvar0"], "logvar", l2=1e-3)
+        pkg.ops.inject_eps(eps)
+        m = model.training_step({"x": xb, "y": xb})
+        _check_metrics(m, steps_meta[key][step], f"{key} step {step}")
+        if step == 0:
+            _check_state(model, key, steps_golden)
+
+
+@pytest.mark.parametrize("key,paired", [("cvg256_unpaired", False), ("cvg256_paired", True)])
+def test_cyclevaegan_step_matches_reference_golden(key, paired, pkg, device, steps_golden, steps_meta):
+    model = pkg.Networks.CycleVAEGAN(latent_dim=64, paired=paired)
+    load_synth(pkg, model, key, STEP_BIAS_STD)
+    model = model.to(device).train()
+    model.configure_optimizers(lr=LR)
+    model.configure_loss(**LAMBDAS)
+    x, y = pkg.synth.batch(1, 256, SEED, step=0)
+    xb, yb = torch.from_numpy(x).to(device), torch.from_numpy(y).to(device)
+    eps = [torch.from_numpy(e) for e in pkg.synth.eps_list(6, (1, 64, 16, 16), SEED, step=0)]
+    with torch.no_grad():
+        pkg.ops.inject_eps(eps)
+        fw = model(xb, yb)
+    assert len(fw) == 18
+    for nm, t in zip(("Gx", "FGx", "Fy", "GFy"), fw[:4]):
+        assert_close(nchw(t)[:, :, ::16, ::16], steps_golden[f"{key}/{nm}0"], nm, l2=1e-3)
+    assert_close(nchw(fw[4])[:, ::8], steps_golden[key + "/mu_x0"], "mu_x", l2=1e-3)
+    assert_close(nchw(fw[5])[:, ::8], steps_golden[key + "/logvar_x0"], "logvar_x", l2=1e-3)
+    assert_close(torch.stack([fw[12], fw[13], fw[14], fw[15]]), steps_golden[key + "/D0"], "D outputs", l2=1e-3)
+    pkg.ops.inject_eps(eps)
+    m = model.training_step({"x": xb, "y": yb})
+    _check_metrics(m, steps_meta[key][0], f"{key} step 0")
+    _check_state(model, key, steps_golden)
+
+
+def test_cyclevaegan_unconfigured_raises_like_the_reference(pkg, device):
+    model = pkg.Networks.CycleVAEGAN(paired=False)
+    with pytest.raises(ValueError, match="Loss functions have not been configured"):
+        model.training_step({"x": None, "y": None})
+    model.configure_loss()
+    with pytest.raises(ValueError, match="Optimizers have not been configured"):
+        model.training_step({"x": None, "y": None})
+    with pytest.raises(ValueError):
+        model.save_optimizer_states()

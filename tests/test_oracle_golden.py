@@ -1,0 +1,228 @@
+"""CPU: pin the oracle (oracle/vcg_oracle.py) against the reference's own outputs
+(tests/golden/*.npz, produced by tests/golden/make_golden.py from /root/reference)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import (SEED, assert_checksum, assert_close, check_step_state, in_cancelled_bias)
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+from cases import ATOM_BIAS_STD, ATOM_CASES, DISC_BIAS_STD, LAMBDAS, LR, STEP_BIAS_STD  # noqa: E402
+
+
+def _params(pkg, shapes, bias_std):
+    sd = pkg.synth.state_dict_like(shapes, SEED, bias_std=bias_std)
+    return {k: torch.from_numpy(v) for k, v in sd.items()}
+
+
+def _atom_shapes(name, cls, args):
+    if cls == "CaSb":
+        cin, cout, k = args
+        return {f"{name}.conv.weight": (cout, cin, k, k), f"{name}.conv.bias": (cout,)}
+    if cls == "D":
+        cin, cout = args
+        return {f"{name}.conv.weight": (cout, cin * 4, 3, 3), f"{name}.conv.bias": (cout,)}
+    if cls == "U":
+        cin, cout = args
+        return {f"{name}.conv.weight": (cout, cin // 4, 3, 3), f"{name}.conv.bias": (cout,)}
+    if cls == "S":
+        cin, cout = args
+        return {f"{name}.conv.weight": (cout, cin, 3, 3), f"{name}.conv.bias": (cout,)}
+    if cls == "R":
+        (c,) = args
+        return {f"{name}.conv1.weight": (c, c, 3, 3), f"{name}.conv1.bias": (c,),
+                f"{name}.conv2.weight": (c, c, 3, 3), f"{name}.conv2.bias": (c,)}
+    raise KeyError(cls)
+
+
+def oracle_atom(oracle, cls, kwargs, x, P, pre):
+    if cls == "CaSb":
+        return oracle.casb(x, P, pre, kwargs.get("stride", 1), kwargs.get("padding", 3),
+                           kwargs.get("activation", "ReLU"), kwargs.get("use_norm", True))
+    return {"D": oracle.d_block, "U": oracle.u_block, "S": oracle.s_conv, "R": oracle.r_block}[cls](x, P, pre)
+
+
+@pytest.mark.parametrize("name", list(ATOM_CASES))
+def test_oracle_atoms_match_reference(name, pkg, oracle, atoms_golden):
+    cls, args, kwargs, xshape, scale = ATOM_CASES[name]
+    P = _params(pkg, _atom_shapes(name, cls, args), ATOM_BIAS_STD)
+    for v in P.values():
+        v.requires_grad_(True)
+    x = torch.from_numpy(pkg.synth.normal(xshape, SEED, name + "/x") * scale).requires_grad_(True)
+    y = oracle_atom(oracle, cls, kwargs, x, P, name + ".")
+    g = torch.from_numpy(pkg.synth.normal(tuple(y.shape), SEED, name + "/g"))
+    y.backward(g)
+    assert_close(y, atoms_golden[name + "/y"], name + " y", l2=1e-5, mx=1e-4)
+    assert_close(x.grad, atoms_golden[name + "/dx"], name + " dx", l2=1e-5, mx=1e-4)
+    for k, v in P.items():
+        ref = atoms_golden[name + "/d." + k[len(name) + 1:]]
+        if in_cancelled_bias(k) or (cls == "CaSb" and kwargs.get("use_norm", True) and k.endswith("bias")):
+            assert np.abs(v.grad.numpy()).max() < 1e-4      # analytically zero
+            continue
+        assert_close(v.grad, ref, f"{name} d{k}", l2=1e-5, mx=1e-4)
+
+
+def test_oracle_vae_bottleneck_matches_reference(pkg, oracle, atoms_golden):
+    name = "veb"
+    shapes = {f"{name}.muConv.conv.weight": (8, 16, 3, 3), f"{name}.muConv.conv.bias": (8,),
+              f"{name}.logvarConv.0.conv.weight": (8, 16, 3, 3), f"{name}.logvarConv.0.conv.bias": (8,),
+              f"{name}.logvarConv.1.conv.weight": (8, 8, 3, 3), f"{name}.logvarConv.1.conv.bias": (8,)}
+    P = _params(pkg, shapes, ATOM_BIAS_STD)
+    for v in P.values():
+        v.requires_grad_(True)
+    x = torch.from_numpy(pkg.synth.normal((2, 16, 4, 6), SEED, name + "/x") * 6.0).requires_grad_(True)
+    eps = torch.from_numpy(pkg.synth.normal((2, 8, 4, 6), SEED, name + "/eps"))
+    z, mu, lv = oracle.variational_encoder_block(x, P, name + ".", eps)
+    gz, gm, gl = (torch.from_numpy(pkg.synth.normal(tuple(z.shape), SEED, name + "/" + s)) for s in ("gz", "gm", "gl"))
+    ((z * gz).sum() + (mu * gm).sum() + (lv * gl).sum()).backward()
+    assert atoms_golden[name + "/clamped_fraction"][0] > 0.05      # the clamp branch is exercised
+    assert_close(z, atoms_golden[name + "/z"], "z", l2=1e-5, mx=1e-4)
+    assert_close(mu, atoms_golden[name + "/mu"], "mu", l2=1e-5, mx=1e-4)
+    assert_close(lv, atoms_golden[name + "/logvar"], "logvar", l2=1e-5, mx=1e-4)
+    assert_close(x.grad, atoms_golden[name + "/dx"], "dx", l2=1e-5, mx=1e-4)
+    for k, v in P.items():
+        assert_close(v.grad, atoms_golden[name + "/d." + k[len(name) + 1:]], "d" + k, l2=1e-5, mx=1e-4)
+
+
+def test_oracle_losses_match_reference(pkg, oracle, atoms_golden):
+    G = atoms_golden
+    a = torch.from_numpy(pkg.synth.normal((2, 3, 8, 8), SEED, "loss/a")).requires_grad_(True)
+    b = torch.from_numpy(pkg.synth.normal((2, 3, 8, 8), SEED, "loss/b"))
+    l = oracle.l1(a, b)
+    l.backward()
+    assert abs(l.item() - G["loss/l1"][0]) < 1e-6
+    assert_close(a.grad, G["loss/l1_da"], "l1 grad", l2=1e-6, mx=1e-6)
+    mu = torch.from_numpy(pkg.synth.normal((2, 8, 4, 4), SEED, "loss/mu")).requires_grad_(True)
+    lv = torch.from_numpy(pkg.synth.normal((2, 8, 4, 4), SEED, "loss/lv") * 8.0).requires_grad_(True)
+    k = oracle.kl_loss(mu, lv)
+    k.backward()
+    assert abs(k.item() - G["loss/kl"][0]) <= 1e-6 * abs(G["loss/kl"][0])
+    assert_close(mu.grad, G["loss/kl_dmu"], "kl dmu", l2=1e-6, mx=1e-6)
+    assert_close(lv.grad, G["loss/kl_dlv"], "kl dlv", l2=1e-6, mx=1e-6)
+    d1 = torch.from_numpy(pkg.synth.normal((5,), SEED, "loss/d1")).requires_grad_(True)
+    d2 = torch.from_numpy(pkg.synth.normal((5,), SEED, "loss/d2")).requires_grad_(True)
+    tot, real, fake = oracle.gan_loss_generator(d1, d2)
+    tot.backward()
+    np.testing.assert_allclose([tot.item(), real.item(), fake.item()], G["loss/gan_g"], rtol=1e-6)
+    assert_close(d1.grad, G["loss/gan_g_d1"], "gan_g d1", l2=1e-6, mx=1e-6)
+    assert_close(d2.grad, G["loss/gan_g_d2"], "gan_g d2", l2=1e-6, mx=1e-6)
+    d1.grad = d2.grad = None
+    tot, real, fake = oracle.gan_loss_discriminator(d1, d2)
+    tot.backward()
+    np.testing.assert_allclose([tot.item(), real.item(), fake.item()], G["loss/gan_d"], rtol=1e-6)
+    assert_close(d1.grad, G["loss/gan_d_d1"], "gan_d d1", l2=1e-6, mx=1e-6)
+    assert_close(d2.grad, G["loss/gan_d_d2"], "gan_d d2", l2=1e-6, mx=1e-6)
+
+
+def _disc_shapes(pre):
+    s = {}
+    chans = [(3, 64), (64, 128), (128, 256), (256, 512)]
+    for i, (ci, co) in enumerate(chans):
+        s[f"{pre}model.{i}.conv.weight"] = (co, ci, 4, 4)
+        s[f"{pre}model.{i}.conv.bias"] = (co,)
+    s[f"{pre}model.4.bias"] = (1,)
+    s[f"{pre}model.4.weight_orig"] = (1, 512, 16, 16)
+    s[f"{pre}model.4.weight_u"] = (1,)
+    s[f"{pre}model.4.weight_v"] = (512 * 16 * 16,)
+    return s
+
+
+def test_oracle_discriminator_matches_reference(pkg, oracle, atoms_golden):
+    name = "disc"
+    P = _params(pkg, _disc_shapes(name + "."), DISC_BIAS_STD)
+    names = oracle.trainable_names(P)
+    for n in names:
+        P[n].requires_grad_(True)
+    x = torch.from_numpy(pkg.synth.uniform((2, 3, 256, 256), SEED, name + "/x")).requires_grad_(True)
+    sn = {}
+    o = oracle.discriminator(x, P, name + ".", True, sn)
+    g = torch.from_numpy(pkg.synth.normal((2,), SEED, name + "/g"))
+    o.backward(g)
+    assert_close(o, atoms_golden[name + "/y"], "D(x)", l2=1e-5, mx=1e-5)
+    assert_close(x.grad[:, :, ::32, ::32], atoms_golden[name + "/dx_slice"], "dx slice", l2=1e-4, mx=1e-4)
+    assert_checksum(x.grad, atoms_golden[name + "/dx_ck"], "dx", tol=1e-4)
+    for n in names:
+        if in_cancelled_bias(n):
+            continue
+        assert_checksum(P[n].grad, atoms_golden[name + "/dck." + n[len(name) + 1:]], "d" + n, tol=1e-4)
+    np.testing.assert_allclose(sn[name + ".model.4.weight_u"].numpy(), atoms_golden[name + "/u"], rtol=1e-6)
+    assert_checksum(sn[name + ".model.4.weight_v"], atoms_golden[name + "/v_ck"], "v", tol=1e-5)
+
+
+# ------------------------------------------------------------------------------------- steps
+def _model_shapes(pkg, key, ctor):
+    model = ctor()
+    return {f"{key}.{k}": tuple(v.shape) for k, v in model.state_dict().items()}
+
+
+def _check_metrics(got, ref, what, tol=1e-3):
+    assert set(got) == set(ref), f"{what}: metric keys {sorted(set(got) ^ set(ref))}"
+    for k, v in ref.items():
+        assert abs(got[k] - v) <= tol * max(abs(v), 1e-6), f"{what}: {k} = {got[k]!r}, reference {v!r}"
+
+
+def test_oracle_autoencoder_steps_match_reference(pkg, oracle, steps_golden, steps_meta):
+    key = "ae64"
+    P = _params(pkg, _model_shapes(pkg, key, pkg.Networks.Autoencoder), STEP_BIAS_STD)
+    P = {k[len(key) + 1:]: v for k, v in P.items()}
+    state = {}
+    for step in range(2):
+        x, _ = pkg.synth.batch(2, 64, SEED, step=step)
+        xb = torch.from_numpy(x)
+        if step == 0:
+            with torch.no_grad():
+                assert_close(oracle.autoencoder_forward(xb, P)[:, :, ::4, ::4], steps_golden[key + "/out0"], "AE out", l2=1e-4, mx=1e-3)
+        m, _, grads = oracle.autoencoder_step(P, state, xb, xb, LR)
+        _check_metrics(m, steps_meta[key][step], f"{key} step {step}", tol=1e-4)
+        if step == 0:
+            check_step_state(P, grads, key, steps_golden, LR, snap="@step1", tol=1e-3)
+    check_step_state(P, None, key, steps_golden, LR, nsteps=2)
+
+
+def test_oracle_vae_steps_match_reference(pkg, oracle, steps_golden, steps_meta):
+    key = "vae64"
+    P = _params(pkg, _model_shapes(pkg, key, lambda: pkg.Networks.VariationalAutoencoder(64)), STEP_BIAS_STD)
+    P = {k[len(key) + 1:]: v for k, v in P.items()}
+    state = {}
+    for step in range(2):
+        x, _ = pkg.synth.batch(2, 64, SEED, step=step)
+        xb = torch.from_numpy(x)
+        eps = torch.from_numpy(pkg.synth.eps_list(1, (2, 64, 4, 4), SEED, step=step)[0])
+        if step == 0:
+            with torch.no_grad():
+                o, mu, lv = oracle.vae_forward(xb, P, "", eps)
+            assert_close(o[:, :, ::4, ::4], steps_golden[key + "/out0"], "VAE out", l2=1e-4, mx=1e-3)
+            assert_close(mu, steps_golden[key + "/mu0"], "mu", l2=1e-4, mx=1e-3)
+            assert_close(lv, steps_golden[key + "/logvar0"], "logvar", l2=1e-4, mx=1e-3)
+        m, _, grads = oracle.vae_step(P, state, xb, xb, eps, LR, LAMBDAS["lambda_kl"])
+        _check_metrics(m, steps_meta[key][step], f"{key} step {step}", tol=1e-4)
+        if step == 0:
+            check_step_state(P, grads, key, steps_golden, LR, snap="@step1", tol=1e-3)
+    check_step_state(P, None, key, steps_golden, LR, nsteps=2)
+
+
+@pytest.mark.parametrize("key,paired,nsteps", [("cvg256_unpaired", False, 2), ("cvg256_paired", True, 1)])
+def test_oracle_cyclevaegan_steps_match_reference(key, paired, nsteps, pkg, oracle, steps_golden, steps_meta):
+    torch.set_num_threads(max(1, min(8, os.cpu_count() or 1)))
+    P = _params(pkg, _model_shapes(pkg, key, lambda: pkg.Networks.CycleVAEGAN(64, paired)), STEP_BIAS_STD)
+    P = {k[len(key) + 1:]: v for k, v in P.items()}
+    state = {}
+    for step in range(nsteps):
+        x, y = pkg.synth.batch(1, 256, SEED, step=step)
+        xb, yb = torch.from_numpy(x), torch.from_numpy(y)
+        eps = [torch.from_numpy(e) for e in pkg.synth.eps_list(6, (1, 64, 16, 16), SEED, step=step)]
+        m, outs, g_grads, d_grads = oracle.cyclevaegan_step(P, state, xb, yb, eps, LR, paired, LAMBDAS["lambda_cycle"],
+                                                LAMBDAS["lambda_gan"], LAMBDAS["lambda_kl"], LAMBDAS["lambda_identity"])
+        if step == 0:
+            for nm in ("Gx", "FGx", "Fy", "GFy"):
+                assert_close(outs[nm][:, :, ::16, ::16], steps_golden[f"{key}/{nm}0"], nm, l2=1e-4, mx=1e-3)
+            assert_close(outs["mu_x"][:, ::8], steps_golden[key + "/mu_x0"], "mu_x", l2=1e-4, mx=1e-3)
+            assert_close(outs["logvar_x"][:, ::8], steps_golden[key + "/logvar_x0"], "logvar_x", l2=1e-4, mx=1e-3)
+        # GAN dynamics amplify rounding step over step: the contract is single-step
+        # parity from an identical snapshot; the second step gets a looser bound
+        _check_metrics(m, steps_meta[key][step], f"{key} step {step}", tol=1e-3 if step == 0 else 2e-2)
+        if step == 0:
+            check_step_state(P, {**g_grads, **d_grads}, key, steps_golden, LR, snap="@step1", tol=1e-3)

@@ -1,0 +1,608 @@
+"""MI355X-native networks behind the reference's `Networks.py` module surface.
+
+Class names, constructor signatures, attribute names, `forward` return order, metric keys
+and state_dict keys/shapes follow the reference (file:line cited per class) so a
+reference checkpoint loads and `train.py` drives these classes unchanged.  Underneath,
+every block is a fused HIP launch sequence (`ops.conv_block`): implicit-GEMM conv on the
+fp32 matrix core with bias/activation epilogue, two-stage InstanceNorm statistics, and a
+normalise(+activation)(+residual)(+PixelShuffle) store.  torch modules (`nn.Conv2d`,
+`spectral_norm`) are used only as parameter containers — their forwards are never run.
+
+Tensors crossing module boundaries keep the logical (N, C, H, W) shape and are stored
+NHWC (pitch 4 for 3-channel images); NCHW-contiguous inputs are converted on entry.
+"""
+import math
+
+import torch
+import torch.nn as nn
+from torch.nn.utils import spectral_norm
+
+from . import ops
+from .Losses import (CycleConsistencyLoss, GANLossDiscriminator, GANLossGenerator, IdentityLoss,
+                     KLDivergenceLoss, TranslationLoss)
+from .optim import FusedAdam
+
+_ACTS = {"ReLU": ops.ACT_RELU, "LeakyReLU": ops.ACT_LEAKY, "Identity": ops.ACT_NONE}
+
+
+def _kaiming_relu_init(module):
+    """Kaiming-normal fan_out (gain sqrt 2), zero bias: reference Networks.py:168-178, 1893-1903."""
+    if isinstance(module, nn.Conv2d):
+        nn.init.kaiming_normal_(module.weight, mode="fan_out", nonlinearity="relu")
+        if module.bias is not None:
+            nn.init.zeros_(module.bias)
+
+
+# --------------------------------------------------------------------------- atoms
+class CaSb(nn.Module):
+    """reflect conv -> [InstanceNorm] -> activation  (reference Networks.py:57-81)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=3, activation="ReLU", use_norm=True):
+        super().__init__()
+        if activation not in ("ReLU", "LeakyReLU", "Tanh", "Sigmoid", "Identity"):
+            raise NotImplementedError("Activation not implemented")
+        self.conv = nn.Conv2d(in_channels, out_channels, kernel_size=kernel_size, stride=stride, padding=padding,
+                              padding_mode="reflect")
+        self.norm = nn.InstanceNorm2d(out_channels)
+        self.activation_name = activation
+        self.use_norm = use_norm
+        act = _ACTS.get(activation)
+        if use_norm:
+            self._spec = ops.ConvSpec(in_channels, out_channels, kernel_size, stride, padding, True, 1,
+                                      ops.ACT_NONE, True, act if act is not None else 0)
+        else:
+            self._spec = ops.ConvSpec(in_channels, out_channels, kernel_size, stride, padding, True, 1,
+                                      act if act is not None else 0, False)
+
+    def forward(self, x):
+        if self.activation_name not in _ACTS:
+            raise NotImplementedError(f"{self.activation_name} epilogue is not built: the training path uses ReLU/LeakyReLU/Identity only")
+        return ops.conv_block(x, self.conv.weight, self.conv.bias, self._spec)
+
+
+class D(nn.Module):
+    """PixelUnshuffle(2) -> reflect conv3x3 -> ReLU -> InstanceNorm  (reference Networks.py:83-96).
+    The unshuffle is folded into the conv's gather addresses (K ordered (kh,kw,i,j,c))."""
+
+    def __init__(self, in_channels, out_channels):
+        super().__init__()
+        self.PixelUnshuffle = nn.PixelUnshuffle(downscale_factor=2)
+        self.conv = nn.Conv2d(in_channels * 4, out_channels, kernel_size=3, stride=1, padding=1, padding_mode="reflect")
+        self.norm = nn.InstanceNorm2d(out_channels)
+        self.activation = nn.ReLU(inplace=False)
+        self._spec = ops.ConvSpec(in_channels * 4, out_channels, 3, 1, 1, True, 2, ops.ACT_RELU, True)
+
+    def forward(self, x):
+        return ops.conv_block(x, self.conv.weight, self.conv.bias, self._spec)
+
+
+class R(nn.Module):
+    """x + IN(conv(IN(ReLU(conv(x)))))  (reference Networks.py:98-116)."""
+
+    def __init__(self, out_channels):
+        super().__init__()
+        c = out_channels
+        self.conv1 = nn.Conv2d(c, c, kernel_size=3, stride=1, padding=1, padding_mode="reflect")
+        self.norm1 = nn.InstanceNorm2d(c)
+        self.activation1 = nn.ReLU(inplace=False)
+        self.conv2 = nn.Conv2d(c, c, kernel_size=3, stride=1, padding=1, padding_mode="reflect")
+        self.norm2 = nn.InstanceNorm2d(c)
+        self._spec1 = ops.ConvSpec(c, c, 3, 1, 1, True, 1, ops.ACT_RELU, True)
+        self._spec2 = ops.ConvSpec(c, c, 3, 1, 1, True, 1, ops.ACT_NONE, True)
+
+    def forward(self, x):
+        x = ops.to_nhwc(x)
+        h = ops.conv_block(x, self.conv1.weight, self.conv1.bias, self._spec1)
+        return ops.conv_block(h, self.conv2.weight, self.conv2.bias, self._spec2, residual=x)
+
+
+class U(nn.Module):
+    """PixelShuffle(2) -> reflect conv3x3 -> ReLU -> InstanceNorm  (reference Networks.py:118-131).
+
+    `pre_shuffled`: the producer already stored its output through the shuffle.
+    `shuffle_out`: store this block's output through the NEXT block's PixelShuffle."""
+
+    def __init__(self, in_channels, out_channels):
+        super().__init__()
+        self.PixelShuffle = nn.PixelShuffle(upscale_factor=2)
+        self.conv = nn.Conv2d(in_channels // 4, out_channels, kernel_size=3, stride=1, padding=1, padding_mode="reflect")
+        self.norm = nn.InstanceNorm2d(out_channels)
+        self.activation = nn.ReLU(inplace=False)
+        self._spec = ops.ConvSpec(in_channels // 4, out_channels, 3, 1, 1, True, 1, ops.ACT_RELU, True)
+        self._spec_shuf = None
+        if out_channels % 16 == 0:
+            self._spec_shuf = ops.ConvSpec(in_channels // 4, out_channels, 3, 1, 1, True, 1, ops.ACT_RELU, True,
+                                           ops.ACT_NONE, True)
+
+    def forward(self, x, pre_shuffled=False, shuffle_out=False):
+        if not pre_shuffled:
+            x = ops.pixel_shuffle(x)
+        spec = self._spec_shuf if shuffle_out else self._spec
+        if spec is None:
+            raise RuntimeError("shuffle_out needs out_channels % 16 == 0")
+        return ops.conv_block(x, self.conv.weight, self.conv.bias, spec)
+
+
+class S(nn.Module):
+    """bare reflect conv3x3  (reference Networks.py:133-140)."""
+
+    def __init__(self, in_channels, out_channels):
+        super().__init__()
+        self.conv = nn.Conv2d(in_channels, out_channels, kernel_size=3, stride=1, padding=1, padding_mode="reflect")
+        self._spec = ops.ConvSpec(in_channels, out_channels, 3, 1, 1, True, 1)
+
+    def forward(self, x):
+        return ops.conv_block(x, self.conv.weight, self.conv.bias, self._spec)
+
+
+class L(S):
+    """bare reflect conv3x3  (reference Networks.py:142-149)."""
+
+
+# --------------------------------------------------------------------------- molecules
+class Encoder(nn.Module):
+    """3 -> 1024 channels at 1/16 resolution  (reference Networks.py:154-181)."""
+
+    def __init__(self):
+        super().__init__()
+        self.model = nn.Sequential(CaSb(3, 64, kernel_size=7, stride=1), D(64, 128), D(128, 256), D(256, 512),
+                                   D(512, 1024), R(1024))
+        self.apply(self._init_weights)
+
+    def _init_weights(self, module):
+        _kaiming_relu_init(module)
+
+    def forward(self, x):
+        return self.model(ops.to_nhwc(x))
+
+
+class Decoder(nn.Module):
+    """mirror of Encoder  (reference Networks.py:183-211).  U->U hand-offs are stored pre-shuffled."""
+
+    def __init__(self):
+        super().__init__()
+        self.model = nn.Sequential(R(1024), U(1024, 512), U(512, 256), U(256, 128), U(128, 64),
+                                   CaSb(64, 3, kernel_size=7, stride=1, activation="Identity", use_norm=False))
+        self.apply(self._init_weights)
+
+    def _init_weights(self, module):
+        _kaiming_relu_init(module)
+
+    def forward(self, x):
+        layers = list(self.model)
+        out = ops.to_nhwc(x)
+        pre = False
+        for i, layer in enumerate(layers):
+            if isinstance(layer, U):
+                nxt = layers[i + 1] if i + 1 < len(layers) else None
+                fuse = isinstance(nxt, U) and layer._spec_shuf is not None
+                out = layer(out, pre_shuffled=pre, shuffle_out=fuse)
+                pre = fuse
+            else:
+                out = layer(out)
+                pre = False
+        return out
+
+
+class VariationalEncoderBlock(nn.Module):
+    """mu / logvar convs, clamp, z = mu + eps * exp(0.5 logvar)  (reference Networks.py:214-227)."""
+
+    def __init__(self, in_channels, latent_dim=64):
+        super().__init__()
+        self.muConv = L(in_channels, latent_dim)
+        self.logvarConv = nn.Sequential(S(in_channels, latent_dim), S(latent_dim, latent_dim))
+        self.latent_dim = latent_dim
+
+    def forward(self, x):
+        x = ops.to_nhwc(x)
+        mu = self.muConv(x)
+        logvar = self.logvarConv(x)
+        eps = ops.next_eps(mu.shape, mu.device)
+        z, logvar = ops.reparameterize(mu, logvar, eps)
+        return z, mu, logvar
+
+
+class VariationalDecoderBlock(nn.Module):
+    """latent -> 1024 channels  (reference Networks.py:230-237)."""
+
+    def __init__(self, latent_dim=64, out_channels=1024):
+        super().__init__()
+        self.conv = S(latent_dim, out_channels)
+
+    def forward(self, z):
+        return self.conv(z)
+
+
+class Discriminator(nn.Module):
+    """4x (conv4x4 s2 [+IN] + LeakyReLU 0.2) + spectral-normed 16x16 conv -> one scalar per image
+    (reference Networks.py:240-269)."""
+
+    def __init__(self):
+        super().__init__()
+        self.model = nn.Sequential(
+            CaSb(3, 64, kernel_size=4, stride=2, padding=1, activation="LeakyReLU", use_norm=False),
+            CaSb(64, 128, kernel_size=4, stride=2, padding=1, activation="LeakyReLU"),
+            CaSb(128, 256, kernel_size=4, stride=2, padding=1, activation="LeakyReLU"),
+            CaSb(256, 512, kernel_size=4, stride=2, padding=1, activation="LeakyReLU"),
+            spectral_norm(nn.Conv2d(512, 1, kernel_size=16, stride=1, padding=0)),
+        )
+        self.apply(self._init_weights)
+
+    def _init_weights(self, module):
+        if isinstance(module, nn.Conv2d):
+            nn.init.kaiming_normal_(module.weight, mode="fan_out", nonlinearity="leaky_relu", a=0.2)
+            if module.bias is not None:
+                nn.init.zeros_(module.bias)
+
+    def forward(self, x):
+        x = ops.to_nhwc(x)
+        layers = list(self.model)
+        for blk in layers[:-1]:
+            x = blk(x)
+        head = layers[-1]
+        return ops.fullmap_sn_conv(x, head.weight_orig, head.bias, head.weight_u, head.weight_v, self.training)
+
+
+# --------------------------------------------------------------------------- composites
+def _metrics_to_host(named, reducer=None):
+    """One device->host copy for all the step's scalars (the reference does one .item() each).
+    Under data parallelism the scalars are first averaged over ranks (= the global-batch means)."""
+    keys = list(named.keys())
+    vec = torch.stack([named[k].detach().reshape(()) for k in keys])
+    if reducer is not None:
+        vec = reducer.average_metrics(vec)
+    return dict(zip(keys, vec.tolist()))
+
+
+def _reduced_step(optimizer, reducer):
+    """optimizer.step(), preceded by the data-parallel gradient exchange when one is attached."""
+    if reducer is not None:
+        reducer.start(optimizer)
+        reducer.finish(optimizer)
+    optimizer.step()
+
+
+class _OptimizerStatesMixin:
+    _opt_names = ("optimizer",)
+
+    def save_optimizer_states(self):
+        out = {}
+        for name in self._opt_names:
+            opt = getattr(self, name)
+            if opt is None:
+                raise ValueError("Optimizer has not been configured yet." if len(self._opt_names) == 1
+                                 else "Optimizers have not been configured yet.")
+            out[name] = opt.state_dict()
+        return out
+
+    def load_optimizer_states(self, states):
+        for name in self._opt_names:
+            if getattr(self, name) is None:
+                raise ValueError("Optimizer has not been configured yet." if len(self._opt_names) == 1
+                                 else "Optimizers have not been configured yet.")
+        for name in self._opt_names:
+            if name not in states:
+                raise KeyError(f"{name} state not found in states")
+            getattr(self, name).load_state_dict(states[name])
+
+
+class Autoencoder(_OptimizerStatesMixin, nn.Module):
+    """Encoder -> Decoder, L1 loss, one Adam  (reference Networks.py:276-413)."""
+
+    def __init__(self):
+        super().__init__()
+        self.encoder = Encoder()
+        self.decoder = Decoder()
+        self.optimizer = None
+        self.grad_reducer = None
+        self.loss_fn = None
+        self.apply(self._init_weights)
+
+    def _init_weights(self, module):
+        _kaiming_relu_init(module)
+
+    def forward(self, x):
+        return self.decoder(self.encoder(x))
+
+    def configure_optimizers(self, lr=1e-4, betas=(0.5, 0.999), decoder_only=False):
+        params = self.decoder.parameters() if decoder_only else self.parameters()
+        self.optimizer = FusedAdam(params, lr=lr, betas=betas)
+        return self.optimizer
+
+    def configure_loss(self, **kwargs):
+        self.loss_fn = TranslationLoss()
+
+    def training_step(self, batch):
+        if self.loss_fn is None:
+            raise ValueError("Loss function has not been configured yet.")
+        if self.optimizer is None:
+            raise ValueError("Optimizer has not been configured yet.")
+        x, y = ops.to_nhwc(batch["x"]), ops.to_nhwc(batch["y"])
+        output = self(x)
+        loss_trans = self.loss_fn(output, y)
+        value = float(loss_trans)                      # the reference's isnan/isinf guard syncs here too (:357)
+        if math.isnan(value) or math.isinf(value):
+            print("NaN or Inf detected in loss during training step; skipping the update.")
+            self.optimizer.zero_grad()
+            return {"nan_detected": True, "G_loss": float("nan"), "loss_trans": float("nan"), "total_loss": float("nan")}
+        self.optimizer.zero_grad()
+        loss_trans.backward()
+        _reduced_step(self.optimizer, self.grad_reducer)
+        return {"G_loss": value, "loss_trans": value, "total_loss": value}
+
+    def validation_step(self, batch):
+        if self.loss_fn is None:
+            raise ValueError("Loss function has not been configured yet.")
+        with torch.no_grad():
+            x, y = ops.to_nhwc(batch["x"]), ops.to_nhwc(batch["y"])
+            output = self(x)
+            value = float(self.loss_fn(output, y))
+            return {"G_loss": value, "total_loss": value, "loss_trans": value, "Gx": output}
+
+
+class VariationalAutoencoder(_OptimizerStatesMixin, nn.Module):
+    """Encoder -> VAE bottleneck -> Decoder, L1 + lambda_kl * KL  (reference Networks.py:855-988)."""
+
+    def __init__(self, latent_dim=64):
+        super().__init__()
+        self.encoder = Encoder()
+        self.variational_encoder_block = VariationalEncoderBlock(in_channels=1024, latent_dim=latent_dim)
+        self.variational_decoder_block = VariationalDecoderBlock(latent_dim=latent_dim, out_channels=1024)
+        self.decoder = Decoder()
+        self.optimizer = None
+        self.grad_reducer = None
+        self.loss_trans_fn = None
+        self.loss_kl_fn = None
+        self.lambda_kl = 0
+        self.apply(self._init_weights)
+
+    def _init_weights(self, module):
+        _kaiming_relu_init(module)
+
+    def forward(self, x):
+        encoded = self.encoder(x)
+        z, mu, logvar = self.variational_encoder_block(encoded)
+        Gx = self.decoder(self.variational_decoder_block(z))
+        return Gx, mu, logvar
+
+    def configure_optimizers(self, lr=1e-4, betas=(0.5, 0.999)):
+        self.optimizer = FusedAdam(self.parameters(), lr=lr, betas=betas)
+        return self.optimizer
+
+    def configure_loss(self, **kwargs):
+        self.loss_trans_fn = TranslationLoss()
+        self.loss_kl_fn = KLDivergenceLoss()
+        self.lambda_kl = kwargs.get("lambda_kl", 1e-5)
+
+    def _check_configured(self):
+        if self.optimizer is None:
+            raise ValueError("Optimizer has not been configured yet.")
+        if self.loss_trans_fn is None:
+            raise ValueError("Translation loss function has not been configured yet.")
+        if self.loss_kl_fn is None:
+            raise ValueError("KL divergence loss function has not been configured yet.")
+
+    def _losses(self, batch):
+        x, y = ops.to_nhwc(batch["x"]), ops.to_nhwc(batch["y"])
+        output, mu, logvar = self(x)
+        loss_trans = self.loss_trans_fn(output, y)
+        loss_kl = self.loss_kl_fn(mu, logvar)
+        G_loss = ops.weighted_sum([loss_trans, loss_kl], [1.0, self.lambda_kl])
+        return output, G_loss, loss_trans, loss_kl
+
+    def training_step(self, batch):
+        self._check_configured()
+        _, G_loss, loss_trans, loss_kl = self._losses(batch)
+        self.optimizer.zero_grad()
+        G_loss.backward()
+        _reduced_step(self.optimizer, self.grad_reducer)
+        return _metrics_to_host({"G_loss": G_loss, "loss_trans": loss_trans, "loss_kl": loss_kl}, self.grad_reducer)
+
+    def validation_step(self, batch):
+        self._check_configured()
+        with torch.no_grad():
+            output, G_loss, loss_trans, loss_kl = self._losses(batch)
+            m = _metrics_to_host({"G_loss": G_loss, "loss_trans": loss_trans, "loss_kl": loss_kl})
+            m["Gx"] = output
+            return m
+
+
+class CycleVAEGAN(nn.Module):
+    """Two VAEs (G: X->Y, F: Y->X) + two discriminators; cycle + LSGAN + KL (+identity if paired);
+    alternating G then D update  (reference Networks.py:1872-2150).
+
+    Differences from the reference are work that cannot change any result:
+      * unpaired mode does not compute G(y), F(x) inside training_step (their outputs feed only
+        the identity loss, reference :2016-2018); their eps draws are still consumed;
+      * the discriminators run ONCE per step: the G-phase backward takes only the data gradient
+        and the D-phase backward takes the weight gradients from the same saved activations
+        (the reference recomputes four D forwards at :2032-2035 with unchanged D weights, and
+        discards the D weight gradients of its G-phase backward at :2025).
+    """
+
+    def __init__(self, latent_dim=64, paired=True):
+        super().__init__()
+        self.F = VariationalAutoencoder(latent_dim)
+        self.G = VariationalAutoencoder(latent_dim)
+        self.DX = Discriminator()
+        self.DY = Discriminator()
+        self.paired = paired
+        self.apply(self._init_weights)
+        self.debug_mode = False
+        self.debug_info = {}
+        self.optimizer_G = None
+        self.optimizer_D = None
+        self.loss_cycle = None
+        self.loss_gan_gen = None
+        self.loss_gan_disc = None
+        self.loss_identity = None
+        self.loss_kl = None
+        # data-parallel hook: set by parallel.attach(); called as reducer(phase, optimizer)
+        self.grad_reducer = None
+
+    def _init_weights(self, module):
+        _kaiming_relu_init(module)
+
+    def enable_debug_mode(self, enabled=True):
+        self.debug_mode = enabled
+
+    def forward(self, x, y):
+        x, y = ops.to_nhwc(x), ops.to_nhwc(y)
+        Gx, mu_x, logvar_x = self.G(x)
+        Gy, _, _ = self.G(y)
+        FGx, mu_FGx, logvar_FGx = self.F(Gx)
+        Fy, mu_y, logvar_y = self.F(y)
+        Fx, _, _ = self.F(x)
+        GFy, mu_GFy, logvar_GFy = self.G(Fy)
+        DYGx = self.DY(Gx)
+        DXFy = self.DX(Fy)
+        DXx = self.DX(x)
+        DYy = self.DY(y)
+        return (Gx, FGx, Fy, GFy, mu_x, logvar_x, mu_FGx, logvar_FGx, mu_y, logvar_y, mu_GFy, logvar_GFy,
+                DYGx, DXFy, DXx, DYy, Gy, Fx)
+
+    def configure_optimizers(self, lr=1e-4, betas=(0.5, 0.999)):
+        self.optimizer_G = FusedAdam(list(self.F.parameters()) + list(self.G.parameters()), lr=lr, betas=betas)
+        self.optimizer_D = FusedAdam(list(self.DX.parameters()) + list(self.DY.parameters()), lr=lr, betas=betas)
+        return self.optimizer_G, self.optimizer_D
+
+    def save_optimizer_states(self):
+        if self.optimizer_G is None or self.optimizer_D is None:
+            raise ValueError("Optimizers have not been configured yet.")
+        return {"optimizer_G": self.optimizer_G.state_dict(), "optimizer_D": self.optimizer_D.state_dict()}
+
+    def load_optimizer_states(self, states):
+        if self.optimizer_G is None or self.optimizer_D is None:
+            raise ValueError("Optimizers have not been configured yet.")
+        for name in ("optimizer_G", "optimizer_D"):
+            if name not in states:
+                raise KeyError(f"{name} state not found in states")
+        self.optimizer_G.load_state_dict(states["optimizer_G"])
+        self.optimizer_D.load_state_dict(states["optimizer_D"])
+
+    def configure_loss(self, **kwargs):
+        self.loss_cycle = CycleConsistencyLoss()
+        self.loss_gan_gen = GANLossGenerator()
+        self.loss_gan_disc = GANLossDiscriminator()
+        if self.paired:
+            self.loss_identity = IdentityLoss()
+        self.loss_kl = KLDivergenceLoss()
+        self.lambda_gan = kwargs.get("lambda_gan", 1.0)
+        self.lambda_identity = kwargs.get("lambda_identity", 5.0)
+        self.lambda_cycle = kwargs.get("lambda_cycle", 10.0)
+        self.lambda_kl = kwargs.get("lambda_kl", 1e-5)
+
+    def _check_configured(self, need_opt=True):
+        if self.loss_cycle is None or self.loss_gan_gen is None or self.loss_gan_disc is None or self.loss_kl is None:
+            raise ValueError("Loss functions have not been configured yet.")
+        if self.paired and self.loss_identity is None:
+            raise ValueError("Identity loss not configured for paired mode.")
+        if need_opt and (self.optimizer_G is None or self.optimizer_D is None):
+            raise ValueError("Optimizers have not been configured yet.")
+
+    def _skip_vae(self, ref_shape_src, vae):
+        """Advance the eps stream past a VAE forward that is not computed."""
+        n, _, h, w = ref_shape_src.shape
+        lat = vae.variational_encoder_block.latent_dim
+        ops.next_eps((n, lat, h // 16, w // 16), ref_shape_src.device, skip=True)
+
+    def _generator_losses(self, x, y):
+        """Forward of both generators and everything G_loss needs (reference :1997-2018)."""
+        Gx, mu_x, lv_x = self.G(x)
+        if self.paired:
+            Gy, _, _ = self.G(y)
+        else:
+            Gy = None
+            self._skip_vae(y, self.G)
+        FGx, mu_FGx, lv_FGx = self.F(Gx)
+        Fy, mu_y, lv_y = self.F(y)
+        if self.paired:
+            Fx, _, _ = self.F(x)
+        else:
+            Fx = None
+            self._skip_vae(x, self.F)
+        GFy, mu_GFy, lv_GFy = self.G(Fy)
+        DYGx = self.DY(Gx)
+        DXFy = self.DX(Fy)
+        DXx = self.DX(x)
+        DYy = self.DY(y)
+
+        t = {}
+        t["loss_cycle"] = self.loss_cycle(x, y, FGx, GFy)
+        t["loss_gan_g_x_fake"], t["d_x_fake_mean"] = ops.mse_const(DXFy, 1.0)
+        t["loss_gan_g_y_fake"], t["d_y_fake_mean"] = ops.mse_const(DYGx, 1.0)
+        t["loss_gan_g_x_real"], t["d_x_real_mean"] = ops.mse_const(DXx, 0.0)
+        t["loss_gan_g_y_real"], t["d_y_real_mean"] = ops.mse_const(DYy, 0.0)
+        t["loss_gan_g"] = ops.weighted_sum([t["loss_gan_g_x_fake"], t["loss_gan_g_y_fake"]], [1.0, 1.0])
+        t["loss_kl"] = ops.weighted_sum([self.loss_kl(mu_x, lv_x), self.loss_kl(mu_FGx, lv_FGx),
+                                         self.loss_kl(mu_y, lv_y), self.loss_kl(mu_GFy, lv_GFy)], [1.0] * 4)
+        terms = [t["loss_cycle"], t["loss_gan_g"], t["loss_kl"]]
+        weights = [self.lambda_cycle, self.lambda_gan, self.lambda_kl]
+        if self.paired:
+            t["loss_identity"] = self.loss_identity(x, y, Fx, Gy)
+            terms.append(t["loss_identity"])
+            weights.append(self.lambda_identity)
+        t["G_loss"] = ops.weighted_sum(terms, weights)
+        # discriminator objective on the SAME discriminator outputs (reference :2038-2040)
+        t["D_loss_x_real"], _ = ops.mse_const(DXx, 1.0)
+        t["D_loss_x_fake"], _ = ops.mse_const(DXFy, 0.0)
+        t["D_loss_y_real"], _ = ops.mse_const(DYy, 1.0)
+        t["D_loss_y_fake"], _ = ops.mse_const(DYGx, 0.0)
+        t["D_loss"] = ops.weighted_sum([t["D_loss_x_real"], t["D_loss_x_fake"], t["D_loss_y_real"], t["D_loss_y_fake"]],
+                                       [1.0] * 4)
+        return t, Gx, Fy
+
+    _METRIC_KEYS = ("G_loss", "D_loss", "D_loss_x_real", "D_loss_x_fake", "D_loss_y_real", "D_loss_y_fake",
+                    "loss_cycle", "loss_gan_g", "loss_gan_g_x_real", "loss_gan_g_x_fake", "loss_gan_g_y_real",
+                    "loss_gan_g_y_fake", "loss_kl")
+    _MEAN_KEYS = ("d_x_real_mean", "d_x_fake_mean", "d_y_real_mean", "d_y_fake_mean")
+
+    def _metrics(self, t, with_means):
+        keys = list(self._METRIC_KEYS) + (list(self._MEAN_KEYS) if with_means else [])
+        if self.paired:
+            keys.append("loss_identity")
+        host = _metrics_to_host({k: t[k] for k in keys}, self.grad_reducer if with_means else None)
+        out = {"total_loss": host["G_loss"] + host["D_loss"]}
+        out.update(host)
+        return out
+
+    def training_step(self, batch):
+        self._check_configured()
+        x, y = ops.to_nhwc(batch["x"]), ops.to_nhwc(batch["y"])
+        g_params = self.optimizer_G.params
+        d_params = self.optimizer_D.params
+
+        red = self.grad_reducer
+        self.optimizer_G.zero_grad()
+        t, _, _ = self._generator_losses(x, y)
+        # generator gradients reach F and G only (the discriminators contribute their data gradient)
+        with ops.no_wgrad(d_params):
+            t["G_loss"].backward(inputs=g_params, retain_graph=True)
+        if red is not None:
+            red.start(self.optimizer_G)          # F+G all-reduce runs under the D backward below
+        # discriminator gradients from the same activations reach DX and DY only — what detaching
+        # G(x), F(y) achieves in the reference (:2028-2029).  Neither this backward nor D_loss reads a
+        # generator parameter, so running it before optimizer_G.step() changes nothing.
+        self.optimizer_D.zero_grad()
+        with ops.no_dgrad([self.DX.model[0]._spec, self.DY.model[0]._spec]):
+            t["D_loss"].backward(inputs=d_params)
+        if red is not None:
+            red.start(self.optimizer_D)
+            red.finish(self.optimizer_G)
+        self.optimizer_G.step()
+        if red is not None:
+            red.finish(self.optimizer_D)
+        self.optimizer_D.step()
+        return self._metrics(t, with_means=True)
+
+    def validation_step(self, batch):
+        self._check_configured(need_opt=False)
+        with torch.no_grad():
+            paired = self.paired
+            x, y = ops.to_nhwc(batch["x"]), ops.to_nhwc(batch["y"])
+            t, Gx, Fy = self._generator_losses(x, y)
+            m = self._metrics(t, with_means=False)
+            m["Gx"] = Gx.detach()
+            m["Fy"] = Fy.detach()
+            assert paired == self.paired
+            return m

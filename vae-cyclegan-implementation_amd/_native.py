@@ -1,0 +1,111 @@
+"""ctypes binding of libvcg.so (the C ABI declared in include/vcg.h).
+
+There is no CPU or eager-PyTorch fallback: if the shared library is missing or a call
+fails, a RuntimeError is raised.  `build()` compiles the HIP sources for gfx950 in-tree.
+"""
+import ctypes
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+LIB_PATH = os.path.join(_HERE, "libvcg.so")
+SOURCES = ["conv_igemm.hip", "norm.hip", "misc.hip"]
+HEADER = os.path.join(os.path.dirname(_HERE), "include", "vcg.h")
+
+_c = ctypes
+_P = _c.c_void_p
+_I = _c.c_int
+_Z = _c.c_size_t
+_F = _c.c_float
+_U64 = _c.c_uint64
+_I32P = _c.POINTER(_c.c_int32)
+
+# name -> (restype, argtypes); mirrors include/vcg.h one to one
+SIGNATURES = {
+    "vcg_abi_version": (_I, []),
+    "vcg_last_error": (_c.c_char_p, []),
+    "vcg_nchw_to_nhwc": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
+    "vcg_nhwc_to_nchw": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
+    "vcg_fill": (_I, [_P, _F, _Z, _P]),
+    "vcg_pack_weight": (_I, [_P, _P, _I32P, _P]),
+    "vcg_conv_fwd": (_I, [_P, _P, _P, _P, _I32P, _P]),
+    "vcg_conv_dgrad": (_I, [_P, _P, _P, _I32P, _P]),
+    "vcg_conv_wgrad_workspace": (_Z, [_I32P]),
+    "vcg_conv_wgrad": (_I, [_P, _P, _P, _P, _I32P, _P, _Z, _P]),
+    "vcg_in_workspace": (_Z, [_I, _I, _I]),
+    "vcg_in_stats": (_I, [_P, _P, _P, _I, _I, _I, _F, _P, _Z, _P]),
+    "vcg_in_apply": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "vcg_in_bwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _Z, _P]),
+    "vcg_act_bwd": (_I, [_P, _P, _P, _Z, _I, _P]),
+    "vcg_pixel_shuffle": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
+    "vcg_reparam_fwd": (_I, [_P, _P, _P, _P, _P, _P, _Z, _U64, _U64, _P]),
+    "vcg_reparam_bwd": (_I, [_P, _P, _P, _P, _P, _P, _Z, _P]),
+    "vcg_randn": (_I, [_P, _Z, _U64, _U64, _P]),
+    "vcg_rand_uniform": (_I, [_P, _Z, _U64, _U64, _P]),
+    "vcg_reduce_workspace": (_Z, [_Z]),
+    "vcg_l1_fwd": (_I, [_P, _P, _P, _Z, _Z, _P, _Z, _P]),
+    "vcg_l1_bwd": (_I, [_P, _P, _P, _P, _P, _Z, _Z, _P]),
+    "vcg_mse_const_fwd": (_I, [_P, _F, _P, _Z, _P]),
+    "vcg_mse_const_bwd": (_I, [_P, _F, _P, _P, _Z, _P]),
+    "vcg_kl_fwd": (_I, [_P, _P, _P, _Z, _P, _Z, _P]),
+    "vcg_kl_bwd": (_I, [_P, _P, _P, _P, _P, _Z, _P]),
+    "vcg_lincomb_fwd": (_I, [_c.POINTER(_P), _c.POINTER(_F), _I, _P, _P]),
+    "vcg_sn_prepare": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _Z, _P]),
+    "vcg_fullmap_fwd": (_I, [_P, _P, _P, _P, _I, _Z, _P]),
+    "vcg_fullmap_dgrad": (_I, [_P, _P, _P, _I, _Z, _P]),
+    "vcg_fullmap_wgrad": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _Z, _P]),
+    "vcg_adam_step": (_I, [_P, _P, _P, _P, _Z, _F, _F, _F, _F, _F, _F, _P]),
+}
+
+_lib = None
+
+
+def hipcc_path():
+    for cand in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if cand and (os.path.isabs(cand) and os.path.exists(cand) or not os.path.isabs(cand)):
+            return cand
+    return "hipcc"
+
+
+def build(force=False, verbose=False):
+    """hipcc --offload-arch=gfx950 -> libvcg.so next to this file (cross-compiles without a GPU)."""
+    srcs = [os.path.join(CSRC, s) for s in SOURCES]
+    deps = srcs + [os.path.join(CSRC, "vcg_common.h"), HEADER]
+    if not force and os.path.exists(LIB_PATH):
+        if os.path.getmtime(LIB_PATH) >= max(os.path.getmtime(d) for d in deps):
+            return LIB_PATH
+    cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+           "-o", LIB_PATH] + srcs
+    if verbose:
+        print(" ".join(cmd))
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if res.returncode != 0:
+        raise RuntimeError("hipcc failed:\n" + res.stdout + res.stderr)
+    return LIB_PATH
+
+
+def lib():
+    """The loaded library, with argtypes set.  Raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: the HIP extension has not been built "
+                "(run `python -c 'import __graft_entry__ as g; g.build()'`). "
+                "This package has no fallback path.")
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)
+            fn.restype = res
+            fn.argtypes = args
+        if handle.vcg_abi_version() != 1:
+            raise RuntimeError("libvcg.so ABI version mismatch; rebuild it")
+        _lib = handle
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = lib().vcg_last_error()
+        raise RuntimeError(f"{what} failed (rc={rc}): {msg.decode() if msg else ''}")

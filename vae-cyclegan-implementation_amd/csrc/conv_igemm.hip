@@ -1,0 +1,723 @@
+// Implicit-GEMM convolution on the gfx950 fp32 matrix core (v_mfma_f32_32x32x2_f32).
+//
+// Replaces nn.Conv2d(padding_mode='reflect') forward/backward at the call sites
+// Networks.py:60 (CaSb), :87 (D, with PixelUnshuffle :86 folded into the gather),
+// :101/:104 (R), :122 (U), :136 (S), :145 (L).
+//
+// Data layout in HBM
+//   activations  NHWC fp32, channel pitch % 4 == 0
+//   weights      Wf[K][Cout], K = (kh, kw, i, j, c)   (i,j = PixelUnshuffle phase, ups in {1,2})
+//
+// One workgroup = 256 threads = 4 waves in a 2x2 grid; a wave owns (BM/2)x(BN/2) of the
+// BMxBN output tile as 32x32 MFMA accumulators.  K advances 32 per step; the next
+// step's global loads are issued before the MFMAs of the current one (register staged),
+// so with two workgroups per CU the matrix pipe always has a wave to run.
+//
+//   forward   C[m=(n,oh,ow)][co]  = sum_k A[m][k] * Wf[k][co]         A gathered from x
+//   dgrad     C[m=(n,h,w)][(q,c)] = sum_(tap,co) A[m][(tap,co)] * Wf[(tap,q,c)][co]
+//             A gathered from dy through the ADJOINT of the padding: a padded-domain
+//             coordinate q folds onto h when reflect(q) == h, so each (h, kh) has up to
+//             three source rows (h itself, -h near the top edge, 2(H-1)-h near the bottom).
+//             stride 2 is decomposed into 4 parity classes (blockIdx.z) so no MFMA runs on
+//             structurally-zero taps.
+//   wgrad     C[(tap,q,c)][co] = sum_m A[m][(tap,q,c)] * dy[m][co], split over m across
+//             blockIdx.z into fp32 slabs that a second kernel sums in a fixed order
+//             (bitwise reproducible, no float atomics) and scatters to OIHW.
+#include "vcg_common.h"
+
+struct ConvP {
+  const float* a;
+  const float* b;
+  const float* bias;
+  float* out;
+  int N, H, W, Cin, Cout, KH, KW, stride, pad, reflect, ups, act;
+  int Hl, Wl, Ho, Wo, M, K;
+  int cin4, cout4, cout_log;
+  FastDiv fd_howo, fd_wo, fd_cin4, fd_cout4, fd_kw, fd_cin;
+  // dgrad
+  int Hc, Wc, Mc, NB;
+  FastDiv fd_hcwc, fd_wc;
+  // wgrad
+  int ktiles_per_split, ktiles_total;
+};
+
+#define BK 32
+#define AS_STRIDE 33
+
+__device__ __forceinline__ float4 ldg4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+__device__ __forceinline__ void f4add(float4& a, const float4& b) {
+  a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+}
+
+// chunk g (4 consecutive k) of the forward K axis -> (kh, kw, i, j, c)
+__device__ __forceinline__ void decode_tap(const ConvP& p, uint32_t g, int& kh, int& kw, int& ii, int& jj, int& c) {
+  uint32_t tap = fd_div(g, p.fd_cin4);
+  c = (int)(g - tap * (uint32_t)p.cin4) * 4;
+  ii = 0; jj = 0;
+  if (p.ups == 2) { jj = tap & 1; ii = (tap >> 1) & 1; tap >>= 2; }
+  uint32_t q = fd_div(tap, p.fd_kw);
+  kh = (int)q; kw = (int)(tap - q * (uint32_t)p.KW);
+}
+
+// ------------------------------------------------------------------ forward
+template <int BM, int BN>
+__global__ __launch_bounds__(256) void k_conv_fwd(ConvP p) {
+  constexpr int MI = BM / 64, NI = BN / 64, AR = BM / 32, BE = BN / 32;
+  __shared__ __attribute__((aligned(16))) float As[BM * AS_STRIDE];
+  __shared__ __attribute__((aligned(16))) float Bs[BK * BN];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid >> 1, wn = wid & 1, l31 = lane & 31, lh = lane >> 5;
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  const int a_row = tid >> 3, a_u = tid & 7;
+
+  int pnH[AR], boh[AR], bow[AR];
+  bool pv[AR];
+#pragma unroll
+  for (int r = 0; r < AR; ++r) {
+    uint32_t m = (uint32_t)(m0 + a_row + 32 * r);
+    pv[r] = m < (uint32_t)p.M;
+    uint32_t n = fd_div(m, p.fd_howo);
+    uint32_t rem = m - n * (uint32_t)(p.Ho * p.Wo);
+    uint32_t oh = fd_div(rem, p.fd_wo);
+    uint32_t ow = rem - oh * (uint32_t)p.Wo;
+    pnH[r] = (int)n * p.H;
+    boh[r] = (int)oh * p.stride - p.pad;
+    bow[r] = (int)ow * p.stride - p.pad;
+  }
+
+  f32x16 acc[MI][NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  float4 va[AR], vb[BE];
+  const int nkt = (p.K + BK - 1) / BK;
+
+  auto load_tiles = [&](int kt) {
+    uint32_t g = (uint32_t)(kt * 8 + a_u);
+    bool kv = (int)(g * 4) < p.K;
+    int kh, kw, ii, jj, c;
+    decode_tap(p, g, kh, kw, ii, jj, c);
+#pragma unroll
+    for (int r = 0; r < AR; ++r) {
+      float4 v = f4zero();
+      if (pv[r] && kv) {
+        int ih = boh[r] + kh, iw = bow[r] + kw;
+        bool ok = true;
+        if (p.reflect) {
+          ih = reflect_idx(ih, p.Hl);
+          iw = reflect_idx(iw, p.Wl);
+        } else {
+          ok = (ih >= 0) && (ih < p.Hl) && (iw >= 0) && (iw < p.Wl);
+        }
+        if (ok) {
+          size_t off = ((size_t)(pnH[r] + ih * p.ups + ii) * p.W + (iw * p.ups + jj)) * p.Cin + c;
+          v = ldg4(p.a + off);
+        }
+      }
+      va[r] = v;
+    }
+#pragma unroll
+    for (int e = 0; e < BE; ++e) {
+      int idx = tid + 256 * e;
+      int kk = idx / (BN / 4), j4 = idx % (BN / 4);
+      int kg = kt * BK + kk, co = n0 + j4 * 4;
+      float4 v = f4zero();
+      if (kg < p.K && co < p.Cout) v = ldg4(p.b + (size_t)kg * p.Cout + co);
+      vb[e] = v;
+    }
+  };
+  auto store_tiles = [&]() {
+#pragma unroll
+    for (int r = 0; r < AR; ++r) {
+      float* d = &As[(a_row + 32 * r) * AS_STRIDE + a_u * 4];
+      d[0] = va[r].x; d[1] = va[r].y; d[2] = va[r].z; d[3] = va[r].w;
+    }
+#pragma unroll
+    for (int e = 0; e < BE; ++e) {
+      int idx = tid + 256 * e;
+      int kk = idx / (BN / 4), j4 = idx % (BN / 4);
+      *reinterpret_cast<float4*>(&Bs[kk * BN + j4 * 4]) = vb[e];
+    }
+  };
+
+  load_tiles(0);
+  store_tiles();
+  __syncthreads();
+  for (int kt = 0; kt < nkt; ++kt) {
+    if (kt + 1 < nkt) load_tiles(kt + 1);
+#pragma unroll
+    for (int ks = 0; ks < BK / 2; ++ks) {
+      const int kk = ks * 2 + lh;
+      float a[MI], b[NI];
+#pragma unroll
+      for (int i = 0; i < MI; ++i) a[i] = As[(wm * (BM / 2) + i * 32 + l31) * AS_STRIDE + kk];
+#pragma unroll
+      for (int j = 0; j < NI; ++j) b[j] = Bs[kk * BN + wn * (BN / 2) + j * 32 + l31];
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+    if (kt + 1 < nkt) {
+      store_tiles();
+      __syncthreads();
+    }
+  }
+
+  // epilogue: bias + activation, NHWC store (32 consecutive channels per half-wave)
+#pragma unroll
+  for (int j = 0; j < NI; ++j) {
+    const int co = n0 + wn * (BN / 2) + j * 32 + l31;
+    if (co >= p.Cout) continue;
+    const float bv = (p.bias && co < p.cout_log) ? p.bias[co] : 0.f;
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = (e & 3) + 8 * (e >> 2) + 4 * lh;
+        const int m = m0 + wm * (BM / 2) + i * 32 + row;
+        if (m < p.M) p.out[(size_t)m * p.Cout + co] = act_apply(acc[i][j][e] + bv, p.act);
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------ dgrad
+template <int BM, int BN>
+__global__ __launch_bounds__(256) void k_conv_dgrad(ConvP p) {
+  constexpr int MI = BM / 64, NI = BN / 64, AR = BM / 32, BR = BN / 32;
+  __shared__ __attribute__((aligned(16))) float As[BM * AS_STRIDE];
+  __shared__ __attribute__((aligned(16))) float Bt[BN * AS_STRIDE];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid >> 1, wn = wid & 1, l31 = lane & 31, lh = lane >> 5;
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  const int a_row = tid >> 3, a_u = tid & 7;
+  const int s = p.stride, sshift = s - 1;
+  const int ca = (int)blockIdx.z / s, cb = (int)blockIdx.z % s;
+  const int kh0 = (ca + p.pad) % s, kw0 = (cb + p.pad) % s;
+  const int nKH = (p.KH - kh0 + s - 1) / s, nKW = (p.KW - kw0 + s - 1) / s;
+  const int Kc = nKH * nKW * p.Cout;
+
+  int pnHo[AR], ph[AR], pw[AR];
+  bool pv[AR];
+#pragma unroll
+  for (int r = 0; r < AR; ++r) {
+    uint32_t m = (uint32_t)(m0 + a_row + 32 * r);
+    pv[r] = m < (uint32_t)p.Mc;
+    uint32_t n = fd_div(m, p.fd_hcwc);
+    uint32_t rem = m - n * (uint32_t)(p.Hc * p.Wc);
+    uint32_t hq = fd_div(rem, p.fd_wc);
+    uint32_t wq = rem - hq * (uint32_t)p.Wc;
+    pnHo[r] = (int)n * p.Ho;
+    ph[r] = (int)hq * s + ca;
+    pw[r] = (int)wq * s + cb;
+  }
+
+  f32x16 acc[MI][NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  float4 va[AR], vb[BR];
+  const int nkt = (Kc + BK - 1) / BK;
+
+  auto load_tiles = [&](int kt) {
+    uint32_t g = (uint32_t)(kt * 8 + a_u);
+    bool kv = (int)(g * 4) < Kc;
+    uint32_t tapc = fd_div(g, p.fd_cout4);
+    int co = (int)(g - tapc * (uint32_t)p.cout4) * 4;
+    int u = (int)tapc / nKW, v_ = (int)tapc % nKW;
+    int kh = kh0 + u * s, kw = kw0 + v_ * s;
+#pragma unroll
+    for (int r = 0; r < AR; ++r) {
+      float4 acc4 = f4zero();
+      if (pv[r] && kv) {
+        const int h = ph[r], w = pw[r];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+          int qh; bool okh;
+          if (a == 0) { qh = h; okh = true; }
+          else if (a == 1) { qh = -h; okh = p.reflect && h >= 1 && h <= p.pad; }
+          else { qh = 2 * (p.Hl - 1) - h; okh = p.reflect && h >= p.Hl - 1 - p.pad && h <= p.Hl - 2; }
+          int numh = qh - kh + p.pad;
+          int oh = numh >> sshift;
+          okh = okh && numh >= 0 && oh < p.Ho;
+          if (!okh) continue;
+#pragma unroll
+          for (int b = 0; b < 3; ++b) {
+            int qw; bool okw;
+            if (b == 0) { qw = w; okw = true; }
+            else if (b == 1) { qw = -w; okw = p.reflect && w >= 1 && w <= p.pad; }
+            else { qw = 2 * (p.Wl - 1) - w; okw = p.reflect && w >= p.Wl - 1 - p.pad && w <= p.Wl - 2; }
+            int numw = qw - kw + p.pad;
+            int ow = numw >> sshift;
+            okw = okw && numw >= 0 && ow < p.Wo;
+            if (!okw) continue;
+            size_t off = ((size_t)(pnHo[r] + oh) * p.Wo + ow) * p.Cout + co;
+            f4add(acc4, ldg4(p.a + off));
+          }
+        }
+      }
+      va[r] = acc4;
+    }
+    const int tapfull = kh * p.KW + kw;
+#pragma unroll
+    for (int r = 0; r < BR; ++r) {
+      int J = n0 + a_row + 32 * r;
+      float4 v = f4zero();
+      if (kv && J < p.NB) v = ldg4(p.b + ((size_t)tapfull * p.NB + J) * p.Cout + co);
+      vb[r] = v;
+    }
+  };
+  auto store_tiles = [&]() {
+#pragma unroll
+    for (int r = 0; r < AR; ++r) {
+      float* d = &As[(a_row + 32 * r) * AS_STRIDE + a_u * 4];
+      d[0] = va[r].x; d[1] = va[r].y; d[2] = va[r].z; d[3] = va[r].w;
+    }
+#pragma unroll
+    for (int r = 0; r < BR; ++r) {
+      float* d = &Bt[(a_row + 32 * r) * AS_STRIDE + a_u * 4];
+      d[0] = vb[r].x; d[1] = vb[r].y; d[2] = vb[r].z; d[3] = vb[r].w;
+    }
+  };
+
+  if (nkt > 0) {
+    load_tiles(0);
+    store_tiles();
+  }
+  __syncthreads();
+  for (int kt = 0; kt < nkt; ++kt) {
+    if (kt + 1 < nkt) load_tiles(kt + 1);
+#pragma unroll
+    for (int ks = 0; ks < BK / 2; ++ks) {
+      const int kk = ks * 2 + lh;
+      float a[MI], b[NI];
+#pragma unroll
+      for (int i = 0; i < MI; ++i) a[i] = As[(wm * (BM / 2) + i * 32 + l31) * AS_STRIDE + kk];
+#pragma unroll
+      for (int j = 0; j < NI; ++j) b[j] = Bt[(wn * (BN / 2) + j * 32 + l31) * AS_STRIDE + kk];
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+    if (kt + 1 < nkt) {
+      store_tiles();
+      __syncthreads();
+    }
+  }
+
+  // epilogue: column J = (q, c) -> physical pixel (h*ups + i, w*ups + j), channel c
+#pragma unroll
+  for (int j = 0; j < NI; ++j) {
+    const int J = n0 + wn * (BN / 2) + j * 32 + l31;
+    if (J >= p.NB) continue;
+    int q = 0, c = J;
+    if (p.ups == 2) { q = (int)fd_div((uint32_t)J, p.fd_cin); c = J - q * p.Cin; }
+    const int qi = q >> 1, qj = q & 1;
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = (e & 3) + 8 * (e >> 2) + 4 * lh;
+        const uint32_t m = (uint32_t)(m0 + wm * (BM / 2) + i * 32 + row);
+        if (m < (uint32_t)p.Mc) {
+          uint32_t n = fd_div(m, p.fd_hcwc);
+          uint32_t rem = m - n * (uint32_t)(p.Hc * p.Wc);
+          uint32_t hq = fd_div(rem, p.fd_wc);
+          uint32_t wq = rem - hq * (uint32_t)p.Wc;
+          int h = (int)hq * s + ca, w = (int)wq * s + cb;
+          size_t off = ((size_t)((int)n * p.H + h * p.ups + qi) * p.W + (w * p.ups + qj)) * p.Cin + c;
+          p.out[off] = acc[i][j][e];
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------ wgrad
+template <int BM, int BN>
+__global__ __launch_bounds__(256) void k_conv_wgrad(ConvP p) {
+  constexpr int MI = BM / 64, NI = BN / 64;
+  constexpr int RQ = BM / 4, PS = 256 / RQ, AP = BK / PS, BE = BN / 32;
+  __shared__ __attribute__((aligned(16))) float Xs[BK * BM];
+  __shared__ __attribute__((aligned(16))) float Ds[BK * BN];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid >> 1, wn = wid & 1, l31 = lane & 31, lh = lane >> 5;
+  const int r0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  const int rq = tid % RQ, ps = tid / RQ;
+
+  // this thread's K-row quad (fixed for the whole kernel)
+  const int R = r0 + rq * 4;
+  const bool rv = R < p.K;
+  int kh, kw, ii, jj, c;
+  decode_tap(p, (uint32_t)(R >> 2), kh, kw, ii, jj, c);
+
+  const int kt_begin = blockIdx.z * p.ktiles_per_split;
+  int kt_end = kt_begin + p.ktiles_per_split;
+  if (kt_end > p.ktiles_total) kt_end = p.ktiles_total;
+
+  f32x16 acc[MI][NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  float4 va[AP], vb[BE];
+
+  auto load_tiles = [&](int kt) {
+#pragma unroll
+    for (int a = 0; a < AP; ++a) {
+      uint32_t m = (uint32_t)(kt * BK + ps + PS * a);
+      float4 v = f4zero();
+      if (rv && m < (uint32_t)p.M) {
+        uint32_t n = fd_div(m, p.fd_howo);
+        uint32_t rem = m - n * (uint32_t)(p.Ho * p.Wo);
+        uint32_t oh = fd_div(rem, p.fd_wo);
+        uint32_t ow = rem - oh * (uint32_t)p.Wo;
+        int ih = (int)oh * p.stride - p.pad + kh, iw = (int)ow * p.stride - p.pad + kw;
+        bool ok = true;
+        if (p.reflect) {
+          ih = reflect_idx(ih, p.Hl);
+          iw = reflect_idx(iw, p.Wl);
+        } else {
+          ok = (ih >= 0) && (ih < p.Hl) && (iw >= 0) && (iw < p.Wl);
+        }
+        if (ok) {
+          size_t off = ((size_t)((int)n * p.H + ih * p.ups + ii) * p.W + (iw * p.ups + jj)) * p.Cin + c;
+          v = ldg4(p.a + off);
+        }
+      }
+      va[a] = v;
+    }
+#pragma unroll
+    for (int e = 0; e < BE; ++e) {
+      int idx = tid + 256 * e;
+      int pp = idx / (BN / 4), j4 = idx % (BN / 4);
+      uint32_t m = (uint32_t)(kt * BK + pp);
+      int co = n0 + j4 * 4;
+      float4 v = f4zero();
+      if (m < (uint32_t)p.M && co < p.Cout) v = ldg4(p.b + (size_t)m * p.Cout + co);
+      vb[e] = v;
+    }
+  };
+  auto store_tiles = [&]() {
+#pragma unroll
+    for (int a = 0; a < AP; ++a)
+      *reinterpret_cast<float4*>(&Xs[(ps + PS * a) * BM + rq * 4]) = va[a];
+#pragma unroll
+    for (int e = 0; e < BE; ++e) {
+      int idx = tid + 256 * e;
+      int pp = idx / (BN / 4), j4 = idx % (BN / 4);
+      *reinterpret_cast<float4*>(&Ds[pp * BN + j4 * 4]) = vb[e];
+    }
+  };
+
+  if (kt_begin < kt_end) {
+    load_tiles(kt_begin);
+    store_tiles();
+  }
+  __syncthreads();
+  for (int kt = kt_begin; kt < kt_end; ++kt) {
+    if (kt + 1 < kt_end) load_tiles(kt + 1);
+#pragma unroll
+    for (int ks = 0; ks < BK / 2; ++ks) {
+      const int kk = ks * 2 + lh;
+      float a[MI], b[NI];
+#pragma unroll
+      for (int i = 0; i < MI; ++i) a[i] = Xs[kk * BM + wm * (BM / 2) + i * 32 + l31];
+#pragma unroll
+      for (int j = 0; j < NI; ++j) b[j] = Ds[kk * BN + wn * (BN / 2) + j * 32 + l31];
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+    if (kt + 1 < kt_end) {
+      store_tiles();
+      __syncthreads();
+    }
+  }
+
+  float* slab = p.out + (size_t)blockIdx.z * p.K * p.Cout;
+#pragma unroll
+  for (int j = 0; j < NI; ++j) {
+    const int co = n0 + wn * (BN / 2) + j * 32 + l31;
+    if (co >= p.Cout) continue;
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = (e & 3) + 8 * (e >> 2) + 4 * lh;
+        const int Rr = r0 + wm * (BM / 2) + i * 32 + row;
+        if (Rr < p.K) slab[(size_t)Rr * p.Cout + co] = acc[i][j][e];
+      }
+    }
+  }
+}
+
+// slabs[z][K][Cout] -> gw_oihw += sum_z (fixed order)
+__global__ void k_wgrad_reduce(const float* __restrict__ slabs, float* __restrict__ gw, ConvP p, int nsplit,
+                               int cin_log, int cout_log) {
+  const size_t total = (size_t)p.K * p.Cout;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (size_t)gridDim.x * blockDim.x) {
+    uint32_t R = (uint32_t)(idx / p.Cout);
+    int co = (int)(idx - (size_t)R * p.Cout);
+    uint32_t tap = R / (uint32_t)p.Cin;
+    int c = (int)(R - tap * (uint32_t)p.Cin);
+    if (co >= cout_log || c >= cin_log) continue;
+    int ii = 0, jj = 0;
+    if (p.ups == 2) { jj = tap & 1; ii = (tap >> 1) & 1; tap >>= 2; }
+    int kh = (int)tap / p.KW, kw = (int)tap % p.KW;
+    int cl = (p.ups == 2) ? (c * 4 + ii * 2 + jj) : c;
+    int cinL = (p.ups == 2) ? cin_log * 4 : cin_log;
+    float s = 0.f;
+    for (int z = 0; z < nsplit; ++z) s += slabs[(size_t)z * total + idx];
+    size_t o = (((size_t)co * cinL + cl) * p.KH + kh) * p.KW + kw;
+    gw[o] += s;
+  }
+}
+
+// OIHW -> Wf[K][Cout] (pad rows / pad columns are zero)
+__global__ void k_pack_weight(const float* __restrict__ w, float* __restrict__ wf, ConvP p, int cin_log,
+                              int cout_log) {
+  const size_t total = (size_t)p.K * p.Cout;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (size_t)gridDim.x * blockDim.x) {
+    uint32_t R = (uint32_t)(idx / p.Cout);
+    int co = (int)(idx - (size_t)R * p.Cout);
+    uint32_t tap = R / (uint32_t)p.Cin;
+    int c = (int)(R - tap * (uint32_t)p.Cin);
+    float v = 0.f;
+    if (co < cout_log && c < cin_log) {
+      int ii = 0, jj = 0;
+      if (p.ups == 2) { jj = tap & 1; ii = (tap >> 1) & 1; tap >>= 2; }
+      int kh = (int)tap / p.KW, kw = (int)tap % p.KW;
+      int cl = (p.ups == 2) ? (c * 4 + ii * 2 + jj) : c;
+      int cinL = (p.ups == 2) ? cin_log * 4 : cin_log;
+      v = w[(((size_t)co * cinL + cl) * p.KH + kh) * p.KW + kw];
+    }
+    wf[idx] = v;
+  }
+}
+
+// gbias[co] += sum_m dy[m][co]: per-chunk partials then a fixed-order final sum
+__global__ __launch_bounds__(256) void k_colsum_partial(const float* __restrict__ dy, float* __restrict__ part,
+                                                        int M, int C, int rows_per_chunk) {
+  __shared__ float red[256];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int pl = threadIdx.x >> 6;
+  const int mb = blockIdx.y * rows_per_chunk;
+  int me = mb + rows_per_chunk;
+  if (me > M) me = M;
+  float s = 0.f;
+  if (c < C)
+    for (int m = mb + pl; m < me; m += 4) s += dy[(size_t)m * C + c];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  if (pl == 0 && c < C)
+    part[(size_t)blockIdx.y * C + c] = red[threadIdx.x] + red[threadIdx.x + 64] + red[threadIdx.x + 128] + red[threadIdx.x + 192];
+}
+__global__ void k_colsum_final(const float* __restrict__ part, float* __restrict__ out, int C, int nchunk,
+                               int c_log) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= c_log) return;
+  float s = 0.f;
+  for (int k = 0; k < nchunk; ++k) s += part[(size_t)k * C + c];
+  out[c] += s;
+}
+
+// ------------------------------------------------------------------ host side
+int vcg_conv_geom(const int32_t* cd, ConvGeom* g, const char* who) {
+  g->N = cd[VCG_CD_N]; g->H = cd[VCG_CD_H]; g->W = cd[VCG_CD_W];
+  g->Cin = cd[VCG_CD_CIN]; g->Cout = cd[VCG_CD_COUT];
+  g->KH = cd[VCG_CD_KH]; g->KW = cd[VCG_CD_KW];
+  g->stride = cd[VCG_CD_STRIDE]; g->pad = cd[VCG_CD_PAD];
+  g->reflect = cd[VCG_CD_REFLECT]; g->ups = cd[VCG_CD_UPS]; g->act = cd[VCG_CD_ACT];
+  g->cin_log = cd[VCG_CD_CIN_LOGICAL]; g->cout_log = cd[VCG_CD_COUT_LOGICAL];
+  VCG_CHECK_ARG(g->N > 0 && g->H > 0 && g->W > 0, "%s: bad N/H/W %d %d %d", who, g->N, g->H, g->W);
+  VCG_CHECK_ARG(g->Cin > 0 && g->Cin % 4 == 0, "%s: Cin pitch %d must be a positive multiple of 4", who, g->Cin);
+  VCG_CHECK_ARG(g->Cout > 0 && g->Cout % 4 == 0, "%s: Cout pitch %d must be a positive multiple of 4", who, g->Cout);
+  VCG_CHECK_ARG(g->ups == 1 || g->ups == 2, "%s: ups must be 1 or 2", who);
+  VCG_CHECK_ARG(g->stride == 1 || g->stride == 2, "%s: stride must be 1 or 2", who);
+  VCG_CHECK_ARG(g->H % g->ups == 0 && g->W % g->ups == 0, "%s: H,W must be divisible by ups", who);
+  VCG_CHECK_ARG(g->cin_log > 0 && g->cin_log <= g->Cin && g->cout_log > 0 && g->cout_log <= g->Cout,
+                "%s: logical channels out of range", who);
+  VCG_CHECK_ARG(g->act >= 0 && g->act <= 2, "%s: bad act", who);
+  g->Hl = g->H / g->ups; g->Wl = g->W / g->ups;
+  VCG_CHECK_ARG(g->KH > 0 && g->KW > 0 && g->pad >= 0, "%s: bad kernel/pad", who);
+  VCG_CHECK_ARG(g->Hl + 2 * g->pad >= g->KH && g->Wl + 2 * g->pad >= g->KW, "%s: kernel larger than padded input", who);
+  if (g->reflect)
+    VCG_CHECK_ARG(g->pad < g->Hl && g->pad < g->Wl, "%s: reflect pad %d needs input > pad (got %dx%d)", who, g->pad, g->Hl, g->Wl);
+  g->Ho = (g->Hl + 2 * g->pad - g->KH) / g->stride + 1;
+  g->Wo = (g->Wl + 2 * g->pad - g->KW) / g->stride + 1;
+  long long M = (long long)g->N * g->Ho * g->Wo;
+  long long in_elems = (long long)g->N * g->H * g->W * g->Cin;
+  long long out_elems = M * g->Cout;
+  VCG_CHECK_ARG(M < (1ll << 30) && in_elems < (1ll << 40) && out_elems < (1ll << 40), "%s: tensor too large", who);
+  g->M = (int)M;
+  g->taps = g->KH * g->KW * g->ups * g->ups;
+  long long K = (long long)g->taps * g->Cin;
+  VCG_CHECK_ARG(K < (1ll << 30), "%s: K too large", who);
+  g->K = (int)K;
+  return 0;
+}
+
+static void fill_params(const ConvGeom& g, ConvP& p) {
+  p.N = g.N; p.H = g.H; p.W = g.W; p.Cin = g.Cin; p.Cout = g.Cout; p.KH = g.KH; p.KW = g.KW;
+  p.stride = g.stride; p.pad = g.pad; p.reflect = g.reflect; p.ups = g.ups; p.act = g.act;
+  p.Hl = g.Hl; p.Wl = g.Wl; p.Ho = g.Ho; p.Wo = g.Wo; p.M = g.M; p.K = g.K;
+  p.cin4 = g.Cin / 4; p.cout4 = g.Cout / 4; p.cout_log = g.cout_log;
+  p.fd_howo = make_fastdiv((uint32_t)(g.Ho * g.Wo));
+  p.fd_wo = make_fastdiv((uint32_t)g.Wo);
+  p.fd_cin4 = make_fastdiv((uint32_t)p.cin4);
+  p.fd_cout4 = make_fastdiv((uint32_t)p.cout4);
+  p.fd_kw = make_fastdiv((uint32_t)g.KW);
+  p.fd_cin = make_fastdiv((uint32_t)g.Cin);
+  p.Hc = p.Wc = p.Mc = p.NB = 0;
+  p.fd_hcwc = make_fastdiv(1); p.fd_wc = make_fastdiv(1);
+  p.ktiles_per_split = p.ktiles_total = 0;
+  p.bias = nullptr;
+}
+
+// pick the largest tile that still gives the 256 CUs two workgroups each
+static void pick_tile(long long rows, long long cols, int& bm, int& bn) {
+  const int cand[4][2] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}};
+  for (int i = 0; i < 4; ++i) {
+    int m = cand[i][0], n = cand[i][1];
+    if (cols <= 64 && n == 128) continue;
+    long long wgs = ((rows + m - 1) / m) * ((cols + n - 1) / n);
+    if (wgs >= 512 || i == 3) { bm = m; bn = n; return; }
+  }
+  bm = 64; bn = 64;
+}
+
+#define DISPATCH_TILE(KERNEL, bm, bn, grid, stream, p)                                        \
+  do {                                                                                        \
+    if (bm == 128 && bn == 128) hipLaunchKernelGGL((KERNEL<128, 128>), grid, dim3(256), 0, stream, p); \
+    else if (bm == 128 && bn == 64) hipLaunchKernelGGL((KERNEL<128, 64>), grid, dim3(256), 0, stream, p); \
+    else if (bm == 64 && bn == 128) hipLaunchKernelGGL((KERNEL<64, 128>), grid, dim3(256), 0, stream, p); \
+    else hipLaunchKernelGGL((KERNEL<64, 64>), grid, dim3(256), 0, stream, p);                  \
+  } while (0)
+
+extern "C" int vcg_pack_weight(const float* w_oihw, float* wf, const int32_t* cd, void* stream) {
+  ConvGeom g;
+  if (vcg_conv_geom(cd, &g, "vcg_pack_weight")) return -1;
+  VCG_CHECK_ARG(w_oihw && wf, "vcg_pack_weight: null pointer");
+  ConvP p; fill_params(g, p);
+  size_t total = (size_t)g.K * g.Cout;
+  int blocks = (int)((total + 255) / 256); if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(k_pack_weight, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w_oihw, wf, p, g.cin_log, g.cout_log);
+  VCG_LAUNCH_CHECK("vcg_pack_weight");
+  return 0;
+}
+
+extern "C" int vcg_conv_fwd(const float* x, const float* wf, const float* bias, float* y,
+                            const int32_t* cd, void* stream) {
+  ConvGeom g;
+  if (vcg_conv_geom(cd, &g, "vcg_conv_fwd")) return -1;
+  VCG_CHECK_ARG(x && wf && y, "vcg_conv_fwd: null pointer");
+  ConvP p; fill_params(g, p);
+  p.a = x; p.b = wf; p.bias = bias; p.out = y;
+  int bm, bn; pick_tile(g.M, g.Cout, bm, bn);
+  dim3 grid((g.M + bm - 1) / bm, (g.Cout + bn - 1) / bn, 1);
+  DISPATCH_TILE(k_conv_fwd, bm, bn, grid, (hipStream_t)stream, p);
+  VCG_LAUNCH_CHECK("vcg_conv_fwd");
+  return 0;
+}
+
+extern "C" int vcg_conv_dgrad(const float* dy, const float* wf, float* dx, const int32_t* cd, void* stream) {
+  ConvGeom g;
+  if (vcg_conv_geom(cd, &g, "vcg_conv_dgrad")) return -1;
+  VCG_CHECK_ARG(dy && wf && dx, "vcg_conv_dgrad: null pointer");
+  VCG_CHECK_ARG(g.Hl % g.stride == 0 && g.Wl % g.stride == 0, "vcg_conv_dgrad: input %dx%d not divisible by stride", g.Hl, g.Wl);
+  VCG_CHECK_ARG(g.stride == 1 || g.ups == 1, "vcg_conv_dgrad: stride 2 with ups 2 unsupported");
+  ConvP p; fill_params(g, p);
+  p.a = dy; p.b = wf; p.out = dx;
+  p.Hc = g.Hl / g.stride; p.Wc = g.Wl / g.stride; p.Mc = g.N * p.Hc * p.Wc;
+  p.NB = g.ups * g.ups * g.Cin;
+  p.fd_hcwc = make_fastdiv((uint32_t)(p.Hc * p.Wc));
+  p.fd_wc = make_fastdiv((uint32_t)p.Wc);
+  int bm, bn; pick_tile(p.Mc, p.NB, bm, bn);
+  dim3 grid((p.Mc + bm - 1) / bm, (p.NB + bn - 1) / bn, g.stride * g.stride);
+  DISPATCH_TILE(k_conv_dgrad, bm, bn, grid, (hipStream_t)stream, p);
+  VCG_LAUNCH_CHECK("vcg_conv_dgrad");
+  return 0;
+}
+
+static void wgrad_plan(const ConvGeom& g, int& bm, int& bn, int& nsplit, int& per, int& total) {
+  bn = g.Cout >= 128 ? 128 : 64;
+  bm = g.K >= 128 ? 128 : 64;
+  long long tiles = (long long)((g.K + bm - 1) / bm) * ((g.Cout + bn - 1) / bn);
+  total = (g.M + BK - 1) / BK;
+  long long want = (768 + tiles - 1) / tiles;
+  long long maxs = total / 4; if (maxs < 1) maxs = 1;
+  if (want > maxs) want = maxs;
+  if (want < 1) want = 1;
+  per = (int)((total + want - 1) / want);
+  nsplit = (total + per - 1) / per;
+}
+
+static const int kColsumRows = 2048;
+
+extern "C" size_t vcg_conv_wgrad_workspace(const int32_t* cd) {
+  ConvGeom g;
+  if (vcg_conv_geom(cd, &g, "vcg_conv_wgrad_workspace")) return 0;
+  int bm, bn, nsplit, per, total;
+  wgrad_plan(g, bm, bn, nsplit, per, total);
+  size_t slabs = (size_t)nsplit * g.K * g.Cout * sizeof(float);
+  size_t nchunk = (size_t)(g.M + kColsumRows - 1) / kColsumRows;
+  size_t cols = nchunk * g.Cout * sizeof(float);
+  return slabs + cols + 256;
+}
+
+extern "C" int vcg_conv_wgrad(const float* x, const float* dy, float* gw_oihw, float* gbias,
+                              const int32_t* cd, void* ws, size_t ws_bytes, void* stream) {
+  ConvGeom g;
+  if (vcg_conv_geom(cd, &g, "vcg_conv_wgrad")) return -1;
+  VCG_CHECK_ARG(x && dy && gw_oihw && ws, "vcg_conv_wgrad: null pointer");
+  size_t need = vcg_conv_wgrad_workspace(cd);
+  VCG_CHECK_ARG(ws_bytes >= need, "vcg_conv_wgrad: workspace %zu < %zu", ws_bytes, need);
+  ConvP p; fill_params(g, p);
+  int bm, bn, nsplit, per, total;
+  wgrad_plan(g, bm, bn, nsplit, per, total);
+  p.a = x; p.b = dy; p.out = (float*)ws;
+  p.ktiles_per_split = per; p.ktiles_total = total;
+  dim3 grid((g.K + bm - 1) / bm, (g.Cout + bn - 1) / bn, nsplit);
+  hipStream_t st = (hipStream_t)stream;
+  if (bm == 128 && bn == 128) hipLaunchKernelGGL((k_conv_wgrad<128, 128>), grid, dim3(256), 0, st, p);
+  else if (bm == 128 && bn == 64) hipLaunchKernelGGL((k_conv_wgrad<128, 64>), grid, dim3(256), 0, st, p);
+  else if (bm == 64 && bn == 128) hipLaunchKernelGGL((k_conv_wgrad<64, 128>), grid, dim3(256), 0, st, p);
+  else hipLaunchKernelGGL((k_conv_wgrad<64, 64>), grid, dim3(256), 0, st, p);
+  VCG_LAUNCH_CHECK("vcg_conv_wgrad");
+  size_t totalw = (size_t)g.K * g.Cout;
+  int blocks = (int)((totalw + 255) / 256); if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(k_wgrad_reduce, dim3(blocks), dim3(256), 0, st, (const float*)ws, gw_oihw, p, nsplit, g.cin_log, g.cout_log);
+  VCG_LAUNCH_CHECK("vcg_conv_wgrad(reduce)");
+  if (gbias) {
+    float* part = (float*)((char*)ws + (((size_t)nsplit * g.K * g.Cout * sizeof(float) + 255) / 256) * 256);
+    int nchunk = (g.M + kColsumRows - 1) / kColsumRows;
+    hipLaunchKernelGGL(k_colsum_partial, dim3((g.Cout + 63) / 64, nchunk), dim3(256), 0, st, dy, part, g.M, g.Cout, kColsumRows);
+    hipLaunchKernelGGL(k_colsum_final, dim3((g.cout_log + 63) / 64), dim3(64), 0, st, (const float*)part, gbias, g.Cout, nchunk, g.cout_log);
+    VCG_LAUNCH_CHECK("vcg_conv_wgrad(bias)");
+  }
+  return 0;
+}

@@ -1,0 +1,584 @@
+// HBM-bound pieces of the training step: layout repack, the reparameterisation sampler
+// (Networks.py:219-227), the loss reductions of Losses.py:14-121, the spectral-normed
+// full-map conv that ends the discriminator (Networks.py:248) and torch.optim.Adam's update
+// (call sites Networks.py:312,894,1928-1935).  Reductions are wavefront-shuffle (64 lanes)
+// -> LDS across the block's waves -> one partial per block -> fixed-order final sum in double.
+#include <stdarg.h>
+#include <string.h>
+#include "vcg_common.h"
+
+// ---------------------------------------------------------------- error plumbing
+static thread_local char g_err[512] = "";
+void vcg_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+extern "C" const char* vcg_last_error(void) { return g_err; }
+extern "C" int vcg_abi_version(void) { return VCG_ABI_VERSION; }
+
+static int ew_blocks(size_t work) {
+  size_t b = (work + 255) / 256;
+  if (b > 2048) b = 2048;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+// ---------------------------------------------------------------- layout
+__global__ void k_nchw_to_nhwc(const float* __restrict__ src, float* __restrict__ dst, int N, int C, int H, int W,
+                               int P) {
+  const size_t total = (size_t)N * H * W * P;
+  const size_t HW = (size_t)H * W;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (size_t)gridDim.x * blockDim.x) {
+    int c = (int)(idx % P);
+    size_t pixg = idx / P;
+    size_t n = pixg / HW, pix = pixg - n * HW;
+    dst[idx] = (c < C) ? src[(n * C + c) * HW + pix] : 0.f;
+  }
+}
+__global__ void k_nhwc_to_nchw(const float* __restrict__ src, float* __restrict__ dst, int N, int C, int H, int W,
+                               int P) {
+  const size_t total = (size_t)N * C * H * W;
+  const size_t HW = (size_t)H * W;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (size_t)gridDim.x * blockDim.x) {
+    size_t pix = idx % HW;
+    size_t nc = idx / HW;
+    size_t n = nc / C;
+    int c = (int)(nc - n * C);
+    dst[idx] = src[(n * HW + pix) * P + c];
+  }
+}
+__global__ void k_fill(float* __restrict__ dst, float v, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = v;
+}
+
+extern "C" int vcg_nchw_to_nhwc(const float* src, float* dst, int N, int C, int H, int W, int P, void* stream) {
+  VCG_CHECK_ARG(src && dst && N > 0 && C > 0 && H > 0 && W > 0 && P >= C, "vcg_nchw_to_nhwc: bad args");
+  hipLaunchKernelGGL(k_nchw_to_nhwc, dim3(ew_blocks((size_t)N * H * W * P)), dim3(256), 0, (hipStream_t)stream, src,
+                     dst, N, C, H, W, P);
+  VCG_LAUNCH_CHECK("vcg_nchw_to_nhwc");
+  return 0;
+}
+extern "C" int vcg_nhwc_to_nchw(const float* src, float* dst, int N, int C, int H, int W, int P, void* stream) {
+  VCG_CHECK_ARG(src && dst && N > 0 && C > 0 && H > 0 && W > 0 && P >= C, "vcg_nhwc_to_nchw: bad args");
+  hipLaunchKernelGGL(k_nhwc_to_nchw, dim3(ew_blocks((size_t)N * H * W * C)), dim3(256), 0, (hipStream_t)stream, src,
+                     dst, N, C, H, W, P);
+  VCG_LAUNCH_CHECK("vcg_nhwc_to_nchw");
+  return 0;
+}
+extern "C" int vcg_fill(float* dst, float value, size_t n, void* stream) {
+  VCG_CHECK_ARG(dst || n == 0, "vcg_fill: null pointer");
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(k_fill, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, dst, value, n);
+  VCG_LAUNCH_CHECK("vcg_fill");
+  return 0;
+}
+
+// ---------------------------------------------------------------- Philox4x32-10
+struct Philox4 { uint32_t x, y, z, w; };
+__host__ __device__ static inline Philox4 philox4x32_10(uint64_t ctr, uint64_t key) {
+  uint32_t c0 = (uint32_t)ctr, c1 = (uint32_t)(ctr >> 32), c2 = 0x243F6A88u, c3 = 0x85A308D3u;
+  uint32_t k0 = (uint32_t)key, k1 = (uint32_t)(key >> 32);
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+    uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
+    uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  Philox4 o = {c0, c1, c2, c3};
+  return o;
+}
+__device__ static inline float u01(uint32_t x) { return ((float)(x >> 8) + 0.5f) * (1.0f / 16777216.0f); }
+__device__ static inline void box_muller(uint32_t a, uint32_t b, float& n0, float& n1) {
+  float r = sqrtf(-2.0f * __logf(u01(a)));
+  float th = 6.283185307179586f * u01(b);
+  float s, c;
+  __sincosf(th, &s, &c);
+  n0 = r * c; n1 = r * s;
+}
+__device__ static inline float4 randn4(uint64_t seed, uint64_t quad) {
+  Philox4 r = philox4x32_10(quad, seed);
+  float4 o;
+  box_muller(r.x, r.y, o.x, o.y);
+  box_muller(r.z, r.w, o.z, o.w);
+  return o;
+}
+
+__global__ void k_randn(float* __restrict__ out, size_t n, uint64_t seed, uint64_t offset) {
+  const size_t nq = (n + 3) / 4;
+  for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += (size_t)gridDim.x * blockDim.x) {
+    float4 v = randn4(seed, offset + q);
+    float vv[4] = {v.x, v.y, v.z, v.w};
+    for (int e = 0; e < 4; ++e)
+      if (q * 4 + e < n) out[q * 4 + e] = vv[e];
+  }
+}
+__global__ void k_rand_uniform(float* __restrict__ out, size_t n, uint64_t seed, uint64_t offset) {
+  const size_t nq = (n + 3) / 4;
+  for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += (size_t)gridDim.x * blockDim.x) {
+    Philox4 r = philox4x32_10(offset + q, seed);
+    // [0,1): torch.rand-like synthetic pixels
+    float vv[4] = {(float)(r.x >> 8) * (1.0f / 16777216.0f), (float)(r.y >> 8) * (1.0f / 16777216.0f),
+                   (float)(r.z >> 8) * (1.0f / 16777216.0f), (float)(r.w >> 8) * (1.0f / 16777216.0f)};
+    for (int e = 0; e < 4; ++e)
+      if (q * 4 + e < n) out[q * 4 + e] = vv[e];
+  }
+}
+extern "C" int vcg_randn(float* out, size_t n, uint64_t seed, uint64_t offset, void* stream) {
+  VCG_CHECK_ARG(out || n == 0, "vcg_randn: null pointer");
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(k_randn, dim3(ew_blocks((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, out, n, seed, offset);
+  VCG_LAUNCH_CHECK("vcg_randn");
+  return 0;
+}
+extern "C" int vcg_rand_uniform(float* out, size_t n, uint64_t seed, uint64_t offset, void* stream) {
+  VCG_CHECK_ARG(out || n == 0, "vcg_rand_uniform: null pointer");
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(k_rand_uniform, dim3(ew_blocks((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, out, n, seed, offset);
+  VCG_LAUNCH_CHECK("vcg_rand_uniform");
+  return 0;
+}
+
+// ---------------------------------------------------------------- reparameterisation
+__global__ void k_reparam_fwd(const float* __restrict__ mu, const float* __restrict__ lv,
+                              const float* __restrict__ eps, float* __restrict__ eps_out, float* __restrict__ z,
+                              float* __restrict__ lvc, size_t n, uint64_t seed, uint64_t offset) {
+  const size_t nq = (n + 3) / 4;
+  for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += (size_t)gridDim.x * blockDim.x) {
+    float e4[4];
+    if (!eps) {
+      float4 v = randn4(seed, offset + q);
+      e4[0] = v.x; e4[1] = v.y; e4[2] = v.z; e4[3] = v.w;
+    }
+    for (int e = 0; e < 4; ++e) {
+      size_t i = q * 4 + e;
+      if (i >= n) break;
+      float ev = eps ? eps[i] : e4[e];
+      float l = fminf(fmaxf(lv[i], -10.f), 10.f);
+      float sd = expf(0.5f * l);
+      z[i] = mu[i] + ev * sd;
+      lvc[i] = l;
+      if (eps_out) eps_out[i] = ev;
+    }
+  }
+}
+__global__ void k_reparam_bwd(const float* __restrict__ gz, const float* __restrict__ glvc,
+                              const float* __restrict__ eps, const float* __restrict__ lv, float* __restrict__ dmu,
+                              float* __restrict__ dlv, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    float l = lv[i];
+    float lc = fminf(fmaxf(l, -10.f), 10.f);
+    float g = gz ? gz[i] : 0.f;
+    float gl = g * eps[i] * 0.5f * expf(0.5f * lc) + (glvc ? glvc[i] : 0.f);
+    // torch.clamp passes the gradient on the closed interval [-10, 10]
+    dlv[i] = (l >= -10.f && l <= 10.f) ? gl : 0.f;
+    dmu[i] = g;
+  }
+}
+extern "C" int vcg_reparam_fwd(const float* mu, const float* lv, const float* eps, float* eps_out, float* z,
+                               float* lvc, size_t n, uint64_t seed, uint64_t offset, void* stream) {
+  VCG_CHECK_ARG(mu && lv && z && lvc, "vcg_reparam_fwd: null pointer");
+  VCG_CHECK_ARG(eps || eps_out, "vcg_reparam_fwd: device-drawn eps must be written to eps_out for the backward");
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(k_reparam_fwd, dim3(ew_blocks((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, mu, lv, eps,
+                     eps_out, z, lvc, n, seed, offset);
+  VCG_LAUNCH_CHECK("vcg_reparam_fwd");
+  return 0;
+}
+extern "C" int vcg_reparam_bwd(const float* gz, const float* glvc, const float* eps, const float* lv, float* dmu,
+                               float* dlv, size_t n, void* stream) {
+  VCG_CHECK_ARG(eps && lv && dmu && dlv, "vcg_reparam_bwd: null pointer");
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(k_reparam_bwd, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, gz, glvc, eps, lv, dmu,
+                     dlv, n);
+  VCG_LAUNCH_CHECK("vcg_reparam_bwd");
+  return 0;
+}
+
+// ---------------------------------------------------------------- block reductions
+__device__ static inline float block_sum(float v, float* red) {
+  v = wave_sum(v);
+  const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  __syncthreads();
+  if (lane == 0) red[wid] = v;
+  __syncthreads();
+  float s = 0.f;
+  const int nw = (blockDim.x + 63) >> 6;
+  for (int i = 0; i < nw; ++i) s += red[i];
+  return s;
+}
+
+static const int kRedBlocks = 1024;
+extern "C" size_t vcg_reduce_workspace(size_t n) {
+  (void)n;
+  return (size_t)kRedBlocks * 2 * sizeof(float) + 256;
+}
+
+// MODE 0: |a-b| ; MODE 1: KL term 1 + lvc - mu^2 - exp(lvc)  (a=mu, b=lv)
+template <int MODE>
+__global__ __launch_bounds__(256) void k_reduce_partial(const float* __restrict__ a, const float* __restrict__ b,
+                                                        float* __restrict__ part, size_t n) {
+  __shared__ float red[4];
+  float s = 0.f;
+  const size_t n4 = n / 4;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    float4 x = reinterpret_cast<const float4*>(a)[i];
+    float4 y = reinterpret_cast<const float4*>(b)[i];
+    if (MODE == 0) {
+      s += fabsf(x.x - y.x) + fabsf(x.y - y.y) + fabsf(x.z - y.z) + fabsf(x.w - y.w);
+    } else {
+      float l;
+      l = fminf(fmaxf(y.x, -10.f), 10.f); s += 1.f + l - x.x * x.x - expf(l);
+      l = fminf(fmaxf(y.y, -10.f), 10.f); s += 1.f + l - x.y * x.y - expf(l);
+      l = fminf(fmaxf(y.z, -10.f), 10.f); s += 1.f + l - x.z * x.z - expf(l);
+      l = fminf(fmaxf(y.w, -10.f), 10.f); s += 1.f + l - x.w * x.w - expf(l);
+    }
+  }
+  if (blockIdx.x == 0)
+    for (size_t i = n4 * 4 + threadIdx.x; i < n; i += blockDim.x) {
+      if (MODE == 0) s += fabsf(a[i] - b[i]);
+      else { float l = fminf(fmaxf(b[i], -10.f), 10.f); s += 1.f + l - a[i] * a[i] - expf(l); }
+    }
+  float tot = block_sum(s, red);
+  if (threadIdx.x == 0) part[blockIdx.x] = tot;
+}
+__global__ void k_reduce_final(const float* __restrict__ part, int nblocks, double scale, float* __restrict__ out) {
+  // one wave; fixed order
+  double s = 0.0;
+  for (int i = threadIdx.x; i < nblocks; i += 64) s += (double)part[i];
+  s = wave_sum_d(s);
+  if (threadIdx.x == 0) out[0] = (float)(s * scale);
+}
+
+static int red_blocks(size_t n) {
+  size_t b = (n / 4 + 255) / 256;
+  if (b > (size_t)kRedBlocks) b = kRedBlocks;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+extern "C" int vcg_l1_fwd(const float* a, const float* b, float* out, size_t n_phys, size_t n_logical,
+                          void* ws, size_t ws_bytes, void* stream) {
+  VCG_CHECK_ARG(a && b && out && ws && n_logical > 0, "vcg_l1_fwd: bad args");
+  VCG_CHECK_ARG(ws_bytes >= vcg_reduce_workspace(n_phys), "vcg_l1_fwd: workspace too small");
+  int nb = red_blocks(n_phys);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_reduce_partial<0>, dim3(nb), dim3(256), 0, st, a, b, (float*)ws, n_phys);
+  hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(64), 0, st, (const float*)ws, nb, 1.0 / (double)n_logical, out);
+  VCG_LAUNCH_CHECK("vcg_l1_fwd");
+  return 0;
+}
+__global__ void k_l1_bwd(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ gout,
+                         float* __restrict__ ga, float* __restrict__ gb, size_t n, float inv_n) {
+  const float s = gout[0] * inv_n;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    float d = a[i] - b[i];
+    float g = d > 0.f ? s : (d < 0.f ? -s : 0.f);
+    if (ga) ga[i] = g;
+    if (gb) gb[i] = -g;
+  }
+}
+extern "C" int vcg_l1_bwd(const float* a, const float* b, const float* gout, float* ga, float* gb, size_t n_phys,
+                          size_t n_logical, void* stream) {
+  VCG_CHECK_ARG(a && b && gout && (ga || gb) && n_logical > 0, "vcg_l1_bwd: bad args");
+  hipLaunchKernelGGL(k_l1_bwd, dim3(ew_blocks(n_phys)), dim3(256), 0, (hipStream_t)stream, a, b, gout, ga, gb,
+                     n_phys, 1.0f / (float)n_logical);
+  VCG_LAUNCH_CHECK("vcg_l1_bwd");
+  return 0;
+}
+
+extern "C" int vcg_kl_fwd(const float* mu, const float* lv, float* out, size_t n, void* ws, size_t ws_bytes,
+                          void* stream) {
+  VCG_CHECK_ARG(mu && lv && out && ws && n > 0, "vcg_kl_fwd: bad args");
+  VCG_CHECK_ARG(ws_bytes >= vcg_reduce_workspace(n), "vcg_kl_fwd: workspace too small");
+  int nb = red_blocks(n);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_reduce_partial<1>, dim3(nb), dim3(256), 0, st, mu, lv, (float*)ws, n);
+  hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(64), 0, st, (const float*)ws, nb, -0.5 / (double)n, out);
+  VCG_LAUNCH_CHECK("vcg_kl_fwd");
+  return 0;
+}
+__global__ void k_kl_bwd(const float* __restrict__ mu, const float* __restrict__ lv, const float* __restrict__ gout,
+                         float* __restrict__ gmu, float* __restrict__ glv, size_t n, float inv_n) {
+  const float s = gout[0] * inv_n;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    float l = lv[i];
+    float lc = fminf(fmaxf(l, -10.f), 10.f);
+    gmu[i] = mu[i] * s;
+    glv[i] = (l >= -10.f && l <= 10.f) ? -0.5f * (1.f - expf(lc)) * s : 0.f;
+  }
+}
+extern "C" int vcg_kl_bwd(const float* mu, const float* lv, const float* gout, float* gmu, float* glv, size_t n,
+                          void* stream) {
+  VCG_CHECK_ARG(mu && lv && gout && gmu && glv && n > 0, "vcg_kl_bwd: bad args");
+  hipLaunchKernelGGL(k_kl_bwd, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, mu, lv, gout, gmu, glv, n,
+                     1.0f / (float)n);
+  VCG_LAUNCH_CHECK("vcg_kl_bwd");
+  return 0;
+}
+
+// LSGAN: one wave handles the (B,) discriminator output
+__global__ void k_mse_const_fwd(const float* __restrict__ d, float target, float* __restrict__ out, size_t n) {
+  double s = 0.0, m = 0.0;
+  for (size_t i = threadIdx.x; i < n; i += 64) {
+    float e = d[i] - target;
+    s += (double)(e * e);
+    m += (double)d[i];
+  }
+  s = wave_sum_d(s);
+  m = wave_sum_d(m);
+  if (threadIdx.x == 0) {
+    out[0] = (float)(s / (double)n);
+    out[1] = (float)(m / (double)n);
+  }
+}
+__global__ void k_mse_const_bwd(const float* __restrict__ d, float target, const float* __restrict__ gout,
+                                float* __restrict__ gd, size_t n) {
+  const float s = gout[0] * 2.0f / (float)n;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    gd[i] = (d[i] - target) * s;
+}
+extern "C" int vcg_mse_const_fwd(const float* d, float target, float* out, size_t n, void* stream) {
+  VCG_CHECK_ARG(d && out && n > 0, "vcg_mse_const_fwd: bad args");
+  hipLaunchKernelGGL(k_mse_const_fwd, dim3(1), dim3(64), 0, (hipStream_t)stream, d, target, out, n);
+  VCG_LAUNCH_CHECK("vcg_mse_const_fwd");
+  return 0;
+}
+extern "C" int vcg_mse_const_bwd(const float* d, float target, const float* gout, float* gd, size_t n, void* stream) {
+  VCG_CHECK_ARG(d && gout && gd && n > 0, "vcg_mse_const_bwd: bad args");
+  hipLaunchKernelGGL(k_mse_const_bwd, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, d, target, gout, gd, n);
+  VCG_LAUNCH_CHECK("vcg_mse_const_bwd");
+  return 0;
+}
+
+struct LinComb {
+  const float* s[16];
+  float w[16];
+  int count;
+};
+__global__ void k_lincomb(LinComb lc, float* __restrict__ out) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    float acc = 0.f;
+    for (int i = 0; i < lc.count; ++i) acc += lc.w[i] * lc.s[i][0];
+    out[0] = acc;
+  }
+}
+extern "C" int vcg_lincomb_fwd(const float* const* s, const float* w, int count, float* out, void* stream) {
+  VCG_CHECK_ARG(s && w && out && count > 0 && count <= 16, "vcg_lincomb_fwd: bad args (count %d)", count);
+  LinComb lc;
+  memset(&lc, 0, sizeof(lc));
+  lc.count = count;
+  for (int i = 0; i < count; ++i) {
+    VCG_CHECK_ARG(s[i], "vcg_lincomb_fwd: null term %d", i);
+    lc.s[i] = s[i];
+    lc.w[i] = w[i];
+  }
+  hipLaunchKernelGGL(k_lincomb, dim3(1), dim3(64), 0, (hipStream_t)stream, lc, out);
+  VCG_LAUNCH_CHECK("vcg_lincomb_fwd");
+  return 0;
+}
+
+// ---------------------------------------------------------------- spectral norm + full-map conv
+// W is (1, C, KH, KW): a 1 x K matrix, so the power iteration collapses to two dot products.
+// v stays in OIHW order (state_dict parity); wsn_k is W/sigma permuted to (kh, kw, c) = the
+// NHWC order of the 16x16x512 feature map it is dotted with.
+__global__ __launch_bounds__(1024) void k_sn_prepare(const float* __restrict__ w, float* __restrict__ u,
+                                                     float* __restrict__ v, float* __restrict__ sigma,
+                                                     float* __restrict__ wsn_k, int C, int KH, int KW,
+                                                     int update_uv) {
+  __shared__ float red[16];
+  const int K = C * KH * KW, KK = KH * KW;
+  const float u0 = u[0];
+  float wv_sum;
+  float vnorm_inv = 0.f;
+  if (update_uv) {
+    float s = 0.f;
+    for (int k = threadIdx.x; k < K; k += blockDim.x) { float x = w[k] * u0; s += x * x; }
+    float nrm = sqrtf(block_sum(s, red));
+    vnorm_inv = 1.0f / fmaxf(nrm, 1e-12f);
+    float t = 0.f;
+    for (int k = threadIdx.x; k < K; k += blockDim.x) { float vk = w[k] * u0 * vnorm_inv; t += w[k] * vk; }
+    wv_sum = block_sum(t, red);
+  } else {
+    float t = 0.f;
+    for (int k = threadIdx.x; k < K; k += blockDim.x) t += w[k] * v[k];
+    wv_sum = block_sum(t, red);
+  }
+  float un = update_uv ? wv_sum / fmaxf(fabsf(wv_sum), 1e-12f) : u0;
+  float sg = un * wv_sum;
+  for (int k = threadIdx.x; k < K; k += blockDim.x) {
+    float wk = w[k];
+    if (update_uv) v[k] = wk * u0 * vnorm_inv;
+    int c = k / KK, r = k - c * KK;  // r = kh*KW + kw
+    wsn_k[(size_t)r * C + c] = wk / sg;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    sigma[0] = sg;
+    if (update_uv) u[0] = un;
+  }
+}
+extern "C" int vcg_sn_prepare(const float* w_orig_oihw, float* u, float* v, float* sigma, float* wsn_k, int C,
+                              int KH, int KW, int update_uv, void* ws, size_t ws_bytes, void* stream) {
+  (void)ws; (void)ws_bytes;
+  VCG_CHECK_ARG(w_orig_oihw && u && v && sigma && wsn_k && C > 0 && KH > 0 && KW > 0, "vcg_sn_prepare: bad args");
+  hipLaunchKernelGGL(k_sn_prepare, dim3(1), dim3(1024), 0, (hipStream_t)stream, w_orig_oihw, u, v, sigma, wsn_k, C,
+                     KH, KW, update_uv);
+  VCG_LAUNCH_CHECK("vcg_sn_prepare");
+  return 0;
+}
+
+__global__ __launch_bounds__(1024) void k_fullmap_fwd(const float* __restrict__ x, const float* __restrict__ w,
+                                                      const float* __restrict__ bias, float* __restrict__ out,
+                                                      size_t K) {
+  __shared__ float red[16];
+  const float* xn = x + (size_t)blockIdx.x * K;
+  float s = 0.f;
+  const size_t K4 = K / 4;
+  for (size_t i = threadIdx.x; i < K4; i += blockDim.x) {
+    float4 a = reinterpret_cast<const float4*>(xn)[i];
+    float4 b = reinterpret_cast<const float4*>(w)[i];
+    s += a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
+  }
+  float tot = block_sum(s, red);
+  if (threadIdx.x == 0) out[blockIdx.x] = tot + (bias ? bias[0] : 0.f);
+}
+extern "C" int vcg_fullmap_fwd(const float* x, const float* wsn_k, const float* bias, float* out, int N, size_t K,
+                               void* stream) {
+  VCG_CHECK_ARG(x && wsn_k && out && N > 0 && K > 0 && K % 4 == 0, "vcg_fullmap_fwd: bad args");
+  hipLaunchKernelGGL(k_fullmap_fwd, dim3(N), dim3(1024), 0, (hipStream_t)stream, x, wsn_k, bias, out, K);
+  VCG_LAUNCH_CHECK("vcg_fullmap_fwd");
+  return 0;
+}
+__global__ void k_fullmap_dgrad(const float* __restrict__ g, const float* __restrict__ w, float* __restrict__ dx,
+                                int N, size_t K4) {
+  const size_t total = (size_t)N * K4;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (size_t)gridDim.x * blockDim.x) {
+    size_t n = idx / K4, k = idx - n * K4;
+    float gn = g[n];
+    float4 b = reinterpret_cast<const float4*>(w)[k];
+    reinterpret_cast<float4*>(dx)[idx] = make_float4(gn * b.x, gn * b.y, gn * b.z, gn * b.w);
+  }
+}
+extern "C" int vcg_fullmap_dgrad(const float* g, const float* wsn_k, float* dx, int N, size_t K, void* stream) {
+  VCG_CHECK_ARG(g && wsn_k && dx && N > 0 && K % 4 == 0, "vcg_fullmap_dgrad: bad args");
+  hipLaunchKernelGGL(k_fullmap_dgrad, dim3(ew_blocks((size_t)N * K / 4)), dim3(256), 0, (hipStream_t)stream, g,
+                     wsn_k, dx, N, K / 4);
+  VCG_LAUNCH_CHECK("vcg_fullmap_dgrad");
+  return 0;
+}
+// stage 1: gk[k] = sum_n g[n] x[n][k]; part[block] = sum_k gk[k] * wsn[k]
+__global__ __launch_bounds__(256) void k_fullmap_wgrad1(const float* __restrict__ g, const float* __restrict__ x,
+                                                        const float* __restrict__ w, float* __restrict__ gk,
+                                                        float* __restrict__ part, int N, size_t K) {
+  __shared__ float red[4];
+  float s = 0.f;
+  for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < K; k += (size_t)gridDim.x * blockDim.x) {
+    float acc = 0.f;
+    for (int n = 0; n < N; ++n) acc += g[n] * x[(size_t)n * K + k];
+    gk[k] = acc;
+    s += acc * w[k];
+  }
+  float tot = block_sum(s, red);
+  if (threadIdx.x == 0) part[blockIdx.x] = tot;
+}
+// stage 2: gw_orig[oihw(k)] += (gk[k] - dot * u*v[oihw(k)]) / sigma
+__global__ __launch_bounds__(256) void k_fullmap_wgrad2(const float* __restrict__ gk, const float* __restrict__ part,
+                                                        int nparts, const float* __restrict__ sigma,
+                                                        const float* __restrict__ u, const float* __restrict__ v,
+                                                        const float* __restrict__ g, float* __restrict__ gw,
+                                                        float* __restrict__ gbias, int N, int C, int KK) {
+  __shared__ float dot_s;
+  if (threadIdx.x < 64) {
+    double s = 0.0;
+    for (int i = threadIdx.x; i < nparts; i += 64) s += (double)part[i];
+    s = wave_sum_d(s);
+    if (threadIdx.x == 0) dot_s = (float)s;
+  }
+  __syncthreads();
+  const float dot = dot_s, inv_sigma = 1.0f / sigma[0], u0 = u[0];
+  const size_t K = (size_t)C * KK;
+  for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < K; k += (size_t)gridDim.x * blockDim.x) {
+    int r = (int)(k / C), c = (int)(k - (size_t)r * C);  // k = r*C + c (NHWC-K order)
+    size_t o = (size_t)c * KK + r;
+    gw[o] += (gk[k] - dot * u0 * v[o]) * inv_sigma;
+  }
+  if (gbias && blockIdx.x == 0 && threadIdx.x == 0) {
+    float s = 0.f;
+    for (int n = 0; n < N; ++n) s += g[n];
+    gbias[0] += s;
+  }
+}
+static const int kFmBlocks = 256;
+extern "C" int vcg_fullmap_wgrad(const float* g, const float* x, const float* wsn_k, const float* sigma,
+                                 const float* u, const float* v, float* gw_orig_oihw, float* gbias, int N, int C,
+                                 int KH, int KW, void* ws, size_t ws_bytes, void* stream) {
+  VCG_CHECK_ARG(g && x && wsn_k && sigma && u && v && gw_orig_oihw && ws, "vcg_fullmap_wgrad: null pointer");
+  VCG_CHECK_ARG(N > 0 && C > 0 && KH > 0 && KW > 0, "vcg_fullmap_wgrad: bad dims");
+  const size_t K = (size_t)C * KH * KW;
+  VCG_CHECK_ARG(ws_bytes >= (K + kFmBlocks) * sizeof(float), "vcg_fullmap_wgrad: workspace too small");
+  float* gk = (float*)ws;
+  float* part = gk + K;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_fullmap_wgrad1, dim3(kFmBlocks), dim3(256), 0, st, g, x, wsn_k, gk, part, N, K);
+  hipLaunchKernelGGL(k_fullmap_wgrad2, dim3(kFmBlocks), dim3(256), 0, st, (const float*)gk, (const float*)part,
+                     kFmBlocks, sigma, u, v, g, gw_orig_oihw, gbias, N, C, KH * KW);
+  VCG_LAUNCH_CHECK("vcg_fullmap_wgrad");
+  return 0;
+}
+
+// ---------------------------------------------------------------- Adam
+// torch.optim.adam._single_tensor_adam, fp32, amsgrad=False, weight_decay=0, maximize=False:
+//   exp_avg.lerp_(grad, 1-beta1); exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value=1-beta2)
+//   denom = exp_avg_sq.sqrt() / bias_correction2_sqrt + eps; param.addcdiv_(exp_avg, denom, value=-step_size)
+// One launch over the model's flat parameter buffer: 28 B/param of HBM traffic, float4 per lane.
+__global__ __launch_bounds__(256) void k_adam(float* __restrict__ p, const float* __restrict__ g,
+                                              float* __restrict__ m, float* __restrict__ v, size_t n,
+                                              float step_size, float b1, float b2, float eps, float bc2_sqrt,
+                                              float gscale) {
+  const size_t n4 = n / 4;
+  const float w1 = 1.f - b1, w2 = 1.f - b2;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    float4 pv = reinterpret_cast<float4*>(p)[i];
+    float4 gv = reinterpret_cast<const float4*>(g)[i];
+    float4 mv = reinterpret_cast<float4*>(m)[i];
+    float4 vv = reinterpret_cast<float4*>(v)[i];
+#define ADAM1(c)                                         \
+    {                                                    \
+      float gg = gv.c * gscale;                          \
+      mv.c = mv.c + w1 * (gg - mv.c);                    \
+      vv.c = vv.c * b2 + w2 * gg * gg;                   \
+      float den = sqrtf(vv.c) / bc2_sqrt + eps;          \
+      pv.c = pv.c - step_size * (mv.c / den);            \
+    }
+    ADAM1(x) ADAM1(y) ADAM1(z) ADAM1(w)
+    reinterpret_cast<float4*>(p)[i] = pv;
+    reinterpret_cast<float4*>(m)[i] = mv;
+    reinterpret_cast<float4*>(v)[i] = vv;
+  }
+  if (blockIdx.x == 0)
+    for (size_t i = n4 * 4 + threadIdx.x; i < n; i += blockDim.x) {
+      float gg = g[i] * gscale;
+      float mm = m[i] + w1 * (gg - m[i]);
+      float vv = v[i] * b2 + w2 * gg * gg;
+      float den = sqrtf(vv) / bc2_sqrt + eps;
+      p[i] = p[i] - step_size * (mm / den);
+      m[i] = mm;
+      v[i] = vv;
+    }
+}
+extern "C" int vcg_adam_step(float* p, const float* g, float* m, float* v, size_t n, float step_size, float beta1,
+                             float beta2, float eps, float bc2_sqrt, float grad_scale, void* stream) {
+  VCG_CHECK_ARG(p && g && m && v, "vcg_adam_step: null pointer");
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(k_adam, dim3(ew_blocks(n / 4 + 1)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, step_size,
+                     beta1, beta2, eps, bc2_sqrt, grad_scale);
+  VCG_LAUNCH_CHECK("vcg_adam_step");
+  return 0;
+}

@@ -1,0 +1,335 @@
+// InstanceNorm2d (eps 1e-5, biased variance, no affine, no running stats) forward and
+// backward on NHWC activations.  Replaces nn.InstanceNorm2d at Networks.py:61,88,102,105,123
+// together with the activation that sits next to it (ReLU before the norm in D/U/R.conv1
+// :94,:111,:129; after it in CaSb :79-80) and, for U, the nn.PixelShuffle(2) (:121) that
+// follows in the next block, folded here into the store address.
+//
+// All of it is HBM-bound.  Per (n, c) reductions run in two stages: a workgroup sums one
+// pixel chunk for a group of channel quads (float4 per lane, 64 lanes = 1 KiB per row
+// segment), then a tiny kernel combines the chunk partials in double precision in a fixed
+// order, so results are bitwise reproducible and free of the E[x^2]-E[x]^2 cancellation
+// a single fp32 pass would have.
+#include "vcg_common.h"
+
+struct NormPlan {
+  int TC, TP, cgroups, nchunk, chunk;
+};
+
+static NormPlan make_plan(int N, int HW, int C) {
+  NormPlan pl;
+  int c4 = C / 4;
+  int tc = 1;
+  while (tc * 2 <= c4 && tc * 2 <= 256) tc *= 2;
+  pl.TC = tc;
+  pl.TP = 256 / tc;
+  pl.cgroups = (c4 + tc - 1) / tc;
+  long long target = 1024 / ((long long)N * pl.cgroups);
+  if (target < 1) target = 1;
+  long long maxc = (HW + pl.TP * 2 - 1) / (pl.TP * 2);
+  if (maxc < 1) maxc = 1;
+  if (target > maxc) target = maxc;
+  pl.chunk = (int)((HW + target - 1) / target);
+  pl.nchunk = (HW + pl.chunk - 1) / pl.chunk;
+  return pl;
+}
+
+// ---- stage 1 of every per-(n,c) reduction -------------------------------------------
+// MODE 0: (sum t, sum t^2)
+// MODE 1: (sum g', sum g' * xhat)  with xhat=(t-mean)*rstd, g' = g * post_act'(xhat)
+template <int MODE>
+__global__ __launch_bounds__(256) void k_in_partial(const float* __restrict__ t, const float* __restrict__ g,
+                                                    const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                    float* __restrict__ part, int H, int W, int C, NormPlan pl,
+                                                    int post_act, int shuffle) {
+  __shared__ float4 r1[256];
+  __shared__ float4 r2[256];
+  const int tc = threadIdx.x % pl.TC, tp = threadIdx.x / pl.TC;
+  const int c4 = blockIdx.z * pl.TC + tc;
+  const int n = blockIdx.y;
+  const int HW = H * W;
+  const int pb = blockIdx.x * pl.chunk;
+  int pe = pb + pl.chunk;
+  if (pe > HW) pe = HW;
+  float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
+  if (c4 * 4 < C) {
+    float4 mu = s1, rs = s1;
+    if (MODE == 1) {
+      mu = *reinterpret_cast<const float4*>(mean + (size_t)n * C + c4 * 4);
+      rs = *reinterpret_cast<const float4*>(rstd + (size_t)n * C + c4 * 4);
+    }
+    for (int pix = pb + tp; pix < pe; pix += pl.TP) {
+      float4 v = *reinterpret_cast<const float4*>(t + ((size_t)n * HW + pix) * C + c4 * 4);
+      if (MODE == 0) {
+        s1.x += v.x; s1.y += v.y; s1.z += v.z; s1.w += v.w;
+        s2.x += v.x * v.x; s2.y += v.y * v.y; s2.z += v.z * v.z; s2.w += v.w * v.w;
+      } else {
+        float4 gv;
+        if (shuffle) {
+          // g lives in the pixel-shuffled tensor (N, 2H, 2W, C/4): element e of the quad
+          // sits at pixel (2h + e/2, 2w + e%2), channel c4
+          const int h = pix / W, w = pix - h * W;
+          const int Cq = C / 4;
+          const float* gp = g + (((size_t)n * 2 * H + 2 * h) * (2 * W) + 2 * w) * Cq + c4;
+          gv.x = gp[0];
+          gv.y = gp[Cq];
+          gv.z = gp[(size_t)2 * W * Cq];
+          gv.w = gp[(size_t)2 * W * Cq + Cq];
+        } else {
+          gv = *reinterpret_cast<const float4*>(g + ((size_t)n * HW + pix) * C + c4 * 4);
+        }
+        float4 xh;
+        xh.x = (v.x - mu.x) * rs.x; xh.y = (v.y - mu.y) * rs.y;
+        xh.z = (v.z - mu.z) * rs.z; xh.w = (v.w - mu.w) * rs.w;
+        gv.x *= act_grad_from_out(xh.x, post_act); gv.y *= act_grad_from_out(xh.y, post_act);
+        gv.z *= act_grad_from_out(xh.z, post_act); gv.w *= act_grad_from_out(xh.w, post_act);
+        s1.x += gv.x; s1.y += gv.y; s1.z += gv.z; s1.w += gv.w;
+        s2.x += gv.x * xh.x; s2.y += gv.y * xh.y; s2.z += gv.z * xh.z; s2.w += gv.w * xh.w;
+      }
+    }
+  }
+  r1[threadIdx.x] = s1;
+  r2[threadIdx.x] = s2;
+  __syncthreads();
+  if (tp == 0 && c4 * 4 < C) {
+    for (int k = 1; k < pl.TP; ++k) {
+      float4 a = r1[k * pl.TC + tc], b = r2[k * pl.TC + tc];
+      s1.x += a.x; s1.y += a.y; s1.z += a.z; s1.w += a.w;
+      s2.x += b.x; s2.y += b.y; s2.z += b.z; s2.w += b.w;
+    }
+    float* o = part + (((size_t)n * pl.nchunk + blockIdx.x) * C + c4 * 4) * 2;
+    o[0] = s1.x; o[1] = s2.x; o[2] = s1.y; o[3] = s2.y;
+    o[4] = s1.z; o[5] = s2.z; o[6] = s1.w; o[7] = s2.w;
+  }
+}
+
+// MODE 0: mean, rstd.  MODE 1: (s1/HW, s2/HW) interleaved into out1[(n*C+c)*2 + {0,1}]
+template <int MODE>
+__global__ void k_in_final(const float* __restrict__ part, float* __restrict__ out1, float* __restrict__ out2,
+                           int N, int HW, int C, int nchunk, float eps) {
+  int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= N * C) return;
+  int n = idx / C, c = idx - n * C;
+  double a = 0.0, b = 0.0;
+  for (int k = 0; k < nchunk; ++k) {
+    const float* p = part + (((size_t)n * nchunk + k) * C + c) * 2;
+    a += (double)p[0];
+    b += (double)p[1];
+  }
+  if (MODE == 0) {
+    double m = a / HW;
+    double var = b / HW - m * m;
+    if (var < 0.0) var = 0.0;
+    out1[idx] = (float)m;
+    out2[idx] = (float)(1.0 / sqrt(var + (double)eps));
+  } else {
+    out1[(size_t)idx * 2] = (float)(a / HW);
+    out1[(size_t)idx * 2 + 1] = (float)(b / HW);
+  }
+}
+
+__global__ __launch_bounds__(256) void k_in_apply(const float* __restrict__ t, const float* __restrict__ mean,
+                                                  const float* __restrict__ rstd, const float* __restrict__ residual,
+                                                  float* __restrict__ out, int N, int H, int W, int C, int post_act,
+                                                  int shuffle) {
+  const int C4 = C / 4;
+  const size_t total = (size_t)N * H * W * C4;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (size_t)gridDim.x * blockDim.x) {
+    const int c4 = (int)(idx % C4);
+    const size_t pixg = idx / C4;  // n*HW + pix
+    const int n = (int)(pixg / ((size_t)H * W));
+    float4 v = *reinterpret_cast<const float4*>(t + pixg * C + c4 * 4);
+    float4 mu = *reinterpret_cast<const float4*>(mean + (size_t)n * C + c4 * 4);
+    float4 rs = *reinterpret_cast<const float4*>(rstd + (size_t)n * C + c4 * 4);
+    float4 o;
+    o.x = act_apply((v.x - mu.x) * rs.x, post_act);
+    o.y = act_apply((v.y - mu.y) * rs.y, post_act);
+    o.z = act_apply((v.z - mu.z) * rs.z, post_act);
+    o.w = act_apply((v.w - mu.w) * rs.w, post_act);
+    if (residual) {
+      float4 r = *reinterpret_cast<const float4*>(residual + pixg * C + c4 * 4);
+      o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
+    }
+    if (shuffle) {
+      const int pix = (int)(pixg - (size_t)n * H * W);
+      const int h = pix / W, w = pix - h * W;
+      float* op = out + (((size_t)n * 2 * H + 2 * h) * (2 * W) + 2 * w) * C4 + c4;
+      op[0] = o.x;
+      op[C4] = o.y;
+      op[(size_t)2 * W * C4] = o.z;
+      op[(size_t)2 * W * C4 + C4] = o.w;
+    } else {
+      *reinterpret_cast<float4*>(out + pixg * C + c4 * 4) = o;
+    }
+  }
+}
+
+// dt = epi'(t) * rstd * (g' - s1 - xhat * s2)
+__global__ __launch_bounds__(256) void k_in_bwd_apply(const float* __restrict__ g, const float* __restrict__ t,
+                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                      const float* __restrict__ s12, float* __restrict__ dt, int N,
+                                                      int H, int W, int C, int epi_act, int post_act, int shuffle) {
+  const int C4 = C / 4;
+  const size_t total = (size_t)N * H * W * C4;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (size_t)gridDim.x * blockDim.x) {
+    const int c4 = (int)(idx % C4);
+    const size_t pixg = idx / C4;
+    const int n = (int)(pixg / ((size_t)H * W));
+    float4 v = *reinterpret_cast<const float4*>(t + pixg * C + c4 * 4);
+    float4 mu = *reinterpret_cast<const float4*>(mean + (size_t)n * C + c4 * 4);
+    float4 rs = *reinterpret_cast<const float4*>(rstd + (size_t)n * C + c4 * 4);
+    const float* sp = s12 + ((size_t)n * C + c4 * 4) * 2;
+    float4 gv;
+    if (shuffle) {
+      const int pix = (int)(pixg - (size_t)n * H * W);
+      const int h = pix / W, w = pix - h * W;
+      const float* gp = g + (((size_t)n * 2 * H + 2 * h) * (2 * W) + 2 * w) * C4 + c4;
+      gv.x = gp[0];
+      gv.y = gp[C4];
+      gv.z = gp[(size_t)2 * W * C4];
+      gv.w = gp[(size_t)2 * W * C4 + C4];
+    } else {
+      gv = *reinterpret_cast<const float4*>(g + pixg * C + c4 * 4);
+    }
+    float xh, gg;
+    float4 o;
+    xh = (v.x - mu.x) * rs.x; gg = gv.x * act_grad_from_out(xh, post_act);
+    o.x = act_grad_from_out(v.x, epi_act) * rs.x * (gg - sp[0] - xh * sp[1]);
+    xh = (v.y - mu.y) * rs.y; gg = gv.y * act_grad_from_out(xh, post_act);
+    o.y = act_grad_from_out(v.y, epi_act) * rs.y * (gg - sp[2] - xh * sp[3]);
+    xh = (v.z - mu.z) * rs.z; gg = gv.z * act_grad_from_out(xh, post_act);
+    o.z = act_grad_from_out(v.z, epi_act) * rs.z * (gg - sp[4] - xh * sp[5]);
+    xh = (v.w - mu.w) * rs.w; gg = gv.w * act_grad_from_out(xh, post_act);
+    o.w = act_grad_from_out(v.w, epi_act) * rs.w * (gg - sp[6] - xh * sp[7]);
+    *reinterpret_cast<float4*>(dt + pixg * C + c4 * 4) = o;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_act_bwd(const float* __restrict__ g, const float* __restrict__ t,
+                                                 float* __restrict__ dt, size_t n4, int act) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    float4 gv = reinterpret_cast<const float4*>(g)[i];
+    float4 tv = reinterpret_cast<const float4*>(t)[i];
+    float4 o;
+    o.x = gv.x * act_grad_from_out(tv.x, act);
+    o.y = gv.y * act_grad_from_out(tv.y, act);
+    o.z = gv.z * act_grad_from_out(tv.z, act);
+    o.w = gv.w * act_grad_from_out(tv.w, act);
+    reinterpret_cast<float4*>(dt)[i] = o;
+  }
+}
+
+static int ew_blocks(size_t work) {
+  size_t b = (work + 255) / 256;
+  if (b > 2048) b = 2048;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+extern "C" size_t vcg_in_workspace(int N, int HW, int C) {
+  if (N <= 0 || HW <= 0 || C <= 0 || C % 4) return 0;
+  NormPlan pl = make_plan(N, HW, C);
+  return ((size_t)N * pl.nchunk * C * 2 + (size_t)N * C * 2) * sizeof(float) + 256;
+}
+
+extern "C" int vcg_in_stats(const float* t, float* mean, float* rstd, int N, int HW, int C, float eps,
+                            void* ws, size_t ws_bytes, void* stream) {
+  VCG_CHECK_ARG(t && mean && rstd && ws, "vcg_in_stats: null pointer");
+  VCG_CHECK_ARG(N > 0 && HW > 0 && C > 0 && C % 4 == 0, "vcg_in_stats: bad dims N=%d HW=%d C=%d", N, HW, C);
+  VCG_CHECK_ARG(ws_bytes >= vcg_in_workspace(N, HW, C), "vcg_in_stats: workspace too small");
+  NormPlan pl = make_plan(N, HW, C);
+  hipStream_t st = (hipStream_t)stream;
+  float* part = (float*)ws;
+  hipLaunchKernelGGL(k_in_partial<0>, dim3(pl.nchunk, N, pl.cgroups), dim3(256), 0, st, t, (const float*)nullptr,
+                     (const float*)nullptr, (const float*)nullptr, part, HW, 1, C, pl, 0, 0);
+  hipLaunchKernelGGL(k_in_final<0>, dim3((N * C + 255) / 256), dim3(256), 0, st, (const float*)part, mean, rstd, N,
+                     HW, C, pl.nchunk, eps);
+  VCG_LAUNCH_CHECK("vcg_in_stats");
+  return 0;
+}
+
+extern "C" int vcg_in_apply(const float* t, const float* mean, const float* rstd, const float* residual,
+                            float* out, int N, int H, int W, int C, int post_act, int shuffle, void* stream) {
+  VCG_CHECK_ARG(t && mean && rstd && out, "vcg_in_apply: null pointer");
+  VCG_CHECK_ARG(N > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "vcg_in_apply: bad dims");
+  VCG_CHECK_ARG(!(shuffle && residual), "vcg_in_apply: shuffle with residual unsupported");
+  VCG_CHECK_ARG(!shuffle || C % 16 == 0, "vcg_in_apply: pixel shuffle needs C %% 16 == 0 (channel pitch stays a multiple of 4)");
+  size_t total = (size_t)N * H * W * (C / 4);
+  hipLaunchKernelGGL(k_in_apply, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, t, mean, rstd, residual,
+                     out, N, H, W, C, post_act, shuffle);
+  VCG_LAUNCH_CHECK("vcg_in_apply");
+  return 0;
+}
+
+extern "C" int vcg_in_bwd(const float* g, const float* t, const float* mean, const float* rstd, float* dt,
+                          int N, int H, int W, int C, int epi_act, int post_act, int shuffle,
+                          void* ws, size_t ws_bytes, void* stream) {
+  VCG_CHECK_ARG(g && t && mean && rstd && dt && ws, "vcg_in_bwd: null pointer");
+  VCG_CHECK_ARG(N > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "vcg_in_bwd: bad dims");
+  VCG_CHECK_ARG(!shuffle || C % 16 == 0, "vcg_in_bwd: pixel shuffle needs C %% 16 == 0");
+  const int HW = H * W;
+  VCG_CHECK_ARG(ws_bytes >= vcg_in_workspace(N, HW, C), "vcg_in_bwd: workspace too small");
+  NormPlan pl = make_plan(N, HW, C);
+  hipStream_t st = (hipStream_t)stream;
+  float* part = (float*)ws;
+  float* s12 = part + (size_t)N * pl.nchunk * C * 2;
+  hipLaunchKernelGGL(k_in_partial<1>, dim3(pl.nchunk, N, pl.cgroups), dim3(256), 0, st, t, g, mean, rstd, part, H, W,
+                     C, pl, post_act, shuffle);
+  hipLaunchKernelGGL(k_in_final<1>, dim3((N * C + 255) / 256), dim3(256), 0, st, (const float*)part, s12,
+                     (float*)nullptr, N, HW, C, pl.nchunk, 0.f);
+  size_t total = (size_t)N * HW * (C / 4);
+  hipLaunchKernelGGL(k_in_bwd_apply, dim3(ew_blocks(total)), dim3(256), 0, st, g, t, mean, rstd, (const float*)s12,
+                     dt, N, H, W, C, epi_act, post_act, shuffle);
+  VCG_LAUNCH_CHECK("vcg_in_bwd");
+  return 0;
+}
+
+extern "C" int vcg_act_bwd(const float* g, const float* t, float* dt, size_t n, int act, void* stream) {
+  VCG_CHECK_ARG(g && t && dt, "vcg_act_bwd: null pointer");
+  VCG_CHECK_ARG(n % 4 == 0, "vcg_act_bwd: n must be a multiple of 4");
+  hipLaunchKernelGGL(k_act_bwd, dim3(ew_blocks(n / 4)), dim3(256), 0, (hipStream_t)stream, g, t, dt, n / 4, act);
+  VCG_LAUNCH_CHECK("vcg_act_bwd");
+  return 0;
+}
+
+// nn.PixelShuffle(2) (Networks.py:121) as a standalone copy, and its inverse (the backward).
+// (N,H,W,C) <-> (N,2H,2W,C/4): channel 4c+2i+j of pixel (h,w) <-> channel c of pixel (2h+i, 2w+j)
+__global__ __launch_bounds__(256) void k_pixel_shuffle(const float* __restrict__ src, float* __restrict__ dst, int N,
+                                                       int H, int W, int C, int inverse) {
+  const int C4 = C / 4;
+  const size_t total = (size_t)N * H * W * C4;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (size_t)gridDim.x * blockDim.x) {
+    const int c4 = (int)(idx % C4);
+    const size_t pixg = idx / C4;
+    const int n = (int)(pixg / ((size_t)H * W));
+    const int pix = (int)(pixg - (size_t)n * H * W);
+    const int h = pix / W, w = pix - h * W;
+    const size_t big = (((size_t)n * 2 * H + 2 * h) * (2 * W) + 2 * w) * C4 + c4;
+    const size_t small = pixg * C + c4 * 4;
+    if (!inverse) {
+      float4 v = *reinterpret_cast<const float4*>(src + small);
+      dst[big] = v.x;
+      dst[big + C4] = v.y;
+      dst[big + (size_t)2 * W * C4] = v.z;
+      dst[big + (size_t)2 * W * C4 + C4] = v.w;
+    } else {
+      float4 v;
+      v.x = src[big];
+      v.y = src[big + C4];
+      v.z = src[big + (size_t)2 * W * C4];
+      v.w = src[big + (size_t)2 * W * C4 + C4];
+      *reinterpret_cast<float4*>(dst + small) = v;
+    }
+  }
+}
+extern "C" int vcg_pixel_shuffle(const float* src, float* dst, int N, int H, int W, int C, int inverse, void* stream) {
+  VCG_CHECK_ARG(src && dst && N > 0 && H > 0 && W > 0 && C > 0 && C % 16 == 0,
+                "vcg_pixel_shuffle: bad args (C=%d must be a multiple of 16)", C);
+  size_t total = (size_t)N * H * W * (C / 4);
+  hipLaunchKernelGGL(k_pixel_shuffle, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, src, dst, N, H, W, C,
+                     inverse);
+  VCG_LAUNCH_CHECK("vcg_pixel_shuffle");
+  return 0;
+}

@@ -1,0 +1,101 @@
+// Shared host/device helpers for libvcg (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "../../include/vcg.h"
+
+#define VCG_WAVE 64
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+void vcg_set_error(const char* fmt, ...);
+
+#define VCG_CHECK_ARG(cond, ...)      \
+  do {                                \
+    if (!(cond)) {                    \
+      vcg_set_error(__VA_ARGS__);     \
+      return -1;                      \
+    }                                 \
+  } while (0)
+
+#define VCG_LAUNCH_CHECK(name)                                              \
+  do {                                                                      \
+    hipError_t e__ = hipGetLastError();                                     \
+    if (e__ != hipSuccess) {                                                \
+      vcg_set_error("%s: launch failed: %s", name, hipGetErrorString(e__)); \
+      return -2;                                                            \
+    }                                                                       \
+  } while (0)
+
+// division by a runtime constant: q = (umulhi(n, mul) + n) >> sh, valid for n < 2^31
+struct FastDiv {
+  uint32_t d, mul, sh;
+};
+
+static inline FastDiv make_fastdiv(uint32_t d) {
+  FastDiv f;
+  f.d = d;
+  if (d <= 1) {
+    f.mul = 0;
+    f.sh = 0;
+    return f;
+  }
+  uint32_t sh = 0;
+  while ((1ull << sh) < d) ++sh;
+  f.sh = sh;
+  f.mul = (uint32_t)((((1ull << sh) - d) << 32) / d + 1);
+  return f;
+}
+
+__host__ __device__ static inline uint32_t fd_div(uint32_t n, const FastDiv& f) {
+#ifdef __HIP_DEVICE_COMPILE__
+  return (__umulhi(n, f.mul) + n) >> f.sh;
+#else
+  return (uint32_t)((((uint64_t)n * f.mul) >> 32) + n) >> f.sh;
+#endif
+}
+
+__host__ __device__ static inline void fd_divmod(uint32_t n, const FastDiv& f, uint32_t& q, uint32_t& r) {
+  q = fd_div(n, f);
+  r = n - q * f.d;
+}
+
+// reflect (no edge repeat) index map of torch 'reflect' padding; valid for -L < i < 2L-1
+__host__ __device__ static inline int reflect_idx(int i, int L) {
+  if (i < 0) i = -i;
+  if (i >= L) i = 2 * (L - 1) - i;
+  return i;
+}
+
+__device__ static inline float act_apply(float v, int act) {
+  if (act == VCG_ACT_RELU) return v > 0.f ? v : 0.f;
+  if (act == VCG_ACT_LEAKY02) return v > 0.f ? v : 0.2f * v;
+  return v;
+}
+// derivative expressed on the activation OUTPUT (sign is preserved by both)
+__device__ static inline float act_grad_from_out(float out, int act) {
+  if (act == VCG_ACT_RELU) return out > 0.f ? 1.f : 0.f;
+  if (act == VCG_ACT_LEAKY02) return out > 0.f ? 1.f : 0.2f;
+  return 1.f;
+}
+
+__device__ static inline float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ static inline double wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// geometry derived from the int32[16] conv descriptor
+struct ConvGeom {
+  int N, H, W, Cin, Cout, KH, KW, stride, pad, reflect, ups, act, cin_log, cout_log;
+  int Hl, Wl, Ho, Wo, M, K, taps;
+};
+
+int vcg_conv_geom(const int32_t* cd, ConvGeom* g, const char* who);

@@ -1,0 +1,681 @@
+"""Host-side operators: torch.autograd.Function wrappers over the libvcg C ABI.
+
+Tensors keep the reference's LOGICAL shape (N, C, H, W) but live in HBM as NHWC with a
+channel pitch that is a multiple of 4 (`nhwc_view`), so every module boundary of
+Networks.py is a zero-copy hand-off.  torch is used for device memory, streams and the
+autograd graph only; every arithmetic op below is a HIP kernel.  There is no fallback:
+CPU tensors raise.
+"""
+import ctypes
+import math
+
+import torch
+
+from . import _native
+
+ACT_NONE, ACT_RELU, ACT_LEAKY = 0, 1, 2
+_ACT = {"Identity": ACT_NONE, "ReLU": ACT_RELU, "LeakyReLU": ACT_LEAKY, None: ACT_NONE}
+
+IN_EPS = 1e-5  # nn.InstanceNorm2d default (Networks.py:61)
+
+# bumped whenever parameters change outside torch's version counters (fused Adam step)
+PARAM_EPOCH = [0]
+
+
+def pitch(c):
+    return (c + 3) // 4 * 4
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def _require_gpu(t, what):
+    if not t.is_cuda:
+        raise RuntimeError(f"{what}: expected a tensor on the MI355X (cuda) device, got {t.device}; "
+                           "this package has no CPU path")
+    if t.dtype != torch.float32:
+        raise RuntimeError(f"{what}: expected float32, got {t.dtype}")
+
+
+# ------------------------------------------------------------------ live kernel timing (bench.py)
+# When PROFILE is a list, every launch group below is bracketed by HIP events on the launch
+# stream and appended as (family, algorithmic_flops, start_event, end_event).
+PROFILE = None
+
+
+class _timed:
+    def __init__(self, family, flops=0.0):
+        self.family, self.flops = family, flops
+
+    def __enter__(self):
+        if PROFILE is not None:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e1 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+        return self
+
+    def __exit__(self, *a):
+        if PROFILE is not None:
+            self.e1.record()
+            PROFILE.append((self.family, self.flops, self.e0, self.e1))
+
+
+# ------------------------------------------------------------------ workspace
+_WS = {}
+
+
+def workspace(nbytes, device):
+    """One stream-ordered scratch buffer per device, grown on demand."""
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    buf = _WS.get(key)
+    if buf is None or buf.numel() * 4 < nbytes:
+        n = max(int(nbytes * 1.25) // 4 + 64, 1 << 20)
+        buf = torch.empty(n, dtype=torch.float32, device=device)
+        _WS[key] = buf
+    return buf
+
+
+# ------------------------------------------------------------------ layout
+def nhwc_strides(n, c, h, w):
+    p = pitch(c)
+    return (h * w * p, 1, w * p, p)
+
+
+def is_nhwc_view(t):
+    n, c, h, w = t.shape
+    return t.stride() == nhwc_strides(n, c, h, w)
+
+
+def phys_of(t):
+    """(N,H,W,P) contiguous alias of a logical (N,C,H,W) nhwc view."""
+    n, c, h, w = t.shape
+    p = pitch(c)
+    return t.as_strided((n, h, w, p), (h * w * p, w * p, p, 1), t.storage_offset())
+
+
+def logical_of(phys, c):
+    n, h, w, p = phys.shape
+    return phys.as_strided((n, c, h, w), (h * w * p, 1, w * p, p), phys.storage_offset())
+
+
+def _to_phys_copy(t):
+    """NCHW (any strides) -> fresh NHWC physical tensor, pad channels zeroed."""
+    _require_gpu(t, "to_nhwc")
+    n, c, h, w = t.shape
+    src = t.contiguous()
+    p = pitch(c)
+    dst = torch.empty((n, h, w, p), dtype=torch.float32, device=t.device)
+    _native.check(_native.lib().vcg_nchw_to_nhwc(_ptr(src), _ptr(dst), n, c, h, w, p, _stream()), "vcg_nchw_to_nhwc")
+    return dst
+
+
+def as_phys(t):
+    """Physical NHWC tensor for a logical NCHW tensor: alias if already laid out, else convert."""
+    if t.dim() != 4:
+        raise RuntimeError(f"expected a 4-D (N,C,H,W) tensor, got shape {tuple(t.shape)}")
+    _require_gpu(t, "as_phys")
+    if is_nhwc_view(t):
+        return phys_of(t)
+    return _to_phys_copy(t)
+
+
+def to_nchw_contiguous(t):
+    """Logical (N,C,H,W) nhwc view -> plain contiguous NCHW copy."""
+    _require_gpu(t, "to_nchw")
+    if not is_nhwc_view(t):
+        return t.contiguous()
+    n, c, h, w = t.shape
+    ph = phys_of(t)
+    dst = torch.empty((n, c, h, w), dtype=torch.float32, device=t.device)
+    _native.check(_native.lib().vcg_nhwc_to_nchw(_ptr(ph), _ptr(dst), n, c, h, w, pitch(c), _stream()), "vcg_nhwc_to_nchw")
+    return dst
+
+
+class _ToNHWC(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        return logical_of(_to_phys_copy(x), x.shape[1])
+
+    @staticmethod
+    def backward(ctx, g):
+        return to_nchw_contiguous(g)
+
+
+def to_nhwc(x):
+    """x.to(channels-last) with pitch-4 images; differentiable; no-op when already laid out."""
+    if x.dim() == 4 and x.is_cuda and is_nhwc_view(x):
+        return x
+    _require_gpu(x, "to_nhwc")
+    return _ToNHWC.apply(x)
+
+
+# ------------------------------------------------------------------ conv block
+class ConvSpec:
+    """Static description of one conv (+ fused activation / InstanceNorm / shuffle) block."""
+
+    def __init__(self, cin, cout, k, stride=1, pad=1, reflect=True, ups=1, epi_act=ACT_NONE, norm=False,
+                 post_act=ACT_NONE, shuffle=False):
+        self.cin, self.cout, self.k = cin, cout, k          # logical channels of the torch conv
+        self.stride, self.pad, self.reflect, self.ups = stride, pad, reflect, ups
+        self.epi_act, self.norm, self.post_act, self.shuffle = epi_act, norm, post_act, shuffle
+        if ups == 2:
+            assert cin % 4 == 0
+            self.cin_phys_log = cin // 4                   # channels of the un-shuffled input
+        else:
+            self.cin_phys_log = cin
+        self.cin_pitch = pitch(self.cin_phys_log)
+        self.cout_pitch = pitch(cout)
+        self._packed = None
+        self._packed_key = None
+
+    def desc(self, n, h, w):
+        cd = (ctypes.c_int32 * 16)()
+        cd[0], cd[1], cd[2] = n, h, w
+        cd[3], cd[4] = self.cin_pitch, self.cout_pitch
+        cd[5], cd[6], cd[7], cd[8] = self.k, self.k, self.stride, self.pad
+        cd[9], cd[10], cd[11] = int(self.reflect), self.ups, self.epi_act
+        cd[12], cd[13] = self.cin_phys_log, self.cout
+        return cd
+
+    def out_hw(self, h, w):
+        hl, wl = h // self.ups, w // self.ups
+        return ((hl + 2 * self.pad - self.k) // self.stride + 1, (wl + 2 * self.pad - self.k) // self.stride + 1)
+
+    def packed(self, weight):
+        """Wf[K][Cout] for the current parameter values (repacked once per optimizer step)."""
+        key = (PARAM_EPOCH[0], weight._version, weight.data_ptr())
+        if self._packed is None or self._packed_key != key or self._packed.device != weight.device:
+            kdim = self.k * self.k * self.ups * self.ups * self.cin_pitch
+            if self._packed is None or self._packed.device != weight.device:
+                self._packed = torch.empty(kdim * self.cout_pitch, dtype=torch.float32, device=weight.device)
+            w = weight.detach()
+            if not w.is_contiguous():
+                w = w.contiguous()
+            cd = self.desc(1, max(self.ups * self.k, 2 * self.ups * (self.pad + 1)), max(self.ups * self.k, 2 * self.ups * (self.pad + 1)))
+            _native.check(_native.lib().vcg_pack_weight(_ptr(w), _ptr(self._packed), cd, _stream()), "vcg_pack_weight")
+            self._packed_key = key
+        return self._packed
+
+
+# Phase control of the alternating GAN update.  `ctx.needs_input_grad` is fixed at forward
+# time, so the G phase (which needs only the discriminators' data gradient) and the D phase
+# (which must not spend a data gradient on the generators' images) say so explicitly.
+_NO_WGRAD = set()
+_NO_DGRAD = set()
+
+
+class no_wgrad:
+    """Within this context the backward skips weight/bias gradients of these parameters."""
+
+    def __init__(self, params):
+        self.ids = [id(p) for p in params]
+
+    def __enter__(self):
+        _NO_WGRAD.update(self.ids)
+
+    def __exit__(self, *a):
+        _NO_WGRAD.difference_update(self.ids)
+
+
+class no_dgrad:
+    """Within this context the backward skips the input gradient of these ConvSpecs."""
+
+    def __init__(self, specs):
+        self.ids = [id(s) for s in specs]
+
+    def __enter__(self):
+        _NO_DGRAD.update(self.ids)
+
+    def __exit__(self, *a):
+        _NO_DGRAD.difference_update(self.ids)
+
+
+def _grad_buffer(param):
+    """param.grad as an accumulation target (allocated zeroed on first use)."""
+    if param.grad is None:
+        param.grad = torch.zeros_like(param, memory_format=torch.contiguous_format)
+    g = param.grad
+    if not g.is_contiguous():
+        raise RuntimeError("parameter .grad must be contiguous")
+    return g
+
+
+class _ConvBlockFn(torch.autograd.Function):
+    """conv(+bias)(+act) -> [InstanceNorm (+act) (+residual) (+PixelShuffle store)].
+
+    Weight/bias gradients are ACCUMULATED straight into `.grad` (which the fused optimizer
+    keeps as views of one flat buffer), so autograd receives None for them.
+    """
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, residual, spec, wparam, bparam):
+        lib = _native.lib()
+        xp = as_phys(x)
+        n, h, w, pin = xp.shape
+        if pin != spec.cin_pitch:
+            raise RuntimeError(f"conv block expected {spec.cin_phys_log} input channels (pitch {spec.cin_pitch}), got pitch {pin}")
+        ho, wo = spec.out_hw(h, w)
+        cd = spec.desc(n, h, w)
+        wf = spec.packed(weight)
+        dev = x.device
+        t = torch.empty((n, ho, wo, spec.cout_pitch), dtype=torch.float32, device=dev)
+        flops = 2.0 * n * ho * wo * spec.cout * spec.k * spec.k * spec.cin
+        with _timed("conv_fwd", flops):
+            _native.check(lib.vcg_conv_fwd(_ptr(xp), _ptr(wf), _ptr(bias), _ptr(t), cd, _stream()), "vcg_conv_fwd")
+        mean = rstd = None
+        if spec.norm:
+            c = spec.cout_pitch
+            mean = torch.empty((n, c), dtype=torch.float32, device=dev)
+            rstd = torch.empty((n, c), dtype=torch.float32, device=dev)
+            wsb = lib.vcg_in_workspace(n, ho * wo, c)
+            ws = workspace(wsb, dev)
+            resp = as_phys(residual) if residual is not None else None
+            if spec.shuffle:
+                outp = torch.empty((n, 2 * ho, 2 * wo, c // 4), dtype=torch.float32, device=dev)
+                cout_log = spec.cout // 4
+            else:
+                outp = torch.empty((n, ho, wo, c), dtype=torch.float32, device=dev)
+                cout_log = spec.cout
+            with _timed("in_fwd"):
+                _native.check(lib.vcg_in_stats(_ptr(t), _ptr(mean), _ptr(rstd), n, ho * wo, c, IN_EPS, _ptr(ws),
+                                               ws.numel() * 4, _stream()), "vcg_in_stats")
+                _native.check(lib.vcg_in_apply(_ptr(t), _ptr(mean), _ptr(rstd), _ptr(resp), _ptr(outp), n, ho, wo, c,
+                                               spec.post_act, int(spec.shuffle), _stream()), "vcg_in_apply")
+        else:
+            if residual is not None or spec.shuffle or spec.post_act:
+                raise RuntimeError("residual/shuffle/post_act need norm=True")
+            outp, cout_log = t, spec.cout
+        ctx.spec, ctx.cd, ctx.dims, ctx.flops = spec, cd, (n, h, w, ho, wo), flops
+        ctx.wparam, ctx.bparam = wparam, bparam
+        ctx.has_res = residual is not None
+        ctx.save_for_backward(xp, t, mean, rstd, wf)
+        return logical_of(outp, cout_log)
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _native.lib()
+        spec, cd = ctx.spec, ctx.cd
+        n, h, w, ho, wo = ctx.dims
+        xp, t, mean, rstd, wf = ctx.saved_tensors
+        dev = t.device
+        gp = as_phys(g)
+        d_res = g if ctx.has_res else None
+        c = spec.cout_pitch
+        if spec.norm:
+            dt = torch.empty_like(t)
+            wsb = lib.vcg_in_workspace(n, ho * wo, c)
+            ws = workspace(wsb, dev)
+            with _timed("in_bwd"):
+                _native.check(lib.vcg_in_bwd(_ptr(gp), _ptr(t), _ptr(mean), _ptr(rstd), _ptr(dt), n, ho, wo, c,
+                                             spec.epi_act, spec.post_act, int(spec.shuffle), _ptr(ws), ws.numel() * 4,
+                                             _stream()), "vcg_in_bwd")
+        elif spec.epi_act != ACT_NONE:
+            dt = torch.empty_like(t)
+            _native.check(lib.vcg_act_bwd(_ptr(gp), _ptr(t), _ptr(dt), t.numel(), spec.epi_act, _stream()), "vcg_act_bwd")
+        else:
+            dt = gp
+        wparam, bparam = ctx.wparam, ctx.bparam
+        if wparam is not None and wparam.requires_grad and id(wparam) not in _NO_WGRAD:
+            gw = _grad_buffer(wparam)
+            gb = _grad_buffer(bparam) if (bparam is not None and bparam.requires_grad) else None
+            wsb = lib.vcg_conv_wgrad_workspace(cd)
+            ws = workspace(wsb, dev)
+            with _timed("conv_wgrad", ctx.flops):
+                _native.check(lib.vcg_conv_wgrad(_ptr(xp), _ptr(dt), _ptr(gw), _ptr(gb), cd, _ptr(ws), ws.numel() * 4,
+                                                 _stream()), "vcg_conv_wgrad")
+        dx = None
+        if ctx.needs_input_grad[0] and id(spec) not in _NO_DGRAD:
+            dxp = torch.empty_like(xp)
+            with _timed("conv_dgrad", ctx.flops):
+                _native.check(lib.vcg_conv_dgrad(_ptr(dt), _ptr(wf), _ptr(dxp), cd, _stream()), "vcg_conv_dgrad")
+            dx = logical_of(dxp, spec.cin_phys_log)
+        return dx, None, None, d_res, None, None, None
+
+
+def conv_block(x, weight, bias, spec, residual=None):
+    _require_gpu(x, "conv_block")
+    return _ConvBlockFn.apply(x, weight, bias, residual, spec, weight, bias)
+
+
+class _PixelShuffleFn(torch.autograd.Function):
+    """nn.PixelShuffle(2) as a standalone copy (used when the producer did not store shuffled)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        xp = as_phys(x)
+        n, h, w, c = xp.shape
+        if x.shape[1] != c or c % 16:
+            raise RuntimeError(f"pixel_shuffle needs a channel count that is a multiple of 16, got {x.shape[1]}")
+        out = torch.empty((n, 2 * h, 2 * w, c // 4), dtype=torch.float32, device=x.device)
+        _native.check(_native.lib().vcg_pixel_shuffle(_ptr(xp), _ptr(out), n, h, w, c, 0, _stream()), "vcg_pixel_shuffle")
+        ctx.dims = (n, h, w, c)
+        return logical_of(out, c // 4)
+
+    @staticmethod
+    def backward(ctx, g):
+        n, h, w, c = ctx.dims
+        gp = as_phys(g)
+        dx = torch.empty((n, h, w, c), dtype=torch.float32, device=g.device)
+        _native.check(_native.lib().vcg_pixel_shuffle(_ptr(gp), _ptr(dx), n, h, w, c, 1, _stream()), "vcg_pixel_shuffle")
+        return logical_of(dx, c)
+
+
+def pixel_shuffle(x):
+    _require_gpu(x, "pixel_shuffle")
+    return _PixelShuffleFn.apply(x)
+
+
+# ------------------------------------------------------------------ VAE sampler
+_RNG = {"seed": 0x5EED5EED, "offset": 0}
+_EPS_QUEUE = []
+
+
+def manual_seed(seed):
+    """Seed of the on-device Philox stream that draws eps (replaces torch.randn_like, Networks.py:225)."""
+    _RNG["seed"] = int(seed) & 0xFFFFFFFFFFFFFFFF
+    _RNG["offset"] = 0
+
+
+def inject_eps(tensors):
+    """Parity runs: the next reparameterisations consume these eps tensors (NCHW) in call order."""
+    _EPS_QUEUE.clear()
+    _EPS_QUEUE.extend(tensors)
+
+
+def next_eps(shape, device, skip=False):
+    """Either the next injected eps (as an nhwc view) or None (draw on device).  `skip` consumes
+    the stream position of a forward the caller does not compute."""
+    if _EPS_QUEUE:
+        e = _EPS_QUEUE.pop(0)
+        if skip:
+            return None
+        if tuple(e.shape) != tuple(shape):
+            raise RuntimeError(f"injected eps has shape {tuple(e.shape)}, expected {tuple(shape)}")
+        return to_nhwc(e.to(device))
+    if skip:
+        n = 1
+        for s in shape:
+            n *= s
+        _RNG["offset"] += (n + 3) // 4
+    return None
+
+
+class _ReparamFn(torch.autograd.Function):
+    """(mu, logvar_raw) -> (z, clamp(logvar)); Networks.py:223-226."""
+
+    @staticmethod
+    def forward(ctx, mu, lv, eps):
+        lib = _native.lib()
+        mup, lvp = as_phys(mu), as_phys(lv)
+        n_el = mup.numel()
+        z = torch.empty_like(mup)
+        lvc = torch.empty_like(mup)
+        if eps is not None:
+            epsp = as_phys(eps)
+            _native.check(lib.vcg_reparam_fwd(_ptr(mup), _ptr(lvp), _ptr(epsp), None, _ptr(z), _ptr(lvc), n_el, 0, 0,
+                                              _stream()), "vcg_reparam_fwd")
+        else:
+            epsp = torch.empty_like(mup)
+            off = _RNG["offset"]
+            _RNG["offset"] += (n_el + 3) // 4
+            _native.check(lib.vcg_reparam_fwd(_ptr(mup), _ptr(lvp), None, _ptr(epsp), _ptr(z), _ptr(lvc), n_el,
+                                              _RNG["seed"], off, _stream()), "vcg_reparam_fwd")
+        ctx.save_for_backward(epsp, lvp)
+        c = mu.shape[1]
+        return logical_of(z, c), logical_of(lvc, c)
+
+    @staticmethod
+    def backward(ctx, gz, glvc):
+        lib = _native.lib()
+        epsp, lvp = ctx.saved_tensors
+        gzp = as_phys(gz) if gz is not None else None
+        glp = as_phys(glvc) if glvc is not None else None
+        dmu = torch.empty_like(lvp)
+        dlv = torch.empty_like(lvp)
+        _native.check(lib.vcg_reparam_bwd(_ptr(gzp), _ptr(glp), _ptr(epsp), _ptr(lvp), _ptr(dmu), _ptr(dlv),
+                                          lvp.numel(), _stream()), "vcg_reparam_bwd")
+        c = lvp.shape[3]
+        return logical_of(dmu, c), logical_of(dlv, c), None
+
+
+def reparameterize(mu, logvar, eps=None):
+    return _ReparamFn.apply(mu, logvar, eps)
+
+
+# ------------------------------------------------------------------ losses
+def _pair_phys(a, b):
+    """Two logical NCHW tensors -> physical buffers with identical layout."""
+    if a.shape != b.shape:
+        raise RuntimeError(f"shape mismatch {tuple(a.shape)} vs {tuple(b.shape)}")
+    if a.dim() == 4:
+        return as_phys(a), as_phys(b), a.numel()
+    _require_gpu(a, "loss")
+    _require_gpu(b, "loss")
+    return a.contiguous(), b.contiguous(), a.numel()
+
+
+class _L1Fn(torch.autograd.Function):
+    """nn.L1Loss() (mean); Losses.py:21-24."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        lib = _native.lib()
+        ap, bp, n_log = _pair_phys(a, b)
+        out = torch.empty((), dtype=torch.float32, device=a.device)
+        ws = workspace(lib.vcg_reduce_workspace(ap.numel()), a.device)
+        _native.check(lib.vcg_l1_fwd(_ptr(ap), _ptr(bp), _ptr(out), ap.numel(), n_log, _ptr(ws), ws.numel() * 4,
+                                     _stream()), "vcg_l1_fwd")
+        ctx.save_for_backward(ap, bp)
+        ctx.n_log = n_log
+        ctx.shape = tuple(a.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _native.lib()
+        ap, bp = ctx.saved_tensors
+        g = g.contiguous()
+        ga = torch.empty_like(ap) if ctx.needs_input_grad[0] else None
+        gb = torch.empty_like(bp) if ctx.needs_input_grad[1] else None
+        if ga is None and gb is None:
+            return None, None
+        _native.check(lib.vcg_l1_bwd(_ptr(ap), _ptr(bp), _ptr(g), _ptr(ga), _ptr(gb), ap.numel(), ctx.n_log,
+                                     _stream()), "vcg_l1_bwd")
+
+        def view(t):
+            if t is None:
+                return None
+            return logical_of(t, ctx.shape[1]) if len(ctx.shape) == 4 else t.view(ctx.shape)
+        return view(ga), view(gb)
+
+
+def l1_loss(a, b):
+    return _L1Fn.apply(a, b)
+
+
+class _MseConstFn(torch.autograd.Function):
+    """nn.MSELoss()(d, full_like(d, target)) and d.mean(); Losses.py:80-81,99-100, Networks.py:2048-2051."""
+
+    @staticmethod
+    def forward(ctx, d, target):
+        lib = _native.lib()
+        _require_gpu(d, "mse_const")
+        dc = d.contiguous()
+        out = torch.empty(2, dtype=torch.float32, device=d.device)
+        _native.check(lib.vcg_mse_const_fwd(_ptr(dc), float(target), _ptr(out), dc.numel(), _stream()), "vcg_mse_const_fwd")
+        ctx.save_for_backward(dc)
+        ctx.target = float(target)
+        loss, mean = out[0], out[1]
+        ctx.mark_non_differentiable(mean)
+        return loss, mean
+
+    @staticmethod
+    def backward(ctx, g, _gmean):
+        lib = _native.lib()
+        (dc,) = ctx.saved_tensors
+        g = g.contiguous()
+        gd = torch.empty_like(dc)
+        _native.check(lib.vcg_mse_const_bwd(_ptr(dc), ctx.target, _ptr(g), _ptr(gd), dc.numel(), _stream()), "vcg_mse_const_bwd")
+        return gd, None
+
+
+def mse_const(d, target):
+    """-> (mean((d-target)^2), mean(d))"""
+    return _MseConstFn.apply(d, target)
+
+
+class _KLFn(torch.autograd.Function):
+    """KLDivergenceLoss.forward; Losses.py:115-121."""
+
+    @staticmethod
+    def forward(ctx, mu, lv):
+        lib = _native.lib()
+        mup, lvp, _ = _pair_phys(mu, lv)
+        out = torch.empty((), dtype=torch.float32, device=mu.device)
+        ws = workspace(lib.vcg_reduce_workspace(mup.numel()), mu.device)
+        _native.check(lib.vcg_kl_fwd(_ptr(mup), _ptr(lvp), _ptr(out), mup.numel(), _ptr(ws), ws.numel() * 4, _stream()), "vcg_kl_fwd")
+        ctx.save_for_backward(mup, lvp)
+        ctx.shape = tuple(mu.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _native.lib()
+        mup, lvp = ctx.saved_tensors
+        g = g.contiguous()
+        gmu = torch.empty_like(mup)
+        glv = torch.empty_like(lvp)
+        _native.check(lib.vcg_kl_bwd(_ptr(mup), _ptr(lvp), _ptr(g), _ptr(gmu), _ptr(glv), mup.numel(), _stream()), "vcg_kl_bwd")
+        if len(ctx.shape) == 4:
+            return logical_of(gmu, ctx.shape[1]), logical_of(glv, ctx.shape[1])
+        return gmu.view(ctx.shape), glv.view(ctx.shape)
+
+
+def kl_loss(mu, logvar):
+    return _KLFn.apply(mu, logvar)
+
+
+class _LinCombFn(torch.autograd.Function):
+    """sum_i w_i * s_i over scalar device tensors (the composite-loss lines Networks.py:941, 2012-2018)."""
+
+    @staticmethod
+    def forward(ctx, weights, *terms):
+        lib = _native.lib()
+        k = len(terms)
+        ptrs = (ctypes.c_void_p * k)(*[t.data_ptr() for t in terms])
+        ws = (ctypes.c_float * k)(*[float(w) for w in weights])
+        out = torch.empty((), dtype=torch.float32, device=terms[0].device)
+        _native.check(lib.vcg_lincomb_fwd(ptrs, ws, k, _ptr(out), _stream()), "vcg_lincomb_fwd")
+        ctx.weights = [float(w) for w in weights]
+        ctx.keep = terms  # keep the scalars alive until the kernel has run
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _native.lib()
+        outs = []
+        for w in ctx.weights:
+            o = torch.empty((), dtype=torch.float32, device=g.device)
+            ptrs = (ctypes.c_void_p * 1)(g.data_ptr())
+            ws = (ctypes.c_float * 1)(w)
+            _native.check(lib.vcg_lincomb_fwd(ptrs, ws, 1, _ptr(o), _stream()), "vcg_lincomb_fwd")
+            outs.append(o)
+        return (None, *outs)
+
+
+def weighted_sum(terms, weights):
+    terms = [t for t in terms]
+    for t in terms:
+        _require_gpu(t, "weighted_sum")
+    return _LinCombFn.apply(list(weights), *terms)
+
+
+# ------------------------------------------------------------------ spectral-normed full-map conv
+class _FullMapSNFn(torch.autograd.Function):
+    """spectral_norm(nn.Conv2d(C, 1, k, padding=0)) on a k x k map -> (N,)  (Networks.py:248, :269)."""
+
+    @staticmethod
+    def forward(ctx, x, weight_orig, bias, u, v, training, wparam, bparam):
+        lib = _native.lib()
+        xp = as_phys(x)
+        n, h, w, c = xp.shape
+        _, cw, kh, kw = weight_orig.shape
+        if (h, w) != (kh, kw) or c != cw:
+            raise RuntimeError(f"discriminator head expects a {cw}x{kh}x{kw} map (256x256 input images); got {c}x{h}x{w}")
+        dev = x.device
+        k = c * kh * kw
+        sigma = torch.empty(1, dtype=torch.float32, device=dev)
+        wsn = torch.empty(k, dtype=torch.float32, device=dev)
+        wo = weight_orig.detach().contiguous()
+        _native.check(lib.vcg_sn_prepare(_ptr(wo), _ptr(u), _ptr(v), _ptr(sigma), _ptr(wsn), c, kh, kw, int(training),
+                                         None, 0, _stream()), "vcg_sn_prepare")
+        out = torch.empty(n, dtype=torch.float32, device=dev)
+        _native.check(lib.vcg_fullmap_fwd(_ptr(xp), _ptr(wsn), _ptr(bias), _ptr(out), n, k, _stream()), "vcg_fullmap_fwd")
+        ctx.save_for_backward(xp, wsn, sigma, u.clone(), v.clone())
+        ctx.dims = (n, c, kh, kw)
+        ctx.wparam, ctx.bparam = wparam, bparam
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _native.lib()
+        xp, wsn, sigma, u, v = ctx.saved_tensors
+        n, c, kh, kw = ctx.dims
+        k = c * kh * kw
+        g = g.contiguous()
+        dev = g.device
+        wparam, bparam = ctx.wparam, ctx.bparam
+        if wparam is not None and wparam.requires_grad and id(wparam) not in _NO_WGRAD:
+            gw = _grad_buffer(wparam)
+            gb = _grad_buffer(bparam) if (bparam is not None and bparam.requires_grad) else None
+            ws = workspace((k + 256) * 4, dev)
+            _native.check(lib.vcg_fullmap_wgrad(_ptr(g), _ptr(xp), _ptr(wsn), _ptr(sigma), _ptr(u), _ptr(v), _ptr(gw),
+                                                _ptr(gb), n, c, kh, kw, _ptr(ws), ws.numel() * 4, _stream()), "vcg_fullmap_wgrad")
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dxp = torch.empty_like(xp)
+            _native.check(lib.vcg_fullmap_dgrad(_ptr(g), _ptr(wsn), _ptr(dxp), n, k, _stream()), "vcg_fullmap_dgrad")
+            dx = logical_of(dxp, c)
+        return dx, None, None, None, None, None, None, None
+
+
+def fullmap_sn_conv(x, weight_orig, bias, u, v, training):
+    _require_gpu(x, "fullmap_sn_conv")
+    return _FullMapSNFn.apply(x, weight_orig, bias, u, v, training, weight_orig, bias)
+
+
+# ------------------------------------------------------------------ misc
+def fill_(t, value=0.0):
+    _require_gpu(t, "fill_")
+    if not t.is_contiguous():
+        raise RuntimeError("fill_: tensor must be contiguous")
+    _native.check(_native.lib().vcg_fill(_ptr(t), float(value), t.numel(), _stream()), "vcg_fill")
+    return t
+
+
+def randn(shape, device, seed, offset=0):
+    out = torch.empty(shape, dtype=torch.float32, device=device)
+    _native.check(_native.lib().vcg_randn(_ptr(out), out.numel(), int(seed), int(offset), _stream()), "vcg_randn")
+    return out
+
+
+def rand_uniform(shape, device, seed, offset=0):
+    out = torch.empty(shape, dtype=torch.float32, device=device)
+    _native.check(_native.lib().vcg_rand_uniform(_ptr(out), out.numel(), int(seed), int(offset), _stream()), "vcg_rand_uniform")
+    return out
+
+
+def adam_step_flat(p, g, m, v, step, lr, beta1, beta2, eps, grad_scale=1.0):
+    """One fused launch of torch's single-tensor Adam formula over flat buffers."""
+    bc1 = 1.0 - beta1 ** step
+    bc2 = 1.0 - beta2 ** step
+    step_size = lr / bc1
+    bc2_sqrt = math.sqrt(bc2)
+    _native.check(_native.lib().vcg_adam_step(_ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), step_size, beta1, beta2,
+                                              eps, bc2_sqrt, grad_scale, _stream()), "vcg_adam_step")
+    PARAM_EPOCH[0] += 1

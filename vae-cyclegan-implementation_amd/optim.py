@@ -1,0 +1,111 @@
+"""Fused Adam over one flat fp32 parameter buffer.
+
+Replaces torch.optim.Adam at the reference's call sites (Networks.py:312, 894, 1928-1935:
+lr from --lr, betas (0.5, 0.999), eps 1e-8, no weight decay).  All parameters handed to
+the optimizer are re-homed as views of a single contiguous buffer; `.grad` of each is a
+view of a second buffer that the conv backward kernels accumulate into directly.  One
+optimizer step is therefore ONE kernel launch reading/writing 28 B per parameter, and a
+data-parallel gradient exchange is an all-reduce over contiguous slices of `flat_grad`.
+
+`state_dict()` / `load_state_dict()` speak torch.optim.Adam's format (per-parameter
+`step`, `exp_avg`, `exp_avg_sq`, one param group) so optimizer states move between the
+reference and this implementation.
+"""
+import torch
+
+from . import ops
+
+_ALIGN = 4  # elements; keeps every view 16-byte aligned for float4 access
+
+
+class FusedAdam:
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+        plist = []
+        seen = set()
+        for p in params:
+            if id(p) not in seen:
+                seen.add(id(p))
+                plist.append(p)
+        if not plist:
+            raise ValueError("optimizer got an empty parameter list")
+        dev = plist[0].device
+        if dev.type != "cuda":
+            raise RuntimeError("FusedAdam needs parameters on the GPU (call model.to('cuda') before configure_optimizers)")
+        for p in plist:
+            if p.device != dev or p.dtype != torch.float32:
+                raise RuntimeError("FusedAdam: all parameters must be float32 on one device")
+        self.params = plist
+        self.offsets = []
+        off = 0
+        for p in plist:
+            self.offsets.append(off)
+            off += (p.numel() + _ALIGN - 1) // _ALIGN * _ALIGN
+        self.total = off
+        self.flat_param = torch.empty(off, dtype=torch.float32, device=dev)
+        self.flat_grad = torch.empty(off, dtype=torch.float32, device=dev)
+        self.exp_avg = torch.empty(off, dtype=torch.float32, device=dev)
+        self.exp_avg_sq = torch.empty(off, dtype=torch.float32, device=dev)
+        for buf in (self.flat_param, self.flat_grad, self.exp_avg, self.exp_avg_sq):
+            ops.fill_(buf, 0.0)
+        with torch.no_grad():
+            for p, o in zip(plist, self.offsets):
+                view = self.flat_param[o:o + p.numel()].view(p.shape)
+                view.copy_(p.data)          # one-time re-homing of the initial values
+                p.data = view
+                p.grad = self.flat_grad[o:o + p.numel()].view(p.shape)
+        self.step_count = 0
+        self.grad_scale = 1.0
+        self.defaults = dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=0, amsgrad=False, maximize=False,
+                             foreach=None, capturable=False, differentiable=False, fused=None)
+        self.param_groups = [dict(self.defaults, params=plist)]
+        ops.PARAM_EPOCH[0] += 1
+
+    # -- torch.optim.Optimizer surface -------------------------------------------------
+    def zero_grad(self, set_to_none=False):
+        """Gradients are accumulation targets of the backward kernels, so they are zeroed, never dropped."""
+        for p, o in zip(self.params, self.offsets):
+            g = p.grad
+            if g is None or g.data_ptr() != self.flat_grad.data_ptr() + 4 * o:
+                p.grad = self.flat_grad[o:o + p.numel()].view(p.shape)
+        ops.fill_(self.flat_grad, 0.0)
+
+    def step(self, grad_scale=None):
+        """`grad_scale` multiplies the gradient inside the fused launch (1/world after a summing
+        all-reduce; parallel.GradReducer sets `self.grad_scale`)."""
+        g = self.param_groups[0]
+        self.step_count += 1
+        scale = self.grad_scale if grad_scale is None else grad_scale
+        ops.adam_step_flat(self.flat_param, self.flat_grad, self.exp_avg, self.exp_avg_sq, self.step_count,
+                           g["lr"], g["betas"][0], g["betas"][1], g["eps"], scale)
+
+    def state_dict(self):
+        state = {}
+        if self.step_count > 0:
+            for i, (p, o) in enumerate(zip(self.params, self.offsets)):
+                state[i] = {
+                    "step": torch.tensor(float(self.step_count)),
+                    "exp_avg": self.exp_avg[o:o + p.numel()].view(p.shape).clone(),
+                    "exp_avg_sq": self.exp_avg_sq[o:o + p.numel()].view(p.shape).clone(),
+                }
+        group = {k: v for k, v in self.param_groups[0].items() if k != "params"}
+        group["params"] = list(range(len(self.params)))
+        return {"state": state, "param_groups": [group]}
+
+    def load_state_dict(self, sd):
+        groups = sd["param_groups"]
+        if len(groups) != 1 or len(groups[0]["params"]) != len(self.params):
+            raise ValueError("optimizer state does not match the parameter list")
+        for k in ("lr", "betas", "eps"):
+            if k in groups[0]:
+                self.param_groups[0][k] = tuple(groups[0][k]) if k == "betas" else groups[0][k]
+        steps = set()
+        with torch.no_grad():
+            for idx, st in sd["state"].items():
+                i = int(idx)
+                p, o = self.params[i], self.offsets[i]
+                self.exp_avg[o:o + p.numel()].view(p.shape).copy_(st["exp_avg"])
+                self.exp_avg_sq[o:o + p.numel()].view(p.shape).copy_(st["exp_avg_sq"])
+                steps.add(int(float(st["step"])))
+        if len(steps) > 1:
+            raise ValueError("FusedAdam keeps one step counter; the loaded state has several")
+        self.step_count = steps.pop() if steps else 0

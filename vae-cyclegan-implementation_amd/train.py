@@ -1,0 +1,202 @@
+#!/usr/bin/env python3
+"""Training driver with the reference's `train.py` CLI for the hot path.
+
+Kept from the reference (train.py:588-656): every flag name and default.  Added: `--dataset synthetic`
+(on-device U[0,1) batches, the benchmark input), `--latent_dim` (the reference's README mentions it,
+its argparse lacks it: create_model always used 64), `--steps_per_epoch`, `--seed`, and the BASELINE
+aliases `ae` / `vae_cyclegan` for `--architecture`.  Under `torch.distributed.run` each rank trains
+its shard of the global batch and gradients are exchanged by `parallel.GradReducer` (RCCL).
+
+Out of scope here, as in SURVEY.md §2: the image datasets / torchvision pipelines (`Data_Manager.py`),
+TensorBoard, checkpoint resume and the seven other composites.  Asking for them raises.
+
+`create_model` and `train_epoch` mirror the reference's functions of the same name (train.py:43-128).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from datetime import datetime
+from pathlib import Path
+
+import torch
+
+if __package__ in (None, ""):
+    import importlib
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    _pkg = importlib.import_module("vae-cyclegan-implementation_amd")
+    Networks, ops, parallel = _pkg.Networks, _pkg.ops, _pkg.parallel
+else:
+    from . import Networks, ops, parallel
+
+ALIASES = {"ae": "autoencoder", "vae_cyclegan": "cyclevaegan"}
+BUILT = ("autoencoder", "vae", "cyclevaegan")
+REFERENCE_ARCHS = ["autoencoder", "doubleae", "doublevae", "vae", "aegan", "vaegan", "cycleae", "cyclevae",
+                   "cycleaegan", "cyclevaegan"]
+
+
+def create_model(architecture, paired=True, latent_dim=64):
+    """reference train.py:43-77 (which never passes latent_dim)."""
+    architecture = ALIASES.get(architecture, architecture)
+    if architecture == "autoencoder":
+        model = Networks.Autoencoder()
+        print("Created Autoencoder")
+    elif architecture == "vae":
+        model = Networks.VariationalAutoencoder(latent_dim=latent_dim)
+        print("Created Variational Autoencoder")
+    elif architecture == "cyclevaegan":
+        model = Networks.CycleVAEGAN(latent_dim=latent_dim, paired=paired)
+        print(f"Created Cycle VAE-GAN ({'paired' if paired else 'unpaired'} mode)")
+    elif architecture in REFERENCE_ARCHS:
+        raise NotImplementedError(f"architecture '{architecture}' is not on the accelerated path yet "
+                                  f"(built: {', '.join(BUILT)}); it reuses the same kernels and is listed as a next step")
+    else:
+        raise ValueError(f"Unknown architecture: {architecture}")
+    return model
+
+
+class SyntheticLoader:
+    """len()-able iterable of {'x','y'} batches drawn on the device: x, y ~ U[0,1), (B,3,S,S)."""
+
+    def __init__(self, batch_size, image_size, steps, device, seed=1234, rank=0, same_xy=False, epoch=0):
+        self.b, self.s, self.steps, self.dev = batch_size, image_size, steps, device
+        self.seed, self.rank, self.same_xy, self.epoch = seed, rank, same_xy, epoch
+
+    def __len__(self):
+        return self.steps
+
+    def __iter__(self):
+        nq = (self.b * 3 * self.s * self.s + 3) // 4
+        for i in range(self.steps):
+            base = (((self.epoch * self.steps + i) * 64 + self.rank) * 2) * nq
+            x = ops.rand_uniform((self.b, 3, self.s, self.s), self.dev, self.seed, base)
+            y = x if self.same_xy else ops.rand_uniform((self.b, 3, self.s, self.s), self.dev, self.seed, base + nq)
+            yield {"x": x, "y": y}
+
+
+def train_epoch(model, dataloader, device, args, writer=None, epoch=None):
+    """reference train.py:80-128: per-batch training_step, metric sums averaged by len(dataloader),
+    G_loss as the headline loss.  The reference also runs one extra train-mode forward per batch for a
+    visualisation tensor that its caller never uses (:112-117); it is reproduced only with
+    --reference_viz_forward (it advances the eps stream and costs a full forward)."""
+    model.train()
+    total_loss = 0.0
+    loss_components = {}
+    last_output = last_x = last_y = None
+    for batch in dataloader:
+        batch["x"] = batch["x"].to(device)
+        batch["y"] = batch["y"].to(device)
+        metrics = model.training_step(batch)
+        total_loss += metrics["G_loss"]
+        for key, value in metrics.items():
+            loss_components[key] = loss_components.get(key, 0.0) + value
+        last_x, last_y = batch["x"], batch["y"]
+        if getattr(args, "reference_viz_forward", False):
+            with torch.no_grad():
+                if isinstance(model, (Networks.Autoencoder, Networks.VariationalAutoencoder)):
+                    last_output = model(last_x)[0]
+                else:
+                    last_output = model(last_x, last_y)[0]
+    n = len(dataloader)
+    if n > 0:
+        return total_loss / n, {k: v / n for k, v in loss_components.items()}, last_output, last_x, last_y
+    return float("nan"), {k: float("nan") for k in loss_components}, last_output, last_x, last_y
+
+
+def build_parser():
+    p = argparse.ArgumentParser(description="Train VAE-CycleGAN models (MI355X-native path)")
+    p.add_argument("--architecture", type=str, default="autoencoder", choices=REFERENCE_ARCHS + list(ALIASES))
+    p.add_argument("--paired", action="store_true", default=False)
+    p.add_argument("--unpaired", dest="paired", action="store_false")
+    p.add_argument("--pretrained_doubleae", type=str, default=None)
+    p.add_argument("--pretrained_doublevae", type=str, default=None)
+    p.add_argument("--data_dir", type=str, default="dataset")
+    p.add_argument("--source_modality", type=str, default=None)
+    p.add_argument("--target_modality", type=str, default=None)
+    p.add_argument("--image_size", type=int, default=256)
+    p.add_argument("--test_split", type=float, default=0.1)
+    p.add_argument("--dataset", type=str, default="hypersim", choices=["hypersim", "summer2winter", "maps", "synthetic"])
+    p.add_argument("--batch_size", type=int, default=5)
+    p.add_argument("--epochs", type=int, default=100)
+    p.add_argument("--lr", type=float, default=0.0002)
+    p.add_argument("--lambda_kl", type=float, default=1e-5)
+    p.add_argument("--lambda_gan", type=float, default=1.0)
+    p.add_argument("--lambda_identity", type=float, default=5.0)
+    p.add_argument("--lambda_cycle", type=float, default=10.0)
+    p.add_argument("--lambda_recon", type=float, default=1.0)
+    p.add_argument("--output_dir", type=str, default="runs")
+    p.add_argument("--save_freq", type=int, default=10)
+    p.add_argument("--log_image_freq", type=int, default=5)
+    p.add_argument("--resume", type=str, default=None)
+    p.add_argument("--num_workers", type=int, default=1)
+    p.add_argument("--no_cuda", action="store_true")
+    # additions
+    p.add_argument("--latent_dim", type=int, default=64)
+    p.add_argument("--steps_per_epoch", type=int, default=20, help="synthetic dataset: batches per epoch")
+    p.add_argument("--seed", type=int, default=1234)
+    p.add_argument("--reference_viz_forward", action="store_true")
+    return p
+
+
+def main(args):
+    args.architecture = ALIASES.get(args.architecture, args.architecture)
+    if args.dataset != "synthetic":
+        raise NotImplementedError("only --dataset synthetic is built: the image pipelines of Data_Manager.py "
+                                  "(PIL + torchvision) are outside the accelerated path (SURVEY.md §2)")
+    if args.resume or args.pretrained_doubleae or args.pretrained_doublevae:
+        raise NotImplementedError("--resume/--pretrained_* (checkpoint wire format) is a next-step row (SURVEY.md §8f)")
+    if args.no_cuda or not torch.cuda.is_available():
+        raise RuntimeError("this path has no CPU implementation: an MI355X is required (the reference's own "
+                           "train.py is the CPU path)")
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+    if args.architecture in ("autoencoder", "vae"):
+        if args.source_modality != args.target_modality:
+            raise ValueError("Source and target modalities should be the same for Autoencoder/VAE architectures.")
+
+    output_dir = Path(args.output_dir) / f"{args.architecture}_{datetime.now().strftime('%m%d_%H%M')}_synthetic"
+    if rank == 0:
+        output_dir.mkdir(parents=True, exist_ok=True)
+        with open(output_dir / "args.json", "w") as f:
+            json.dump(vars(args), f, indent=2)
+        print(f"Using device: {device}  world size {world}\nOutput directory: {output_dir}")
+
+    torch.manual_seed(args.seed)                     # identical replicas
+    ops.manual_seed(args.seed + 7919 * (rank + 1))   # per-rank eps stream
+    model = create_model(args.architecture, paired=args.paired, latent_dim=args.latent_dim).to(device)
+    model.configure_optimizers(lr=args.lr)
+    model.configure_loss(lambda_kl=args.lambda_kl, lambda_gan=args.lambda_gan, lambda_identity=args.lambda_identity,
+                         lambda_cycle=args.lambda_cycle, lambda_recon=args.lambda_recon)
+    if world > 1:
+        parallel.attach(model)
+        parallel.broadcast_parameters(model)
+    same_xy = args.architecture in ("autoencoder", "vae")
+    for epoch in range(args.epochs):
+        loader = SyntheticLoader(args.batch_size, args.image_size, args.steps_per_epoch, device, args.seed, rank,
+                                 same_xy, epoch)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        train_loss, comps, *_ = train_epoch(model, loader, device, args, epoch=epoch)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if rank == 0:
+            ips = args.batch_size * world * len(loader) / dt
+            print(f"\nEpoch {epoch + 1}/{args.epochs}\nTrain Loss: {train_loss:.4f}   ({ips:.1f} images/s)")
+            for k, v in comps.items():
+                print(f"  {k}: {v:.6f}")
+    if world > 1:
+        dist.destroy_process_group()
+    if rank == 0:
+        print(f"\nTraining completed. Run directory: {output_dir}")
+
+
+if __name__ == "__main__":
+    main(build_parser().parse_args())
