@@ -142,12 +142,24 @@ def measure_roofline(pkg, model, pool, wl, B, S, latent, ms_per_step):
         model.training_step(pool[i % len(pool)])
     torch.cuda.synchronize()
     recs, ops.PROFILE = ops.PROFILE, None
-    fam = {}
-    for name, flops, e0, e1 in recs:
+    fam, shapes = {}, {}
+    for name, flops, e0, e1, tag in recs:
+        dt = e0.elapsed_time(e1) * 1e-3
         f = fam.setdefault(name, [0.0, 0.0, 0])
         f[0] += flops
-        f[1] += e0.elapsed_time(e1) * 1e-3
+        f[1] += dt
         f[2] += 1
+        if tag:
+            s = shapes.setdefault((name, tag), [0.0, 0.0, 0])
+            s[0] += flops
+            s[1] += dt
+            s[2] += 1
+    dump = os.environ.get("VCG_BENCH_SHAPES")
+    if dump:                                   # per-shape table for kernel work (not part of the JSON line)
+        with open(dump, "w") as fh:
+            for (name, tag), (fl, sec, cnt) in sorted(shapes.items(), key=lambda kv: -kv[1][1]):
+                fh.write(f"{name:11s} {tag:34s} n={cnt // 2:3d} ms/step={sec / 2 * 1e3:8.3f} us/launch={sec / cnt * 1e6:9.1f} "
+                         f"TF={fl / sec / 1e12:7.2f}\n")
     conv = {k: v for k, v in fam.items() if k.startswith("conv_")}
     dom = max(conv, key=lambda k: conv[k][1])
     flops, secs, n = conv[dom]

@@ -473,26 +473,45 @@ __global__ __launch_bounds__(256) void k_conv_wgrad(ConvP p) {
   }
 }
 
-// slabs[z][K][Cout] -> gw_oihw += sum_z (fixed order)
-__global__ void k_wgrad_reduce(const float* __restrict__ slabs, float* __restrict__ gw, ConvP p, int nsplit,
-                               int cin_log, int cout_log) {
+// slabs[z][K][Cout] -> gw_oihw += sum_z (fixed order), transposed through LDS.
+// A block owns 32 output channels x 8 input channels x ALL taps: slab reads are 128-B row segments
+// (co fastest), and for every co the block's OIHW target [8 c][U*U][KH*KW] is one contiguous run,
+// so the read-modify-write of the gradient is coalesced too.  Dynamic LDS: T*8*33 floats.
+__global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ slabs, float* __restrict__ gw,
+                                                      ConvP p, int nsplit, int cin_log, int cout_log) {
+  extern __shared__ __attribute__((aligned(16))) float tile[];
+  const int U2 = p.ups * p.ups, KK = p.KH * p.KW, T = KK * U2;
+  const int co0 = blockIdx.x * 32, c0 = blockIdx.y * 8;
+  const int cl_ = threadIdx.x >> 5, col = threadIdx.x & 31;      // read mapping: 8 c x 32 co
   const size_t total = (size_t)p.K * p.Cout;
-  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-       idx += (size_t)gridDim.x * blockDim.x) {
-    uint32_t R = (uint32_t)(idx / p.Cout);
-    int co = (int)(idx - (size_t)R * p.Cout);
-    uint32_t tap = R / (uint32_t)p.Cin;
-    int c = (int)(R - tap * (uint32_t)p.Cin);
-    if (co >= cout_log || c >= cin_log) continue;
-    int ii = 0, jj = 0;
-    if (p.ups == 2) { jj = tap & 1; ii = (tap >> 1) & 1; tap >>= 2; }
-    int kh = (int)tap / p.KW, kw = (int)tap % p.KW;
-    int cl = (p.ups == 2) ? (c * 4 + ii * 2 + jj) : c;
-    int cinL = (p.ups == 2) ? cin_log * 4 : cin_log;
-    float s = 0.f;
-    for (int z = 0; z < nsplit; ++z) s += slabs[(size_t)z * total + idx];
-    size_t o = (((size_t)co * cinL + cl) * p.KH + kh) * p.KW + kw;
-    gw[o] += s;
+  {
+    const int c = c0 + cl_, co = co0 + col;
+    const bool ok = c < p.Cin && co < p.Cout;
+    for (int t = 0; t < T; ++t) {
+      float s = 0.f;
+      if (ok) {
+        const size_t idx = ((size_t)t * p.Cin + c) * p.Cout + co;
+        for (int z = 0; z < nsplit; ++z) s += slabs[(size_t)z * total + idx];
+      }
+      tile[(t * 8 + cl_) * 33 + col] = s;
+    }
+  }
+  __syncthreads();
+  const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int cinL = cin_log * U2;
+  const int run = 8 * U2 * KK;                                   // OIHW elements per co in this block
+  for (int j = 0; j < 8; ++j) {
+    const int colw = wid * 8 + j, co = co0 + colw;
+    if (co >= cout_log) continue;
+    for (int q = lane; q < run; q += 64) {
+      const int clq = q / KK, tap9 = q - clq * KK;                 // clq = c_local*U2 + phase
+      const int c_local = clq / U2, ph = clq - c_local * U2;
+      const int c = c0 + c_local;
+      if (c >= cin_log) continue;
+      const int t = tap9 * U2 + ph;
+      const size_t o = ((size_t)co * cinL + (size_t)c * U2 + ph) * KK + tap9;
+      gw[o] += tile[(t * 8 + c_local) * 33 + colw];
+    }
   }
 }
 
@@ -520,21 +539,34 @@ __global__ void k_pack_weight(const float* __restrict__ w, float* __restrict__ w
 }
 
 // gbias[co] += sum_m dy[m][co]: per-chunk partials then a fixed-order final sum
+// float4 per lane (TC channel quads x TP row lanes per block), 4 independent rows in flight per lane
 __global__ __launch_bounds__(256) void k_colsum_partial(const float* __restrict__ dy, float* __restrict__ part,
-                                                        int M, int C, int rows_per_chunk) {
-  __shared__ float red[256];
-  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
-  const int pl = threadIdx.x >> 6;
+                                                        int M, int C, int rows_per_chunk, int TC) {
+  __shared__ float4 red[256];
+  const int TP = 256 / TC;
+  const int tc = threadIdx.x % TC, tp = threadIdx.x / TC;
+  const int c4 = blockIdx.x * TC + tc;
   const int mb = blockIdx.y * rows_per_chunk;
   int me = mb + rows_per_chunk;
   if (me > M) me = M;
-  float s = 0.f;
-  if (c < C)
-    for (int m = mb + pl; m < me; m += 4) s += dy[(size_t)m * C + c];
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s, s3 = s, s4 = s;
+  if (c4 * 4 < C) {
+    const float* base = dy + (size_t)c4 * 4;
+    int m = mb + tp;
+    for (; m + 3 * TP < me; m += 4 * TP) {
+      float4 a = ldg4(base + (size_t)m * C), b = ldg4(base + (size_t)(m + TP) * C);
+      float4 c = ldg4(base + (size_t)(m + 2 * TP) * C), d = ldg4(base + (size_t)(m + 3 * TP) * C);
+      f4add(s, a); f4add(s2, b); f4add(s3, c); f4add(s4, d);
+    }
+    for (; m < me; m += TP) f4add(s, ldg4(base + (size_t)m * C));
+    f4add(s, s2); f4add(s3, s4); f4add(s, s3);
+  }
   red[threadIdx.x] = s;
   __syncthreads();
-  if (pl == 0 && c < C)
-    part[(size_t)blockIdx.y * C + c] = red[threadIdx.x] + red[threadIdx.x + 64] + red[threadIdx.x + 128] + red[threadIdx.x + 192];
+  if (tp == 0 && c4 * 4 < C) {
+    for (int k = 1; k < TP; ++k) f4add(s, red[k * TC + tc]);
+    *reinterpret_cast<float4*>(part + (size_t)blockIdx.y * C + c4 * 4) = s;
+  }
 }
 __global__ void k_colsum_final(const float* __restrict__ part, float* __restrict__ out, int C, int nchunk,
                                int c_log) {
@@ -676,7 +708,20 @@ static void wgrad_plan(const ConvGeom& g, int& bm, int& bn, int& nsplit, int& pe
   nsplit = (total + per - 1) / per;
 }
 
-static const int kColsumRows = 2048;
+// bias-gradient column sums: TC channel quads per block, ~1024 blocks in flight
+static void colsum_plan(const ConvGeom& g, int& tc, int& cgroups, int& rows, int& nchunk) {
+  int c4 = g.Cout / 4;
+  tc = 1;
+  while (tc * 2 <= c4 && tc * 2 <= 256) tc *= 2;
+  cgroups = (c4 + tc - 1) / tc;
+  int tp = 256 / tc;
+  long long want = 1024 / cgroups;
+  if (want < 1) want = 1;
+  long long r = (g.M + want - 1) / want;
+  if (r < 4LL * tp) r = 4LL * tp;
+  rows = (int)r;
+  nchunk = (g.M + rows - 1) / rows;
+}
 
 extern "C" size_t vcg_conv_wgrad_workspace(const int32_t* cd) {
   ConvGeom g;
@@ -684,9 +729,10 @@ extern "C" size_t vcg_conv_wgrad_workspace(const int32_t* cd) {
   int bm, bn, nsplit, per, total;
   wgrad_plan(g, bm, bn, nsplit, per, total);
   size_t slabs = (size_t)nsplit * g.K * g.Cout * sizeof(float);
-  size_t nchunk = (size_t)(g.M + kColsumRows - 1) / kColsumRows;
-  size_t cols = nchunk * g.Cout * sizeof(float);
-  return slabs + cols + 256;
+  int tc, cgroups, rows, nchunk;
+  colsum_plan(g, tc, cgroups, rows, nchunk);
+  size_t cols = (size_t)nchunk * g.Cout * sizeof(float);
+  return slabs + cols + 512;
 }
 
 extern "C" int vcg_conv_wgrad(const float* x, const float* dy, float* gw_oihw, float* gbias,
@@ -708,14 +754,17 @@ extern "C" int vcg_conv_wgrad(const float* x, const float* dy, float* gw_oihw, f
   else if (bm == 64 && bn == 128) hipLaunchKernelGGL((k_conv_wgrad<64, 128>), grid, dim3(256), 0, st, p);
   else hipLaunchKernelGGL((k_conv_wgrad<64, 64>), grid, dim3(256), 0, st, p);
   VCG_LAUNCH_CHECK("vcg_conv_wgrad");
-  size_t totalw = (size_t)g.K * g.Cout;
-  int blocks = (int)((totalw + 255) / 256); if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(k_wgrad_reduce, dim3(blocks), dim3(256), 0, st, (const float*)ws, gw_oihw, p, nsplit, g.cin_log, g.cout_log);
+  const int T = g.KH * g.KW * g.ups * g.ups;
+  const size_t lds = (size_t)T * 8 * 33 * sizeof(float);
+  VCG_CHECK_ARG(lds <= 64 * 1024, "vcg_conv_wgrad: %d taps exceed the reduce kernel's LDS tile", T);
+  hipLaunchKernelGGL(k_wgrad_reduce, dim3((g.Cout + 31) / 32, (g.Cin + 7) / 8), dim3(256), lds, st, (const float*)ws,
+                     gw_oihw, p, nsplit, g.cin_log, g.cout_log);
   VCG_LAUNCH_CHECK("vcg_conv_wgrad(reduce)");
   if (gbias) {
     float* part = (float*)((char*)ws + (((size_t)nsplit * g.K * g.Cout * sizeof(float) + 255) / 256) * 256);
-    int nchunk = (g.M + kColsumRows - 1) / kColsumRows;
-    hipLaunchKernelGGL(k_colsum_partial, dim3((g.Cout + 63) / 64, nchunk), dim3(256), 0, st, dy, part, g.M, g.Cout, kColsumRows);
+    int tc, cgroups, rows, nchunk;
+    colsum_plan(g, tc, cgroups, rows, nchunk);
+    hipLaunchKernelGGL(k_colsum_partial, dim3(cgroups, nchunk), dim3(256), 0, st, dy, part, g.M, g.Cout, rows, tc);
     hipLaunchKernelGGL(k_colsum_final, dim3((g.cout_log + 63) / 64), dim3(64), 0, st, (const float*)part, gbias, g.Cout, nchunk, g.cout_log);
     VCG_LAUNCH_CHECK("vcg_conv_wgrad(bias)");
   }

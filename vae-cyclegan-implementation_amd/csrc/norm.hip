@@ -106,15 +106,27 @@ __global__ __launch_bounds__(256) void k_in_partial(const float* __restrict__ t,
 template <int MODE>
 __global__ void k_in_final(const float* __restrict__ part, float* __restrict__ out1, float* __restrict__ out2,
                            int N, int HW, int C, int nchunk, float eps) {
-  int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= N * C) return;
-  int n = idx / C, c = idx - n * C;
+  // 32 (n,c) pairs x 8 chunk lanes per block: the chunk loop is a dependent chain of L2 round trips,
+  // so it is split 8 ways and combined through LDS in a fixed order
+  __shared__ double ra[8][32], rb[8][32];
+  const int il = threadIdx.x & 31, kl = threadIdx.x >> 5;
+  const int idx = blockIdx.x * 32 + il;
+  const bool ok = idx < N * C;
+  int n = 0, c = 0;
   double a = 0.0, b = 0.0;
-  for (int k = 0; k < nchunk; ++k) {
-    const float* p = part + (((size_t)n * nchunk + k) * C + c) * 2;
-    a += (double)p[0];
-    b += (double)p[1];
+  if (ok) {
+    n = idx / C; c = idx - n * C;
+    for (int k = kl; k < nchunk; k += 8) {
+      const float* p = part + (((size_t)n * nchunk + k) * C + c) * 2;
+      a += (double)p[0];
+      b += (double)p[1];
+    }
   }
+  ra[kl][il] = a;
+  rb[kl][il] = b;
+  __syncthreads();
+  if (kl != 0 || !ok) return;
+  for (int k = 1; k < 8; ++k) { a += ra[k][il]; b += rb[k][il]; }
   if (MODE == 0) {
     double m = a / HW;
     double var = b / HW - m * m;
@@ -243,7 +255,7 @@ extern "C" int vcg_in_stats(const float* t, float* mean, float* rstd, int N, int
   float* part = (float*)ws;
   hipLaunchKernelGGL(k_in_partial<0>, dim3(pl.nchunk, N, pl.cgroups), dim3(256), 0, st, t, (const float*)nullptr,
                      (const float*)nullptr, (const float*)nullptr, part, HW, 1, C, pl, 0, 0);
-  hipLaunchKernelGGL(k_in_final<0>, dim3((N * C + 255) / 256), dim3(256), 0, st, (const float*)part, mean, rstd, N,
+  hipLaunchKernelGGL(k_in_final<0>, dim3((N * C + 31) / 32), dim3(256), 0, st, (const float*)part, mean, rstd, N,
                      HW, C, pl.nchunk, eps);
   VCG_LAUNCH_CHECK("vcg_in_stats");
   return 0;
@@ -276,7 +288,7 @@ extern "C" int vcg_in_bwd(const float* g, const float* t, const float* mean, con
   float* s12 = part + (size_t)N * pl.nchunk * C * 2;
   hipLaunchKernelGGL(k_in_partial<1>, dim3(pl.nchunk, N, pl.cgroups), dim3(256), 0, st, t, g, mean, rstd, part, H, W,
                      C, pl, post_act, shuffle);
-  hipLaunchKernelGGL(k_in_final<1>, dim3((N * C + 255) / 256), dim3(256), 0, st, (const float*)part, s12,
+  hipLaunchKernelGGL(k_in_final<1>, dim3((N * C + 31) / 32), dim3(256), 0, st, (const float*)part, s12,
                      (float*)nullptr, N, HW, C, pl.nchunk, 0.f);
   size_t total = (size_t)N * HW * (C / 4);
   hipLaunchKernelGGL(k_in_bwd_apply, dim3(ew_blocks(total)), dim3(256), 0, st, g, t, mean, rstd, (const float*)s12,

@@ -49,8 +49,8 @@ PROFILE = None
 
 
 class _timed:
-    def __init__(self, family, flops=0.0):
-        self.family, self.flops = family, flops
+    def __init__(self, family, flops=0.0, tag=""):
+        self.family, self.flops, self.tag = family, flops, tag
 
     def __enter__(self):
         if PROFILE is not None:
@@ -62,7 +62,7 @@ class _timed:
     def __exit__(self, *a):
         if PROFILE is not None:
             self.e1.record()
-            PROFILE.append((self.family, self.flops, self.e0, self.e1))
+            PROFILE.append((self.family, self.flops, self.e0, self.e1, self.tag))
 
 
 # ------------------------------------------------------------------ workspace
@@ -265,7 +265,8 @@ class _ConvBlockFn(torch.autograd.Function):
         dev = x.device
         t = torch.empty((n, ho, wo, spec.cout_pitch), dtype=torch.float32, device=dev)
         flops = 2.0 * n * ho * wo * spec.cout * spec.k * spec.k * spec.cin
-        with _timed("conv_fwd", flops):
+        tag = f"{n}x{h}x{w}x{spec.cin_pitch}->{spec.cout_pitch} k{spec.k} s{spec.stride} u{spec.ups}"
+        with _timed("conv_fwd", flops, tag):
             _native.check(lib.vcg_conv_fwd(_ptr(xp), _ptr(wf), _ptr(bias), _ptr(t), cd, _stream()), "vcg_conv_fwd")
         mean = rstd = None
         if spec.norm:
@@ -290,7 +291,7 @@ class _ConvBlockFn(torch.autograd.Function):
             if residual is not None or spec.shuffle or spec.post_act:
                 raise RuntimeError("residual/shuffle/post_act need norm=True")
             outp, cout_log = t, spec.cout
-        ctx.spec, ctx.cd, ctx.dims, ctx.flops = spec, cd, (n, h, w, ho, wo), flops
+        ctx.spec, ctx.cd, ctx.dims, ctx.flops, ctx.tag = spec, cd, (n, h, w, ho, wo), flops, tag
         ctx.wparam, ctx.bparam = wparam, bparam
         ctx.has_res = residual is not None
         ctx.save_for_backward(xp, t, mean, rstd, wf)
@@ -325,13 +326,13 @@ class _ConvBlockFn(torch.autograd.Function):
             gb = _grad_buffer(bparam) if (bparam is not None and bparam.requires_grad) else None
             wsb = lib.vcg_conv_wgrad_workspace(cd)
             ws = workspace(wsb, dev)
-            with _timed("conv_wgrad", ctx.flops):
+            with _timed("conv_wgrad", ctx.flops, ctx.tag):
                 _native.check(lib.vcg_conv_wgrad(_ptr(xp), _ptr(dt), _ptr(gw), _ptr(gb), cd, _ptr(ws), ws.numel() * 4,
                                                  _stream()), "vcg_conv_wgrad")
         dx = None
         if ctx.needs_input_grad[0] and id(spec) not in _NO_DGRAD:
             dxp = torch.empty_like(xp)
-            with _timed("conv_dgrad", ctx.flops):
+            with _timed("conv_dgrad", ctx.flops, ctx.tag):
                 _native.check(lib.vcg_conv_dgrad(_ptr(dt), _ptr(wf), _ptr(dxp), cd, _stream()), "vcg_conv_dgrad")
             dx = logical_of(dxp, spec.cin_phys_log)
         return dx, None, None, d_res, None, None, None

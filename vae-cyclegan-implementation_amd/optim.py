@@ -56,7 +56,8 @@ class FusedAdam:
         self.step_count = 0
         self.grad_scale = 1.0
         self.defaults = dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=0, amsgrad=False, maximize=False,
-                             foreach=None, capturable=False, differentiable=False, fused=None)
+                             foreach=None, capturable=False, differentiable=False, fused=None,
+                             decoupled_weight_decay=False)
         self.param_groups = [dict(self.defaults, params=plist)]
         ops.PARAM_EPOCH[0] += 1
 
