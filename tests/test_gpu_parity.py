@@ -9,7 +9,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from conftest import (SEED, assert_checksum, assert_close, check_step_state, in_cancelled_bias)
+from conftest import (GAN_FLIP_BUDGET, SEED, assert_checksum, assert_close, check_step_state, in_cancelled_bias)
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
 from cases import ATOM_BIAS_STD, ATOM_CASES, DISC_BIAS_STD, LAMBDAS, LR, STEP_BIAS_STD  # noqa: E402
@@ -242,10 +242,11 @@ def _check_metrics(got, ref, what, tol=1e-3):
         assert abs(got[k] - v) <= tol * max(abs(v), 1e-6), f"{what}: {k} = {got[k]!r}, reference {v!r}"
 
 
-def _check_state(model, key, steps_golden, snap="@step1"):
+def _check_state(model, key, steps_golden, snap="@step1", flip=None):
     params = {n: v for n, v in model.state_dict().items()}
     grads = {n: p.grad for n, p in model.named_parameters()}
-    check_step_state(params, grads, key, steps_golden, LR, snap=snap)
+    kw = {} if flip is None else {"flip": flip}
+    check_step_state(params, grads, key, steps_golden, LR, snap=snap, **kw)
 
 
 def test_autoencoder_steps_match_reference_golden(pkg, device, steps_golden, steps_meta):
@@ -314,7 +315,7 @@ def test_cyclevaegan_step_matches_reference_golden(key, paired, pkg, device, ste
     pkg.ops.inject_eps(eps)
     m = model.training_step({"x": xb, "y": yb})
     _check_metrics(m, steps_meta[key][0], f"{key} step 0")
-    _check_state(model, key, steps_golden)
+    _check_state(model, key, steps_golden, flip=GAN_FLIP_BUDGET)
 
 
 def test_cyclevaegan_unconfigured_raises_like_the_reference(pkg, device):

@@ -50,6 +50,26 @@ __device__ __forceinline__ void f4add(float4& a, const float4& b) {
   a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
 }
 
+// Two-level accumulation.  An MFMA chain is a sequential fp32 sum: over K = 18 432 its rounding error
+// reaches 2.5e-6 of the result (measured, tools/conv_accuracy.py) against 2.5e-7 for the CPU kernels
+// the reference runs on.  That matters beyond the 1e-3 budget: a pre-activation within rounding of 0
+// flips relu'(.) and moves that element's gradient by its full size, and the flip rate is proportional
+// to this error.  Every FLUSH_TILES K-steps the chain is cut: acc is added into `tot` and restarted,
+// which brings the error to ~u(sqrt(c)+sqrt(n/c)) (5x lower at K = 18 432) for 16*MI*NI more VGPRs.
+#define FLUSH_TILES 8
+
+template <int MI, int NI>
+__device__ __forceinline__ void flush_acc(f32x16 (&acc)[MI][NI], f32x16 (&tot)[MI][NI]) {
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      tot[i][j] += acc[i][j];
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    }
+}
+
 // chunk g (4 consecutive k) of the forward K axis -> (kh, kw, i, j, c)
 __device__ __forceinline__ void decode_tap(const ConvP& p, uint32_t g, int& kh, int& kw, int& ii, int& jj, int& c) {
   uint32_t tap = fd_div(g, p.fd_cin4);
@@ -62,7 +82,7 @@ __device__ __forceinline__ void decode_tap(const ConvP& p, uint32_t g, int& kh, 
 
 // ------------------------------------------------------------------ forward
 template <int BM, int BN>
-__global__ __launch_bounds__(256) void k_conv_fwd(ConvP p) {
+__global__ __launch_bounds__(256, 2) void k_conv_fwd(ConvP p) {   // 2 waves/SIMD: acc + tot must fit 256 regs
   constexpr int MI = BM / 64, NI = BN / 64, AR = BM / 32, BE = BN / 32;
   __shared__ __attribute__((aligned(16))) float As[BM * AS_STRIDE];
   __shared__ __attribute__((aligned(16))) float Bs[BK * BN];
@@ -86,13 +106,13 @@ __global__ __launch_bounds__(256) void k_conv_fwd(ConvP p) {
     bow[r] = (int)ow * p.stride - p.pad;
   }
 
-  f32x16 acc[MI][NI];
+  f32x16 acc[MI][NI], tot[MI][NI];
 #pragma unroll
   for (int i = 0; i < MI; ++i)
 #pragma unroll
     for (int j = 0; j < NI; ++j)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = tot[i][j][e] = 0.f;
 
   float4 va[AR], vb[BE];
   const int nkt = (p.K + BK - 1) / BK;
@@ -164,12 +184,17 @@ __global__ __launch_bounds__(256) void k_conv_fwd(ConvP p) {
         for (int j = 0; j < NI; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
     }
+    if (((kt + 1) & (FLUSH_TILES - 1)) == 0 && kt + 1 < nkt) flush_acc<MI, NI>(acc, tot);
     __syncthreads();
     if (kt + 1 < nkt) {
       store_tiles();
       __syncthreads();
     }
   }
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j) acc[i][j] += tot[i][j];
 
   // epilogue: bias + activation, NHWC store (32 consecutive channels per half-wave)
 #pragma unroll
@@ -191,7 +216,7 @@ __global__ __launch_bounds__(256) void k_conv_fwd(ConvP p) {
 
 // ------------------------------------------------------------------ dgrad
 template <int BM, int BN>
-__global__ __launch_bounds__(256) void k_conv_dgrad(ConvP p) {
+__global__ __launch_bounds__(256, 2) void k_conv_dgrad(ConvP p) {
   constexpr int MI = BM / 64, NI = BN / 64, AR = BM / 32, BR = BN / 32;
   __shared__ __attribute__((aligned(16))) float As[BM * AS_STRIDE];
   __shared__ __attribute__((aligned(16))) float Bt[BN * AS_STRIDE];
@@ -220,13 +245,13 @@ __global__ __launch_bounds__(256) void k_conv_dgrad(ConvP p) {
     pw[r] = (int)wq * s + cb;
   }
 
-  f32x16 acc[MI][NI];
+  f32x16 acc[MI][NI], tot[MI][NI];
 #pragma unroll
   for (int i = 0; i < MI; ++i)
 #pragma unroll
     for (int j = 0; j < NI; ++j)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = tot[i][j][e] = 0.f;
 
   float4 va[AR], vb[BR];
   const int nkt = (Kc + BK - 1) / BK;
@@ -313,12 +338,17 @@ __global__ __launch_bounds__(256) void k_conv_dgrad(ConvP p) {
         for (int j = 0; j < NI; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
     }
+    if (((kt + 1) & (FLUSH_TILES - 1)) == 0 && kt + 1 < nkt) flush_acc<MI, NI>(acc, tot);
     __syncthreads();
     if (kt + 1 < nkt) {
       store_tiles();
       __syncthreads();
     }
   }
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j) acc[i][j] += tot[i][j];
 
   // epilogue: column J = (q, c) -> physical pixel (h*ups + i, w*ups + j), channel c
 #pragma unroll
@@ -470,6 +500,40 @@ __global__ __launch_bounds__(256) void k_conv_wgrad(ConvP p) {
         if (Rr < p.K) slab[(size_t)Rr * p.Cout + co] = acc[i][j][e];
       }
     }
+  }
+}
+
+// stage 0 when there are many slabs: out[g][idx] = sum over the g-th group of slabs (fixed order),
+// fully parallel over elements and groups
+__global__ __launch_bounds__(256) void k_slab_sum(const float* __restrict__ slabs, float* __restrict__ out,
+                                                  size_t total4, int nsplit, int per_group) {
+  const int g = blockIdx.y;
+  const int z0 = g * per_group;
+  int z1 = z0 + per_group;
+  if (z1 > nsplit) z1 = nsplit;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (size_t)gridDim.x * blockDim.x) {
+    float4 s = f4zero();
+    for (int z = z0; z < z1; ++z) f4add(s, reinterpret_cast<const float4*>(slabs)[(size_t)z * total4 + i]);
+    reinterpret_cast<float4*>(out)[(size_t)g * total4 + i] = s;
+  }
+}
+
+// small weights: one thread per (R, co), scattered OIHW read-modify-write (irrelevant at this size)
+__global__ __launch_bounds__(256) void k_wgrad_scatter(const float* __restrict__ slabs, float* __restrict__ gw,
+                                                       ConvP p, int nsplit, int cin_log, int cout_log) {
+  const size_t total = (size_t)p.K * p.Cout;
+  const int U2 = p.ups * p.ups, KK = p.KH * p.KW;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (size_t)gridDim.x * blockDim.x) {
+    const uint32_t R = (uint32_t)(idx / p.Cout);
+    const int co = (int)(idx - (size_t)R * p.Cout);
+    const uint32_t t = R / (uint32_t)p.Cin;
+    const int c = (int)(R - t * (uint32_t)p.Cin);
+    if (co >= cout_log || c >= cin_log) continue;
+    const int tap9 = (int)t / U2, ph = (int)t - tap9 * U2;
+    float s = 0.f;
+    for (int z = 0; z < nsplit; ++z) s += slabs[(size_t)z * total + idx];
+    gw[((size_t)co * (cin_log * U2) + (size_t)c * U2 + ph) * KK + tap9] += s;
   }
 }
 
@@ -708,6 +772,8 @@ static void wgrad_plan(const ConvGeom& g, int& bm, int& bn, int& nsplit, int& pe
   nsplit = (total + per - 1) / per;
 }
 
+static const int kMaxDirectSlabs = 8;
+
 // bias-gradient column sums: TC channel quads per block, ~1024 blocks in flight
 static void colsum_plan(const ConvGeom& g, int& tc, int& cgroups, int& rows, int& nchunk) {
   int c4 = g.Cout / 4;
@@ -729,10 +795,11 @@ extern "C" size_t vcg_conv_wgrad_workspace(const int32_t* cd) {
   int bm, bn, nsplit, per, total;
   wgrad_plan(g, bm, bn, nsplit, per, total);
   size_t slabs = (size_t)nsplit * g.K * g.Cout * sizeof(float);
+  size_t groups = (size_t)16 * g.K * g.Cout * sizeof(float);     // k_slab_sum output (used when nsplit > 8)
   int tc, cgroups, rows, nchunk;
   colsum_plan(g, tc, cgroups, rows, nchunk);
   size_t cols = (size_t)nchunk * g.Cout * sizeof(float);
-  return slabs + cols + 512;
+  return slabs + groups + cols + 1024;
 }
 
 extern "C" int vcg_conv_wgrad(const float* x, const float* dy, float* gw_oihw, float* gbias,
@@ -754,14 +821,32 @@ extern "C" int vcg_conv_wgrad(const float* x, const float* dy, float* gw_oihw, f
   else if (bm == 64 && bn == 128) hipLaunchKernelGGL((k_conv_wgrad<64, 128>), grid, dim3(256), 0, st, p);
   else hipLaunchKernelGGL((k_conv_wgrad<64, 64>), grid, dim3(256), 0, st, p);
   VCG_LAUNCH_CHECK("vcg_conv_wgrad");
+  const size_t totalw = (size_t)g.K * g.Cout;
+  const size_t slab_bytes = (((size_t)nsplit * totalw * sizeof(float) + 255) / 256) * 256;
+  const float* src = (const float*)ws;
+  int ns = nsplit;
+  if (nsplit > kMaxDirectSlabs) {              // many thin slabs: parallel pre-sum into <= 16 group slabs
+    float* grp = (float*)((char*)ws + slab_bytes);
+    int per_group = (nsplit + 15) / 16;
+    int G = (nsplit + per_group - 1) / per_group;
+    size_t total4 = totalw / 4;
+    int bx = (int)((total4 + 255) / 256); if (bx > 1024) bx = 1024;
+    hipLaunchKernelGGL(k_slab_sum, dim3(bx, G), dim3(256), 0, st, src, grp, total4, nsplit, per_group);
+    src = grp;
+    ns = G;
+  }
   const int T = g.KH * g.KW * g.ups * g.ups;
   const size_t lds = (size_t)T * 8 * 33 * sizeof(float);
-  VCG_CHECK_ARG(lds <= 64 * 1024, "vcg_conv_wgrad: %d taps exceed the reduce kernel's LDS tile", T);
-  hipLaunchKernelGGL(k_wgrad_reduce, dim3((g.Cout + 31) / 32, (g.Cin + 7) / 8), dim3(256), lds, st, (const float*)ws,
-                     gw_oihw, p, nsplit, g.cin_log, g.cout_log);
+  if (totalw < (1u << 20) || lds > 64 * 1024) {
+    int blocks = (int)((totalw + 255) / 256); if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(k_wgrad_scatter, dim3(blocks), dim3(256), 0, st, src, gw_oihw, p, ns, g.cin_log, g.cout_log);
+  } else {
+    hipLaunchKernelGGL(k_wgrad_reduce, dim3((g.Cout + 31) / 32, (g.Cin + 7) / 8), dim3(256), lds, st, src, gw_oihw, p,
+                       ns, g.cin_log, g.cout_log);
+  }
   VCG_LAUNCH_CHECK("vcg_conv_wgrad(reduce)");
   if (gbias) {
-    float* part = (float*)((char*)ws + (((size_t)nsplit * g.K * g.Cout * sizeof(float) + 255) / 256) * 256);
+    float* part = (float*)((char*)ws + slab_bytes + (((size_t)16 * totalw * sizeof(float) + 255) / 256) * 256);
     int tc, cgroups, rows, nchunk;
     colsum_plan(g, tc, cgroups, rows, nchunk);
     hipLaunchKernelGGL(k_colsum_partial, dim3(cgroups, nchunk), dim3(256), 0, st, dy, part, g.M, g.Cout, rows, tc);

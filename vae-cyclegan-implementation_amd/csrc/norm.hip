@@ -39,10 +39,13 @@ static NormPlan make_plan(int N, int HW, int C) {
 template <int MODE>
 __global__ __launch_bounds__(256) void k_in_partial(const float* __restrict__ t, const float* __restrict__ g,
                                                     const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                    float* __restrict__ part, int H, int W, int C, NormPlan pl,
+                                                    double* __restrict__ part, int H, int W, int C, NormPlan pl,
                                                     int post_act, int shuffle) {
-  __shared__ float4 r1[256];
-  __shared__ float4 r2[256];
+  // fp64 accumulators: these sums cancel (var = E[x^2] - mean^2 for channels with |mean| >> std;
+  // sum g' and sum g'*xhat in the backward), and torch's CPU kernel — the reference's numerics —
+  // accumulates them in double too.  The kernel is HBM-bound, the extra fp64 adds are free.
+  __shared__ double r1[256 * 4];
+  __shared__ double r2[256 * 4];
   const int tc = threadIdx.x % pl.TC, tp = threadIdx.x / pl.TC;
   const int c4 = blockIdx.z * pl.TC + tc;
   const int n = blockIdx.y;
@@ -50,61 +53,76 @@ __global__ __launch_bounds__(256) void k_in_partial(const float* __restrict__ t,
   const int pb = blockIdx.x * pl.chunk;
   int pe = pb + pl.chunk;
   if (pe > HW) pe = HW;
-  float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
+  double s1[4] = {0.0, 0.0, 0.0, 0.0}, s2[4] = {0.0, 0.0, 0.0, 0.0};
   if (c4 * 4 < C) {
-    float4 mu = s1, rs = s1;
+    float mu[4] = {0.f, 0.f, 0.f, 0.f}, rs[4] = {0.f, 0.f, 0.f, 0.f};
     if (MODE == 1) {
-      mu = *reinterpret_cast<const float4*>(mean + (size_t)n * C + c4 * 4);
-      rs = *reinterpret_cast<const float4*>(rstd + (size_t)n * C + c4 * 4);
+      float4 m4 = *reinterpret_cast<const float4*>(mean + (size_t)n * C + c4 * 4);
+      float4 r4 = *reinterpret_cast<const float4*>(rstd + (size_t)n * C + c4 * 4);
+      mu[0] = m4.x; mu[1] = m4.y; mu[2] = m4.z; mu[3] = m4.w;
+      rs[0] = r4.x; rs[1] = r4.y; rs[2] = r4.z; rs[3] = r4.w;
     }
     for (int pix = pb + tp; pix < pe; pix += pl.TP) {
-      float4 v = *reinterpret_cast<const float4*>(t + ((size_t)n * HW + pix) * C + c4 * 4);
+      float4 v4 = *reinterpret_cast<const float4*>(t + ((size_t)n * HW + pix) * C + c4 * 4);
+      const float v[4] = {v4.x, v4.y, v4.z, v4.w};
       if (MODE == 0) {
-        s1.x += v.x; s1.y += v.y; s1.z += v.z; s1.w += v.w;
-        s2.x += v.x * v.x; s2.y += v.y * v.y; s2.z += v.z * v.z; s2.w += v.w * v.w;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          s1[e] += (double)v[e];
+          s2[e] += (double)v[e] * (double)v[e];
+        }
       } else {
-        float4 gv;
+        float gv[4];
         if (shuffle) {
           // g lives in the pixel-shuffled tensor (N, 2H, 2W, C/4): element e of the quad
           // sits at pixel (2h + e/2, 2w + e%2), channel c4
           const int h = pix / W, w = pix - h * W;
           const int Cq = C / 4;
           const float* gp = g + (((size_t)n * 2 * H + 2 * h) * (2 * W) + 2 * w) * Cq + c4;
-          gv.x = gp[0];
-          gv.y = gp[Cq];
-          gv.z = gp[(size_t)2 * W * Cq];
-          gv.w = gp[(size_t)2 * W * Cq + Cq];
+          gv[0] = gp[0];
+          gv[1] = gp[Cq];
+          gv[2] = gp[(size_t)2 * W * Cq];
+          gv[3] = gp[(size_t)2 * W * Cq + Cq];
         } else {
-          gv = *reinterpret_cast<const float4*>(g + ((size_t)n * HW + pix) * C + c4 * 4);
+          float4 g4 = *reinterpret_cast<const float4*>(g + ((size_t)n * HW + pix) * C + c4 * 4);
+          gv[0] = g4.x; gv[1] = g4.y; gv[2] = g4.z; gv[3] = g4.w;
         }
-        float4 xh;
-        xh.x = (v.x - mu.x) * rs.x; xh.y = (v.y - mu.y) * rs.y;
-        xh.z = (v.z - mu.z) * rs.z; xh.w = (v.w - mu.w) * rs.w;
-        gv.x *= act_grad_from_out(xh.x, post_act); gv.y *= act_grad_from_out(xh.y, post_act);
-        gv.z *= act_grad_from_out(xh.z, post_act); gv.w *= act_grad_from_out(xh.w, post_act);
-        s1.x += gv.x; s1.y += gv.y; s1.z += gv.z; s1.w += gv.w;
-        s2.x += gv.x * xh.x; s2.y += gv.y * xh.y; s2.z += gv.z * xh.z; s2.w += gv.w * xh.w;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float xh = (v[e] - mu[e]) * rs[e];
+          const float gg = gv[e] * act_grad_from_out(xh, post_act);
+          s1[e] += (double)gg;
+          s2[e] += (double)gg * (double)xh;
+        }
       }
     }
   }
-  r1[threadIdx.x] = s1;
-  r2[threadIdx.x] = s2;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    r1[threadIdx.x * 4 + e] = s1[e];
+    r2[threadIdx.x * 4 + e] = s2[e];
+  }
   __syncthreads();
   if (tp == 0 && c4 * 4 < C) {
     for (int k = 1; k < pl.TP; ++k) {
-      float4 a = r1[k * pl.TC + tc], b = r2[k * pl.TC + tc];
-      s1.x += a.x; s1.y += a.y; s1.z += a.z; s1.w += a.w;
-      s2.x += b.x; s2.y += b.y; s2.z += b.z; s2.w += b.w;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        s1[e] += r1[(k * pl.TC + tc) * 4 + e];
+        s2[e] += r2[(k * pl.TC + tc) * 4 + e];
+      }
     }
-    float* o = part + (((size_t)n * pl.nchunk + blockIdx.x) * C + c4 * 4) * 2;
-    o[0] = s1.x; o[1] = s2.x; o[2] = s1.y; o[3] = s2.y;
-    o[4] = s1.z; o[5] = s2.z; o[6] = s1.w; o[7] = s2.w;
+    double* o = part + (((size_t)n * pl.nchunk + blockIdx.x) * C + c4 * 4) * 2;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      o[2 * e] = s1[e];
+      o[2 * e + 1] = s2[e];
+    }
   }
 }
 
 // MODE 0: mean, rstd.  MODE 1: (s1/HW, s2/HW) interleaved into out1[(n*C+c)*2 + {0,1}]
 template <int MODE>
-__global__ void k_in_final(const float* __restrict__ part, float* __restrict__ out1, float* __restrict__ out2,
+__global__ void k_in_final(const double* __restrict__ part, float* __restrict__ out1, float* __restrict__ out2,
                            int N, int HW, int C, int nchunk, float eps) {
   // 32 (n,c) pairs x 8 chunk lanes per block: the chunk loop is a dependent chain of L2 round trips,
   // so it is split 8 ways and combined through LDS in a fixed order
@@ -117,9 +135,9 @@ __global__ void k_in_final(const float* __restrict__ part, float* __restrict__ o
   if (ok) {
     n = idx / C; c = idx - n * C;
     for (int k = kl; k < nchunk; k += 8) {
-      const float* p = part + (((size_t)n * nchunk + k) * C + c) * 2;
-      a += (double)p[0];
-      b += (double)p[1];
+      const double* p = part + (((size_t)n * nchunk + k) * C + c) * 2;
+      a += p[0];
+      b += p[1];
     }
   }
   ra[kl][il] = a;
@@ -242,7 +260,7 @@ static int ew_blocks(size_t work) {
 extern "C" size_t vcg_in_workspace(int N, int HW, int C) {
   if (N <= 0 || HW <= 0 || C <= 0 || C % 4) return 0;
   NormPlan pl = make_plan(N, HW, C);
-  return ((size_t)N * pl.nchunk * C * 2 + (size_t)N * C * 2) * sizeof(float) + 256;
+  return (size_t)N * pl.nchunk * C * 2 * sizeof(double) + (size_t)N * C * 2 * sizeof(float) + 256;
 }
 
 extern "C" int vcg_in_stats(const float* t, float* mean, float* rstd, int N, int HW, int C, float eps,
@@ -252,10 +270,10 @@ extern "C" int vcg_in_stats(const float* t, float* mean, float* rstd, int N, int
   VCG_CHECK_ARG(ws_bytes >= vcg_in_workspace(N, HW, C), "vcg_in_stats: workspace too small");
   NormPlan pl = make_plan(N, HW, C);
   hipStream_t st = (hipStream_t)stream;
-  float* part = (float*)ws;
+  double* part = (double*)ws;
   hipLaunchKernelGGL(k_in_partial<0>, dim3(pl.nchunk, N, pl.cgroups), dim3(256), 0, st, t, (const float*)nullptr,
                      (const float*)nullptr, (const float*)nullptr, part, HW, 1, C, pl, 0, 0);
-  hipLaunchKernelGGL(k_in_final<0>, dim3((N * C + 31) / 32), dim3(256), 0, st, (const float*)part, mean, rstd, N,
+  hipLaunchKernelGGL(k_in_final<0>, dim3((N * C + 31) / 32), dim3(256), 0, st, (const double*)part, mean, rstd, N,
                      HW, C, pl.nchunk, eps);
   VCG_LAUNCH_CHECK("vcg_in_stats");
   return 0;
@@ -284,11 +302,11 @@ extern "C" int vcg_in_bwd(const float* g, const float* t, const float* mean, con
   VCG_CHECK_ARG(ws_bytes >= vcg_in_workspace(N, HW, C), "vcg_in_bwd: workspace too small");
   NormPlan pl = make_plan(N, HW, C);
   hipStream_t st = (hipStream_t)stream;
-  float* part = (float*)ws;
-  float* s12 = part + (size_t)N * pl.nchunk * C * 2;
+  double* part = (double*)ws;
+  float* s12 = (float*)(part + (size_t)N * pl.nchunk * C * 2);
   hipLaunchKernelGGL(k_in_partial<1>, dim3(pl.nchunk, N, pl.cgroups), dim3(256), 0, st, t, g, mean, rstd, part, H, W,
                      C, pl, post_act, shuffle);
-  hipLaunchKernelGGL(k_in_final<1>, dim3((N * C + 31) / 32), dim3(256), 0, st, (const float*)part, s12,
+  hipLaunchKernelGGL(k_in_final<1>, dim3((N * C + 31) / 32), dim3(256), 0, st, (const double*)part, s12,
                      (float*)nullptr, N, HW, C, pl.nchunk, 0.f);
   size_t total = (size_t)N * HW * (C / 4);
   hipLaunchKernelGGL(k_in_bwd_apply, dim3(ew_blocks(total)), dim3(256), 0, st, g, t, mean, rstd, (const float*)s12,
