@@ -63,11 +63,15 @@ int vcg_fill(float* dst, float value, size_t n, void* stream);
 /* OIHW -> Wf[K][Cout], K ordered (kh,kw,i,j,c) so PixelUnshuffle (Networks.py:86)
    needs no data movement.                                                      */
 int vcg_pack_weight(const float* w_oihw, float* wf, const int32_t* cd, void* stream);
-/* y = act(conv(x) + bias): implicit GEMM on v_mfma_f32_32x32x2_f32.          */
+/* y = act(conv(x) + bias): implicit GEMM on v_mfma_f32_32x32x2_f32.  Layers with few output
+   tiles slice K across workgroups into fp32 slabs in `ws` (vcg_conv_fwd_workspace bytes, may be 0). */
+size_t vcg_conv_fwd_workspace(const int32_t* cd);
 int vcg_conv_fwd(const float* x, const float* wf, const float* bias, float* y,
-                 const int32_t* cd, void* stream);
+                 const int32_t* cd, void* ws, size_t ws_bytes, void* stream);
 /* dx = conv^T(dy) including the adjoint of the reflect padding.              */
-int vcg_conv_dgrad(const float* dy, const float* wf, float* dx, const int32_t* cd, void* stream);
+size_t vcg_conv_dgrad_workspace(const int32_t* cd);
+int vcg_conv_dgrad(const float* dy, const float* wf, float* dx, const int32_t* cd,
+                   void* ws, size_t ws_bytes, void* stream);
 /* gw_oihw += x^T dy (split-K slabs in ws, deterministic reduce); gbias += sum(dy).
    gbias may be NULL.                                                         */
 size_t vcg_conv_wgrad_workspace(const int32_t* cd);

@@ -52,12 +52,12 @@ def test_bad_arguments_are_rejected_without_touching_the_gpu(pkg):
     cd[5] = cd[6] = 3
     cd[7], cd[8], cd[9], cd[10], cd[12], cd[13] = 1, 1, 1, 1, 3, 8
     assert lib.vcg_conv_wgrad_workspace(cd) == 0
-    rc = lib.vcg_conv_fwd(None, None, None, None, cd, None)
+    rc = lib.vcg_conv_fwd(None, None, None, None, cd, None, 0, None)
     assert rc != 0
     assert b"multiple of 4" in lib.vcg_last_error()
     cd[3] = 4
     cd[1] = cd[2] = 1                                           # reflect pad 1 on a 1x1 map is illegal
-    assert lib.vcg_conv_fwd(None, None, None, None, cd, None) != 0
+    assert lib.vcg_conv_fwd(None, None, None, None, cd, None, 0, None) != 0
     assert b"reflect" in lib.vcg_last_error()
 
 

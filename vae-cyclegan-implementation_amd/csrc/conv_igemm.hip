@@ -39,6 +39,9 @@ struct ConvP {
   FastDiv fd_hcwc, fd_wc;
   // wgrad
   int ktiles_per_split, ktiles_total;
+  // split-K of fwd / dgrad (stride 1): blockIdx.z = K slice, raw partial tiles go to slab[z][M][N]
+  int ksplit, kt_per;
+  float* slab;
 };
 
 #define BK 32
@@ -115,7 +118,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_fwd(ConvP p) {   // 2 waves/SIM
       for (int e = 0; e < 16; ++e) acc[i][j][e] = tot[i][j][e] = 0.f;
 
   float4 va[AR], vb[BE];
-  const int nkt = (p.K + BK - 1) / BK;
+  int nkt = (p.K + BK - 1) / BK;
 
   auto load_tiles = [&](int kt) {
     uint32_t g = (uint32_t)(kt * 8 + a_u);
@@ -165,10 +168,18 @@ __global__ __launch_bounds__(256, 2) void k_conv_fwd(ConvP p) {   // 2 waves/SIM
     }
   };
 
-  load_tiles(0);
-  store_tiles();
+  int kt0 = 0;
+  if (p.ksplit > 1) {
+    kt0 = (int)blockIdx.z * p.kt_per;
+    int kt1 = kt0 + p.kt_per;
+    nkt = kt1 < nkt ? kt1 : nkt;
+  }
+  if (kt0 < nkt) {
+    load_tiles(kt0);
+    store_tiles();
+  }
   __syncthreads();
-  for (int kt = 0; kt < nkt; ++kt) {
+  for (int kt = kt0; kt < nkt; ++kt) {
     if (kt + 1 < nkt) load_tiles(kt + 1);
 #pragma unroll
     for (int ks = 0; ks < BK / 2; ++ks) {
@@ -184,7 +195,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_fwd(ConvP p) {   // 2 waves/SIM
         for (int j = 0; j < NI; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
     }
-    if (((kt + 1) & (FLUSH_TILES - 1)) == 0 && kt + 1 < nkt) flush_acc<MI, NI>(acc, tot);
+    if (((kt - kt0 + 1) & (FLUSH_TILES - 1)) == 0 && kt + 1 < nkt) flush_acc<MI, NI>(acc, tot);
     __syncthreads();
     if (kt + 1 < nkt) {
       store_tiles();
@@ -196,21 +207,45 @@ __global__ __launch_bounds__(256, 2) void k_conv_fwd(ConvP p) {   // 2 waves/SIM
 #pragma unroll
     for (int j = 0; j < NI; ++j) acc[i][j] += tot[i][j];
 
-  // epilogue: bias + activation, NHWC store (32 consecutive channels per half-wave)
+  // epilogue: bias + activation, NHWC store (32 consecutive channels per half-wave);
+  // a K slice stores its raw partial tile instead (bias/activation happen in k_splitk_finish)
+  float* const dst = p.ksplit > 1 ? p.slab + (size_t)blockIdx.z * p.M * p.Cout : p.out;
+  const int act = p.ksplit > 1 ? VCG_ACT_NONE : p.act;
 #pragma unroll
   for (int j = 0; j < NI; ++j) {
     const int co = n0 + wn * (BN / 2) + j * 32 + l31;
     if (co >= p.Cout) continue;
-    const float bv = (p.bias && co < p.cout_log) ? p.bias[co] : 0.f;
+    const float bv = (p.ksplit <= 1 && p.bias && co < p.cout_log) ? p.bias[co] : 0.f;
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int row = (e & 3) + 8 * (e >> 2) + 4 * lh;
         const int m = m0 + wm * (BM / 2) + i * 32 + row;
-        if (m < p.M) p.out[(size_t)m * p.Cout + co] = act_apply(acc[i][j][e] + bv, p.act);
+        if (m < p.M) dst[(size_t)m * p.Cout + co] = act_apply(acc[i][j][e] + bv, act);
       }
     }
+  }
+}
+
+// out[m][c] = act(sum_z slab[z][m][c] + bias[c]) — fixed summation order, float4 per lane
+__global__ __launch_bounds__(256) void k_splitk_finish(const float* __restrict__ slab, const float* __restrict__ bias,
+                                                       float* __restrict__ out, size_t rows, int C, int nsplit,
+                                                       int c_log, int act) {
+  const int C4 = C / 4;
+  const size_t total4 = rows * C4;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (size_t)gridDim.x * blockDim.x) {
+    float4 s = f4zero();
+    for (int z = 0; z < nsplit; ++z) f4add(s, reinterpret_cast<const float4*>(slab)[(size_t)z * total4 + i]);
+    const int c = (int)(i % C4) * 4;
+    if (bias) {
+      if (c + 0 < c_log) s.x += bias[c + 0];
+      if (c + 1 < c_log) s.y += bias[c + 1];
+      if (c + 2 < c_log) s.z += bias[c + 2];
+      if (c + 3 < c_log) s.w += bias[c + 3];
+    }
+    s.x = act_apply(s.x, act); s.y = act_apply(s.y, act); s.z = act_apply(s.z, act); s.w = act_apply(s.w, act);
+    reinterpret_cast<float4*>(out)[i] = s;
   }
 }
 
@@ -225,7 +260,8 @@ __global__ __launch_bounds__(256, 2) void k_conv_dgrad(ConvP p) {
   const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
   const int a_row = tid >> 3, a_u = tid & 7;
   const int s = p.stride, sshift = s - 1;
-  const int ca = (int)blockIdx.z / s, cb = (int)blockIdx.z % s;
+  const int cls = p.ksplit > 1 ? 0 : (int)blockIdx.z;     // blockIdx.z: parity class (stride 2) OR K slice
+  const int ca = cls / s, cb = cls % s;
   const int kh0 = (ca + p.pad) % s, kw0 = (cb + p.pad) % s;
   const int nKH = (p.KH - kh0 + s - 1) / s, nKW = (p.KW - kw0 + s - 1) / s;
   const int Kc = nKH * nKW * p.Cout;
@@ -254,7 +290,13 @@ __global__ __launch_bounds__(256, 2) void k_conv_dgrad(ConvP p) {
       for (int e = 0; e < 16; ++e) acc[i][j][e] = tot[i][j][e] = 0.f;
 
   float4 va[AR], vb[BR];
-  const int nkt = (Kc + BK - 1) / BK;
+  int nkt = (Kc + BK - 1) / BK;
+  int kt0 = 0;
+  if (p.ksplit > 1) {                      // stride 1 only: blockIdx.z is the K slice, not a parity class
+    kt0 = (int)blockIdx.z * p.kt_per;
+    int kt1 = kt0 + p.kt_per;
+    nkt = kt1 < nkt ? kt1 : nkt;
+  }
 
   auto load_tiles = [&](int kt) {
     uint32_t g = (uint32_t)(kt * 8 + a_u);
@@ -317,12 +359,12 @@ __global__ __launch_bounds__(256, 2) void k_conv_dgrad(ConvP p) {
     }
   };
 
-  if (nkt > 0) {
-    load_tiles(0);
+  if (kt0 < nkt) {
+    load_tiles(kt0);
     store_tiles();
   }
   __syncthreads();
-  for (int kt = 0; kt < nkt; ++kt) {
+  for (int kt = kt0; kt < nkt; ++kt) {
     if (kt + 1 < nkt) load_tiles(kt + 1);
 #pragma unroll
     for (int ks = 0; ks < BK / 2; ++ks) {
@@ -338,7 +380,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_dgrad(ConvP p) {
         for (int j = 0; j < NI; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
     }
-    if (((kt + 1) & (FLUSH_TILES - 1)) == 0 && kt + 1 < nkt) flush_acc<MI, NI>(acc, tot);
+    if (((kt - kt0 + 1) & (FLUSH_TILES - 1)) == 0 && kt + 1 < nkt) flush_acc<MI, NI>(acc, tot);
     __syncthreads();
     if (kt + 1 < nkt) {
       store_tiles();
@@ -349,6 +391,23 @@ __global__ __launch_bounds__(256, 2) void k_conv_dgrad(ConvP p) {
   for (int i = 0; i < MI; ++i)
 #pragma unroll
     for (int j = 0; j < NI; ++j) acc[i][j] += tot[i][j];
+
+  if (p.ksplit > 1) {   // raw partial tile; rows are pixels in memory order (stride 1, ups 1), k_splitk_finish sums
+    float* const dst = p.slab + (size_t)blockIdx.z * p.Mc * p.NB;
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      const int J = n0 + wn * (BN / 2) + j * 32 + l31;
+      if (J >= p.NB) continue;
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int m = m0 + wm * (BM / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+          if (m < p.Mc) dst[(size_t)m * p.NB + J] = acc[i][j][e];
+        }
+    }
+    return;
+  }
 
   // epilogue: column J = (q, c) -> physical pixel (h*ups + i, w*ups + j), channel c
 #pragma unroll
@@ -691,19 +750,35 @@ static void fill_params(const ConvGeom& g, ConvP& p) {
   p.Hc = p.Wc = p.Mc = p.NB = 0;
   p.fd_hcwc = make_fastdiv(1); p.fd_wc = make_fastdiv(1);
   p.ktiles_per_split = p.ktiles_total = 0;
+  p.ksplit = 1; p.kt_per = 0; p.slab = nullptr;
   p.bias = nullptr;
 }
 
-// pick the largest tile that still gives the 256 CUs two workgroups each
-static void pick_tile(long long rows, long long cols, int& bm, int& bn) {
+// Tile and K-slice choice.  The 256 CUs want >= 512 workgroups.  If the largest tile that reaches that
+// exists, use it.  Otherwise (deep layers: M = N*16*16 pixels, K up to 18 432) keep the big, efficient
+// tile and slice K across blockIdx.z instead of shrinking the tile: partial tiles go to fp32 slabs that
+// k_splitk_finish sums in a fixed order (+ bias + activation).
+static void gemm_plan(long long rows, long long cols, int nkt, bool allow_split, int& bm, int& bn, int& nsplit,
+                      int& kt_per) {
   const int cand[4][2] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}};
+  nsplit = 1;
+  kt_per = nkt;
   for (int i = 0; i < 4; ++i) {
     int m = cand[i][0], n = cand[i][1];
     if (cols <= 64 && n == 128) continue;
     long long wgs = ((rows + m - 1) / m) * ((cols + n - 1) / n);
-    if (wgs >= 512 || i == 3) { bm = m; bn = n; return; }
+    if (wgs >= 512) { bm = m; bn = n; return; }
   }
-  bm = 64; bn = 64;
+  bm = rows > 64 ? 128 : 64;
+  bn = cols > 64 ? 128 : 64;
+  long long tiles = ((rows + bm - 1) / bm) * ((cols + bn - 1) / bn);
+  long long want = (512 + tiles - 1) / tiles;
+  long long maxs = nkt / 8;
+  if (want > maxs) want = maxs;
+  if (want > 32) want = 32;
+  if (!allow_split || want < 2) { bm = 64; bn = 64; return; }
+  kt_per = (int)((nkt + want - 1) / want);
+  nsplit = (nkt + kt_per - 1) / kt_per;
 }
 
 #define DISPATCH_TILE(KERNEL, bm, bn, grid, stream, p)                                        \
@@ -726,35 +801,92 @@ extern "C" int vcg_pack_weight(const float* w_oihw, float* wf, const int32_t* cd
   return 0;
 }
 
+static void fwd_plan(const ConvGeom& g, int& bm, int& bn, int& nsplit, int& kt_per) {
+  gemm_plan(g.M, g.Cout, (g.K + BK - 1) / BK, true, bm, bn, nsplit, kt_per);
+}
+
+extern "C" size_t vcg_conv_fwd_workspace(const int32_t* cd) {
+  ConvGeom g;
+  if (vcg_conv_geom(cd, &g, "vcg_conv_fwd_workspace")) return 0;
+  if (vcg_thin_fwd_ok(g)) return 0;
+  int bm, bn, nsplit, kt_per;
+  fwd_plan(g, bm, bn, nsplit, kt_per);
+  return nsplit > 1 ? (size_t)nsplit * g.M * g.Cout * sizeof(float) + 256 : 0;
+}
+
+static int ew_grid(size_t work) {
+  size_t b = (work + 255) / 256;
+  if (b > 2048) b = 2048;
+  return b < 1 ? 1 : (int)b;
+}
+
 extern "C" int vcg_conv_fwd(const float* x, const float* wf, const float* bias, float* y,
-                            const int32_t* cd, void* stream) {
+                            const int32_t* cd, void* ws, size_t ws_bytes, void* stream) {
   ConvGeom g;
   if (vcg_conv_geom(cd, &g, "vcg_conv_fwd")) return -1;
   VCG_CHECK_ARG(x && wf && y, "vcg_conv_fwd: null pointer");
+  if (vcg_thin_fwd_ok(g)) return vcg_thin_fwd(g, x, wf, bias, y, (hipStream_t)stream);
   ConvP p; fill_params(g, p);
   p.a = x; p.b = wf; p.bias = bias; p.out = y;
-  int bm, bn; pick_tile(g.M, g.Cout, bm, bn);
-  dim3 grid((g.M + bm - 1) / bm, (g.Cout + bn - 1) / bn, 1);
-  DISPATCH_TILE(k_conv_fwd, bm, bn, grid, (hipStream_t)stream, p);
+  int bm, bn, nsplit, kt_per;
+  fwd_plan(g, bm, bn, nsplit, kt_per);
+  if (nsplit > 1) {
+    VCG_CHECK_ARG(ws && ws_bytes >= vcg_conv_fwd_workspace(cd), "vcg_conv_fwd: workspace too small (%zu)", ws_bytes);
+    p.ksplit = nsplit; p.kt_per = kt_per; p.slab = (float*)ws;
+  }
+  dim3 grid((g.M + bm - 1) / bm, (g.Cout + bn - 1) / bn, nsplit);
+  hipStream_t st = (hipStream_t)stream;
+  DISPATCH_TILE(k_conv_fwd, bm, bn, grid, st, p);
+  if (nsplit > 1)
+    hipLaunchKernelGGL(k_splitk_finish, dim3(ew_grid((size_t)g.M * g.Cout / 4)), dim3(256), 0, st, (const float*)ws, bias,
+                       y, (size_t)g.M, g.Cout, nsplit, g.cout_log, g.act);
   VCG_LAUNCH_CHECK("vcg_conv_fwd");
   return 0;
 }
 
-extern "C" int vcg_conv_dgrad(const float* dy, const float* wf, float* dx, const int32_t* cd, void* stream) {
+static int dgrad_setup(const ConvGeom& g, ConvP& p, int& bm, int& bn, int& nsplit, int& kt_per) {
+  p.Hc = g.Hl / g.stride; p.Wc = g.Wl / g.stride; p.Mc = g.N * p.Hc * p.Wc;
+  p.NB = g.ups * g.ups * g.Cin;
+  p.fd_hcwc = make_fastdiv((uint32_t)(p.Hc * p.Wc));
+  p.fd_wc = make_fastdiv((uint32_t)p.Wc);
+  const bool plain = g.stride == 1 && g.ups == 1;       // rows are pixels in memory order
+  gemm_plan(p.Mc, p.NB, (g.KH * g.KW * g.Cout + BK - 1) / BK, plain, bm, bn, nsplit, kt_per);
+  return 0;
+}
+
+extern "C" size_t vcg_conv_dgrad_workspace(const int32_t* cd) {
+  ConvGeom g;
+  if (vcg_conv_geom(cd, &g, "vcg_conv_dgrad_workspace")) return 0;
+  if (g.Hl % g.stride || g.Wl % g.stride) return 0;
+  if (vcg_thin_dgrad_ok(g)) return vcg_thin_dgrad_workspace(g);
+  ConvP p; fill_params(g, p);
+  int bm, bn, nsplit, kt_per;
+  dgrad_setup(g, p, bm, bn, nsplit, kt_per);
+  return nsplit > 1 ? (size_t)nsplit * p.Mc * p.NB * sizeof(float) + 256 : 0;
+}
+
+extern "C" int vcg_conv_dgrad(const float* dy, const float* wf, float* dx, const int32_t* cd, void* ws,
+                              size_t ws_bytes, void* stream) {
   ConvGeom g;
   if (vcg_conv_geom(cd, &g, "vcg_conv_dgrad")) return -1;
   VCG_CHECK_ARG(dy && wf && dx, "vcg_conv_dgrad: null pointer");
   VCG_CHECK_ARG(g.Hl % g.stride == 0 && g.Wl % g.stride == 0, "vcg_conv_dgrad: input %dx%d not divisible by stride", g.Hl, g.Wl);
   VCG_CHECK_ARG(g.stride == 1 || g.ups == 1, "vcg_conv_dgrad: stride 2 with ups 2 unsupported");
+  if (vcg_thin_dgrad_ok(g)) return vcg_thin_dgrad(g, dy, wf, dx, ws, ws_bytes, (hipStream_t)stream);
   ConvP p; fill_params(g, p);
   p.a = dy; p.b = wf; p.out = dx;
-  p.Hc = g.Hl / g.stride; p.Wc = g.Wl / g.stride; p.Mc = g.N * p.Hc * p.Wc;
-  p.NB = g.ups * g.ups * g.Cin;
-  p.fd_hcwc = make_fastdiv((uint32_t)(p.Hc * p.Wc));
-  p.fd_wc = make_fastdiv((uint32_t)p.Wc);
-  int bm, bn; pick_tile(p.Mc, p.NB, bm, bn);
-  dim3 grid((p.Mc + bm - 1) / bm, (p.NB + bn - 1) / bn, g.stride * g.stride);
-  DISPATCH_TILE(k_conv_dgrad, bm, bn, grid, (hipStream_t)stream, p);
+  int bm, bn, nsplit, kt_per;
+  dgrad_setup(g, p, bm, bn, nsplit, kt_per);
+  if (nsplit > 1) {
+    VCG_CHECK_ARG(ws && ws_bytes >= vcg_conv_dgrad_workspace(cd), "vcg_conv_dgrad: workspace too small (%zu)", ws_bytes);
+    p.ksplit = nsplit; p.kt_per = kt_per; p.slab = (float*)ws;
+  }
+  dim3 grid((p.Mc + bm - 1) / bm, (p.NB + bn - 1) / bn, nsplit > 1 ? nsplit : g.stride * g.stride);
+  hipStream_t st = (hipStream_t)stream;
+  DISPATCH_TILE(k_conv_dgrad, bm, bn, grid, st, p);
+  if (nsplit > 1)
+    hipLaunchKernelGGL(k_splitk_finish, dim3(ew_grid((size_t)p.Mc * p.NB / 4)), dim3(256), 0, st, (const float*)ws,
+                       (const float*)nullptr, dx, (size_t)p.Mc, p.NB, nsplit, p.NB, (int)VCG_ACT_NONE);
   VCG_LAUNCH_CHECK("vcg_conv_dgrad");
   return 0;
 }

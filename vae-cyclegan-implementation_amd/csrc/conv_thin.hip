@@ -1,0 +1,177 @@
+// Direct convolution for the layers with <= 4 output channels per pixel: the decoder head
+// CaSb(64, 3, k7) forward (Networks.py:192) and the data gradient of the encoder stem CaSb(3, 64, k7)
+// (Networks.py:158), which CycleVAEGAN needs because F(G(x)) and G(F(y)) differentiate through their
+// input images (Networks.py:1912, :1915).
+//
+// Why not the MFMA kernel: with N = 3 real columns a 32-wide MFMA tile does 10x the necessary work, and
+// on gfx950 the fp32 MFMA rate equals the fp32 VALU rate (64 FLOP/clk/SIMD), so the matrix core buys
+// nothing here.  Each lane owns ONE output pixel of a 16x16 tile and keeps its 3 (+1 pad) sums in
+// registers; the (16+k-1)^2 input patch of a 16-channel chunk is staged once in LDS as four float4
+// planes (lanes of a wave read consecutive 16-B slots: conflict-free ds_read_b128); the weights are the
+// same for every lane, so they stream through the scalar unit (s_load into SGPRs) and feed v_fma as the
+// scalar operand.  Per ds_read_b128: 12 useful FMAs.  HBM traffic = the activation once + 16 B/pixel out.
+//
+// Forward uses Wf[(tap, c)][4] as is.  The data gradient runs the same loop on dy with the taps flipped
+// and weights read as Wf[(tap, ci)][co], over the PADDED domain (zero extension, no reflection), and
+// k_fold_pad then folds the halo back: dx[q] = sum over {u : reflect(u) = q} of dxp[u] — the adjoint of
+// reflect padding, exact and atomic-free.
+#include "vcg_common.h"
+
+struct ThinP {
+  const float* x;      // (N, H, W, C) activations
+  const float* w;      // Wf
+  const float* bias;   // forward only (may be null)
+  float* out;          // (N, Ho, Wo, 4)
+  int N, H, W, C, Ho, Wo, K, pad, reflect, n_out, act;
+};
+
+#define TT 16   // output tile side
+#define CC 16   // channels per LDS chunk
+
+// MODE 0: forward      w(tap, c, j) = Wf[(tap*C + c)*4 + j]
+// MODE 1: data grad    w(tap, c, j) = Wf[((K*K-1-tap)*4 + j)*C + c]   (taps flipped, c = dy channel)
+template <int MODE>
+__global__ __launch_bounds__(256) void k_conv_thin(ThinP p) {
+  extern __shared__ __attribute__((aligned(16))) float4 patch[];   // [CC/4][PS*PS]
+  const int PS = TT + p.K - 1, PP = PS * PS;
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  const int ox0 = blockIdx.x * TT, oy0 = blockIdx.y * TT, n = blockIdx.z;
+  float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
+  const float* xn = p.x + (size_t)n * p.H * p.W * p.C;
+  const int KK = p.K * p.K;
+
+  for (int c0 = 0; c0 < p.C; c0 += CC) {
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < PP * (CC / 4); idx += 256) {
+      const int j = idx & (CC / 4 - 1), pos = idx / (CC / 4);
+      const int py = pos / PS, px = pos - py * PS;
+      int iy = oy0 + py - p.pad, ix = ox0 + px - p.pad;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      bool ok;
+      if (p.reflect) {
+        ok = iy > -p.H && iy < 2 * p.H - 1 && ix > -p.W && ix < 2 * p.W - 1 && iy >= -p.pad && ix >= -p.pad &&
+             iy <= p.H - 1 + p.pad && ix <= p.W - 1 + p.pad;
+        if (ok) { iy = reflect_idx(iy, p.H); ix = reflect_idx(ix, p.W); }
+      } else {
+        ok = iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+      }
+      if (ok) v = *reinterpret_cast<const float4*>(xn + ((size_t)iy * p.W + ix) * p.C + c0 + j * 4);
+      patch[j * PP + pos] = v;
+    }
+    __syncthreads();
+    for (int tap = 0; tap < KK; ++tap) {
+      const int ky = tap / p.K, kx = tap - ky * p.K;
+      const int pos = (ty + ky) * PS + tx + kx;
+#pragma unroll
+      for (int j = 0; j < CC / 4; ++j) {
+        const float4 v = patch[j * PP + pos];
+        const int c = c0 + j * 4;
+        if (MODE == 0) {
+          const float* wp = p.w + ((size_t)tap * p.C + c) * 4;          // wave-uniform -> scalar loads
+          acc0 += v.x * wp[0] + v.y * wp[4] + v.z * wp[8] + v.w * wp[12];
+          acc1 += v.x * wp[1] + v.y * wp[5] + v.z * wp[9] + v.w * wp[13];
+          acc2 += v.x * wp[2] + v.y * wp[6] + v.z * wp[10] + v.w * wp[14];
+        } else {
+          const float* wp = p.w + ((size_t)(KK - 1 - tap) * 4) * p.C + c;
+          acc0 += v.x * wp[0] + v.y * wp[1] + v.z * wp[2] + v.w * wp[3];
+          const float* w1 = wp + p.C;
+          acc1 += v.x * w1[0] + v.y * w1[1] + v.z * w1[2] + v.w * w1[3];
+          const float* w2 = w1 + p.C;
+          acc2 += v.x * w2[0] + v.y * w2[1] + v.z * w2[2] + v.w * w2[3];
+        }
+      }
+    }
+  }
+  const int oy = oy0 + ty, ox = ox0 + tx;
+  if (oy < p.Ho && ox < p.Wo) {
+    float4 o = make_float4(acc0, acc1, acc2, acc3);
+    if (p.bias) {
+      if (p.n_out > 0) o.x += p.bias[0];
+      if (p.n_out > 1) o.y += p.bias[1];
+      if (p.n_out > 2) o.z += p.bias[2];
+    }
+    if (p.n_out < 3) o.z = 0.f;
+    if (p.n_out < 2) o.y = 0.f;
+    o.x = act_apply(o.x, p.act); o.y = act_apply(o.y, p.act); o.z = act_apply(o.z, p.act);
+    *reinterpret_cast<float4*>(p.out + (((size_t)n * p.Ho + oy) * p.Wo + ox) * 4) = o;
+  }
+}
+
+// dx[n,h,w,:] = sum over padded-domain coordinates that reflect onto (h,w) of dxp[n,u,v,:]
+__global__ __launch_bounds__(256) void k_fold_pad(const float4* __restrict__ dxp, float4* __restrict__ dx, int N, int H,
+                                                  int W, int pad, int reflect) {
+  const size_t total = (size_t)N * H * W;
+  const int Hp = H + 2 * pad, Wp = W + 2 * pad;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    const int w = (int)(idx % W);
+    const size_t r = idx / W;
+    const int h = (int)(r % H), n = (int)(r / H);
+    int us[3], vs[3], nu = 0, nv = 0;
+    us[nu++] = h + pad;
+    vs[nv++] = w + pad;
+    if (reflect) {
+      if (h >= 1 && h <= pad) us[nu++] = pad - h;
+      if (h >= H - 1 - pad && h <= H - 2) us[nu++] = 2 * (H - 1) - h + pad;
+      if (w >= 1 && w <= pad) vs[nv++] = pad - w;
+      if (w >= W - 1 - pad && w <= W - 2) vs[nv++] = 2 * (W - 1) - w + pad;
+    }
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int a = 0; a < nu; ++a)
+      for (int b = 0; b < nv; ++b) {
+        const float4 t = dxp[((size_t)n * Hp + us[a]) * Wp + vs[b]];
+        s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+      }
+    dx[idx] = s;
+  }
+}
+
+bool vcg_thin_fwd_ok(const ConvGeom& g) {
+  return g.Cout == 4 && g.stride == 1 && g.ups == 1 && g.KH == g.KW && (g.KH & 1) && g.Cin % CC == 0 &&
+         g.pad == g.KH / 2;
+}
+bool vcg_thin_dgrad_ok(const ConvGeom& g) {
+  return g.Cin == 4 && g.stride == 1 && g.ups == 1 && g.KH == g.KW && (g.KH & 1) && g.Cout % CC == 0 &&
+         g.pad == g.KH / 2;
+}
+size_t vcg_thin_dgrad_workspace(const ConvGeom& g) {
+  return (size_t)g.N * (g.H + 2 * g.pad) * (g.W + 2 * g.pad) * 4 * sizeof(float) + 256;
+}
+
+int vcg_thin_fwd(const ConvGeom& g, const float* x, const float* wf, const float* bias, float* y, hipStream_t st) {
+  ThinP p;
+  p.x = x; p.w = wf; p.bias = bias; p.out = y;
+  p.N = g.N; p.H = g.H; p.W = g.W; p.C = g.Cin; p.Ho = g.Ho; p.Wo = g.Wo; p.K = g.KH; p.pad = g.pad;
+  p.reflect = g.reflect; p.n_out = g.cout_log < 3 ? g.cout_log : 3; p.act = g.act;
+  const int PS = TT + g.KH - 1;
+  const size_t lds = (size_t)PS * PS * CC * sizeof(float);
+  VCG_CHECK_ARG(lds <= 64 * 1024, "vcg_conv_fwd(thin): kernel %d too large for the LDS patch", g.KH);
+  VCG_CHECK_ARG(g.cout_log <= 3, "vcg_conv_fwd(thin): at most 3 logical output channels");
+  dim3 grid((g.Wo + TT - 1) / TT, (g.Ho + TT - 1) / TT, g.N);
+  hipLaunchKernelGGL(k_conv_thin<0>, grid, dim3(256), lds, st, p);
+  VCG_LAUNCH_CHECK("vcg_conv_fwd(thin)");
+  return 0;
+}
+
+int vcg_thin_dgrad(const ConvGeom& g, const float* dy, const float* wf, float* dx, void* ws, size_t ws_bytes,
+                   hipStream_t st) {
+  VCG_CHECK_ARG(ws && ws_bytes >= vcg_thin_dgrad_workspace(g), "vcg_conv_dgrad(thin): workspace too small");
+  VCG_CHECK_ARG(g.cin_log <= 3, "vcg_conv_dgrad(thin): at most 3 logical input channels");
+  ThinP p;
+  p.x = dy; p.w = wf; p.bias = nullptr; p.out = (float*)ws;
+  p.N = g.N; p.H = g.Ho; p.W = g.Wo; p.C = g.Cout; p.K = g.KH;
+  p.pad = 2 * g.pad;                         // full correlation: zero-extend dy by k-1 on every side
+  p.Ho = g.H + 2 * g.pad; p.Wo = g.W + 2 * g.pad;
+  p.reflect = 0; p.n_out = g.cin_log; p.act = VCG_ACT_NONE;
+  const int PS = TT + g.KH - 1;
+  const size_t lds = (size_t)PS * PS * CC * sizeof(float);
+  VCG_CHECK_ARG(lds <= 64 * 1024, "vcg_conv_dgrad(thin): kernel %d too large for the LDS patch", g.KH);
+  dim3 grid((p.Wo + TT - 1) / TT, (p.Ho + TT - 1) / TT, g.N);
+  hipLaunchKernelGGL(k_conv_thin<1>, grid, dim3(256), lds, st, p);
+  size_t total = (size_t)g.N * g.H * g.W;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(k_fold_pad, dim3(blocks), dim3(256), 0, st, (const float4*)ws, (float4*)dx, g.N, g.H, g.W, g.pad,
+                     g.reflect);
+  VCG_LAUNCH_CHECK("vcg_conv_dgrad(thin)");
+  return 0;
+}

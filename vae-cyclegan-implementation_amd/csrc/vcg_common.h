@@ -99,3 +99,11 @@ struct ConvGeom {
 };
 
 int vcg_conv_geom(const int32_t* cd, ConvGeom* g, const char* who);
+
+// conv_thin.hip: direct kernels for layers with <= 4 channels on the narrow side
+bool vcg_thin_fwd_ok(const ConvGeom& g);
+bool vcg_thin_dgrad_ok(const ConvGeom& g);
+size_t vcg_thin_dgrad_workspace(const ConvGeom& g);
+int vcg_thin_fwd(const ConvGeom& g, const float* x, const float* wf, const float* bias, float* y, hipStream_t st);
+int vcg_thin_dgrad(const ConvGeom& g, const float* dy, const float* wf, float* dx, void* ws, size_t ws_bytes,
+                   hipStream_t st);

@@ -267,7 +267,9 @@ class _ConvBlockFn(torch.autograd.Function):
         flops = 2.0 * n * ho * wo * spec.cout * spec.k * spec.k * spec.cin
         tag = f"{n}x{h}x{w}x{spec.cin_pitch}->{spec.cout_pitch} k{spec.k} s{spec.stride} u{spec.ups}"
         with _timed("conv_fwd", flops, tag):
-            _native.check(lib.vcg_conv_fwd(_ptr(xp), _ptr(wf), _ptr(bias), _ptr(t), cd, _stream()), "vcg_conv_fwd")
+            ws = workspace(lib.vcg_conv_fwd_workspace(cd), dev)
+            _native.check(lib.vcg_conv_fwd(_ptr(xp), _ptr(wf), _ptr(bias), _ptr(t), cd, _ptr(ws), ws.numel() * 4,
+                                           _stream()), "vcg_conv_fwd")
         mean = rstd = None
         if spec.norm:
             c = spec.cout_pitch
@@ -333,7 +335,9 @@ class _ConvBlockFn(torch.autograd.Function):
         if ctx.needs_input_grad[0] and id(spec) not in _NO_DGRAD:
             dxp = torch.empty_like(xp)
             with _timed("conv_dgrad", ctx.flops, ctx.tag):
-                _native.check(lib.vcg_conv_dgrad(_ptr(dt), _ptr(wf), _ptr(dxp), cd, _stream()), "vcg_conv_dgrad")
+                ws = workspace(lib.vcg_conv_dgrad_workspace(cd), dev)
+                _native.check(lib.vcg_conv_dgrad(_ptr(dt), _ptr(wf), _ptr(dxp), cd, _ptr(ws), ws.numel() * 4,
+                                                 _stream()), "vcg_conv_dgrad")
             dx = logical_of(dxp, spec.cin_phys_log)
         return dx, None, None, d_res, None, None, None
 
