@@ -42,6 +42,9 @@ struct ConvP {
   // split-K of fwd / dgrad (stride 1): blockIdx.z = K slice, raw partial tiles go to slab[z][M][N]
   int ksplit, kt_per;
   float* slab;
+  // wgrad with swapped roles (thin Cout): rows are gathered from dy through the adjoint of the padding
+  int adjoint;
+  int src_pitch;   // channel pitch of the tensor adjoint_gather reads (dy)
 };
 
 #define BK 32
@@ -81,6 +84,40 @@ __device__ __forceinline__ void decode_tap(const ConvP& p, uint32_t g, int& kh, 
   if (p.ups == 2) { jj = tap & 1; ii = (tap >> 1) & 1; tap >>= 2; }
   uint32_t q = fd_div(tap, p.fd_kw);
   kh = (int)q; kw = (int)(tap - q * (uint32_t)p.KW);
+}
+
+// sum of src[n, oh, ow, co..co+3] over every output pixel (oh, ow) whose padded-domain tap (kh, kw) lands on
+// input pixel (h, w): the adjoint of (reflect) padding.  A padded coordinate q folds onto h when
+// reflect(q) == h, so there are up to three source rows: h itself, -h near the top edge, 2(H-1)-h near the
+// bottom one (same for columns).  nHo = n * Ho.
+__device__ __forceinline__ float4 adjoint_gather(const ConvP& p, const float* __restrict__ src, int nHo, int h, int w,
+                                                 int kh, int kw, int co, int sshift) {
+  float4 acc4 = f4zero();
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    int qh; bool okh;
+    if (a == 0) { qh = h; okh = true; }
+    else if (a == 1) { qh = -h; okh = p.reflect && h >= 1 && h <= p.pad; }
+    else { qh = 2 * (p.Hl - 1) - h; okh = p.reflect && h >= p.Hl - 1 - p.pad && h <= p.Hl - 2; }
+    int numh = qh - kh + p.pad;
+    int oh = numh >> sshift;
+    okh = okh && numh >= 0 && oh < p.Ho;
+    if (!okh) continue;
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+      int qw; bool okw;
+      if (b == 0) { qw = w; okw = true; }
+      else if (b == 1) { qw = -w; okw = p.reflect && w >= 1 && w <= p.pad; }
+      else { qw = 2 * (p.Wl - 1) - w; okw = p.reflect && w >= p.Wl - 1 - p.pad && w <= p.Wl - 2; }
+      int numw = qw - kw + p.pad;
+      int ow = numw >> sshift;
+      okw = okw && numw >= 0 && ow < p.Wo;
+      if (!okw) continue;
+      size_t off = ((size_t)(nHo + oh) * p.Wo + ow) * p.src_pitch + co;
+      f4add(acc4, ldg4(src + off));
+    }
+  }
+  return acc4;
 }
 
 // ------------------------------------------------------------------ forward
@@ -308,33 +345,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_dgrad(ConvP p) {
 #pragma unroll
     for (int r = 0; r < AR; ++r) {
       float4 acc4 = f4zero();
-      if (pv[r] && kv) {
-        const int h = ph[r], w = pw[r];
-#pragma unroll
-        for (int a = 0; a < 3; ++a) {
-          int qh; bool okh;
-          if (a == 0) { qh = h; okh = true; }
-          else if (a == 1) { qh = -h; okh = p.reflect && h >= 1 && h <= p.pad; }
-          else { qh = 2 * (p.Hl - 1) - h; okh = p.reflect && h >= p.Hl - 1 - p.pad && h <= p.Hl - 2; }
-          int numh = qh - kh + p.pad;
-          int oh = numh >> sshift;
-          okh = okh && numh >= 0 && oh < p.Ho;
-          if (!okh) continue;
-#pragma unroll
-          for (int b = 0; b < 3; ++b) {
-            int qw; bool okw;
-            if (b == 0) { qw = w; okw = true; }
-            else if (b == 1) { qw = -w; okw = p.reflect && w >= 1 && w <= p.pad; }
-            else { qw = 2 * (p.Wl - 1) - w; okw = p.reflect && w >= p.Wl - 1 - p.pad && w <= p.Wl - 2; }
-            int numw = qw - kw + p.pad;
-            int ow = numw >> sshift;
-            okw = okw && numw >= 0 && ow < p.Wo;
-            if (!okw) continue;
-            size_t off = ((size_t)(pnHo[r] + oh) * p.Wo + ow) * p.Cout + co;
-            f4add(acc4, ldg4(p.a + off));
-          }
-        }
-      }
+      if (pv[r] && kv) acc4 = adjoint_gather(p, p.a, pnHo[r], ph[r], pw[r], kh, kw, co, sshift);
       va[r] = acc4;
     }
     const int tapfull = kh * p.KW + kw;
@@ -392,24 +403,9 @@ __global__ __launch_bounds__(256, 2) void k_conv_dgrad(ConvP p) {
 #pragma unroll
     for (int j = 0; j < NI; ++j) acc[i][j] += tot[i][j];
 
-  if (p.ksplit > 1) {   // raw partial tile; rows are pixels in memory order (stride 1, ups 1), k_splitk_finish sums
-    float* const dst = p.slab + (size_t)blockIdx.z * p.Mc * p.NB;
-#pragma unroll
-    for (int j = 0; j < NI; ++j) {
-      const int J = n0 + wn * (BN / 2) + j * 32 + l31;
-      if (J >= p.NB) continue;
-#pragma unroll
-      for (int i = 0; i < MI; ++i)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const int m = m0 + wm * (BM / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-          if (m < p.Mc) dst[(size_t)m * p.NB + J] = acc[i][j][e];
-        }
-    }
-    return;
-  }
-
-  // epilogue: column J = (q, c) -> physical pixel (h*ups + i, w*ups + j), channel c
+  // epilogue: column J = (q, c) -> physical pixel (h*ups + i, w*ups + j), channel c.
+  // A K slice writes its raw partial into slab[z] in the same physical layout; k_splitk_finish sums them.
+  float* const dst = p.ksplit > 1 ? p.slab + (size_t)blockIdx.z * p.N * p.H * p.W * p.Cin : p.out;
 #pragma unroll
   for (int j = 0; j < NI; ++j) {
     const int J = n0 + wn * (BN / 2) + j * 32 + l31;
@@ -430,7 +426,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_dgrad(ConvP p) {
           uint32_t wq = rem - hq * (uint32_t)p.Wc;
           int h = (int)hq * s + ca, w = (int)wq * s + cb;
           size_t off = ((size_t)((int)n * p.H + h * p.ups + qi) * p.W + (w * p.ups + qj)) * p.Cin + c;
-          p.out[off] = acc[i][j][e];
+          dst[off] = acc[i][j][e];
         }
       }
     }
@@ -479,17 +475,22 @@ __global__ __launch_bounds__(256) void k_conv_wgrad(ConvP p) {
         uint32_t rem = m - n * (uint32_t)(p.Ho * p.Wo);
         uint32_t oh = fd_div(rem, p.fd_wo);
         uint32_t ow = rem - oh * (uint32_t)p.Wo;
-        int ih = (int)oh * p.stride - p.pad + kh, iw = (int)ow * p.stride - p.pad + kw;
-        bool ok = true;
-        if (p.reflect) {
-          ih = reflect_idx(ih, p.Hl);
-          iw = reflect_idx(iw, p.Wl);
+        if (p.adjoint) {
+          // swapped roles: this K' pixel is an INPUT pixel; its row entries come from the 4-channel dy
+          v = adjoint_gather(p, p.a, (int)n * p.Ho, (int)oh, (int)ow, kh, kw, 0, 0);
         } else {
-          ok = (ih >= 0) && (ih < p.Hl) && (iw >= 0) && (iw < p.Wl);
-        }
-        if (ok) {
-          size_t off = ((size_t)((int)n * p.H + ih * p.ups + ii) * p.W + (iw * p.ups + jj)) * p.Cin + c;
-          v = ldg4(p.a + off);
+          int ih = (int)oh * p.stride - p.pad + kh, iw = (int)ow * p.stride - p.pad + kw;
+          bool ok = true;
+          if (p.reflect) {
+            ih = reflect_idx(ih, p.Hl);
+            iw = reflect_idx(iw, p.Wl);
+          } else {
+            ok = (ih >= 0) && (ih < p.Hl) && (iw >= 0) && (iw < p.Wl);
+          }
+          if (ok) {
+            size_t off = ((size_t)((int)n * p.H + ih * p.ups + ii) * p.W + (iw * p.ups + jj)) * p.Cin + c;
+            v = ldg4(p.a + off);
+          }
         }
       }
       va[a] = v;
@@ -593,6 +594,22 @@ __global__ __launch_bounds__(256) void k_wgrad_scatter(const float* __restrict__
     float s = 0.f;
     for (int z = 0; z < nsplit; ++z) s += slabs[(size_t)z * total + idx];
     gw[((size_t)co * (cin_log * U2) + (size_t)c * U2 + ph) * KK + tap9] += s;
+  }
+}
+
+// swapped-role wgrad: slabs[z][(tap, j)][c] -> gw_oihw[j][c][tap] += sum_z
+__global__ __launch_bounds__(256) void k_wgrad_scatter_swapped(const float* __restrict__ slabs, float* __restrict__ gw,
+                                                               int T, int C, int nsplit, int cin_real, int cout_real) {
+  const size_t total = (size_t)T * 4 * C;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(idx % C);
+    const int R = (int)(idx / C);
+    const int t = R >> 2, j = R & 3;
+    if (j >= cout_real || c >= cin_real) continue;
+    float s = 0.f;
+    for (int z = 0; z < nsplit; ++z) s += slabs[(size_t)z * total + idx];
+    gw[((size_t)j * cin_real + c) * T + t] += s;
   }
 }
 
@@ -750,7 +767,7 @@ static void fill_params(const ConvGeom& g, ConvP& p) {
   p.Hc = p.Wc = p.Mc = p.NB = 0;
   p.fd_hcwc = make_fastdiv(1); p.fd_wc = make_fastdiv(1);
   p.ktiles_per_split = p.ktiles_total = 0;
-  p.ksplit = 1; p.kt_per = 0; p.slab = nullptr;
+  p.ksplit = 1; p.kt_per = 0; p.slab = nullptr; p.adjoint = 0; p.src_pitch = g.Cout;
   p.bias = nullptr;
 }
 
@@ -760,25 +777,33 @@ static void fill_params(const ConvGeom& g, ConvP& p) {
 // k_splitk_finish sums in a fixed order (+ bias + activation).
 static void gemm_plan(long long rows, long long cols, int nkt, bool allow_split, int& bm, int& bn, int& nsplit,
                       int& kt_per) {
-  const int cand[4][2] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}};
+  const int cand[3][2] = {{128, 128}, {128, 64}, {64, 128}};
   nsplit = 1;
   kt_per = nkt;
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < 3; ++i) {
     int m = cand[i][0], n = cand[i][1];
     if (cols <= 64 && n == 128) continue;
+    if (rows <= 64 && m == 128) continue;
     long long wgs = ((rows + m - 1) / m) * ((cols + n - 1) / n);
     if (wgs >= 512) { bm = m; bn = n; return; }
   }
-  bm = rows > 64 ? 128 : 64;
-  bn = cols > 64 ? 128 : 64;
-  long long tiles = ((rows + bm - 1) / bm) * ((cols + bn - 1) / bn);
-  long long want = (512 + tiles - 1) / tiles;
-  long long maxs = nkt / 8;
-  if (want > maxs) want = maxs;
-  if (want > 32) want = 32;
-  if (!allow_split || want < 2) { bm = 64; bn = 64; return; }
-  kt_per = (int)((nkt + want - 1) / want);
-  nsplit = (nkt + kt_per - 1) / kt_per;
+  // too few output tiles: slice K under the big tile (measured: 128x128 + 4 slices beats 64x64 tiles on the
+  // 1024->1024 convs at 16x16), unless K is too short to slice
+  if (allow_split) {
+    int m = rows > 64 ? 128 : 64, n = cols > 64 ? 128 : 64;
+    long long tiles = ((rows + m - 1) / m) * ((cols + n - 1) / n);
+    long long want = (512 + tiles - 1) / tiles;
+    long long maxs = nkt / 8;
+    if (want > maxs) want = maxs;
+    if (want > 32) want = 32;
+    if (want >= 2) {
+      bm = m; bn = n;
+      kt_per = (int)((nkt + want - 1) / want);
+      nsplit = (nkt + kt_per - 1) / kt_per;
+      return;
+    }
+  }
+  bm = 64; bn = 64;
 }
 
 #define DISPATCH_TILE(KERNEL, bm, bn, grid, stream, p)                                        \
@@ -849,8 +874,8 @@ static int dgrad_setup(const ConvGeom& g, ConvP& p, int& bm, int& bn, int& nspli
   p.NB = g.ups * g.ups * g.Cin;
   p.fd_hcwc = make_fastdiv((uint32_t)(p.Hc * p.Wc));
   p.fd_wc = make_fastdiv((uint32_t)p.Wc);
-  const bool plain = g.stride == 1 && g.ups == 1;       // rows are pixels in memory order
-  gemm_plan(p.Mc, p.NB, (g.KH * g.KW * g.Cout + BK - 1) / BK, plain, bm, bn, nsplit, kt_per);
+  // stride 2 uses blockIdx.z for its parity classes, so only stride 1 can slice K
+  gemm_plan(p.Mc, p.NB, (g.KH * g.KW * g.Cout + BK - 1) / BK, g.stride == 1, bm, bn, nsplit, kt_per);
   return 0;
 }
 
@@ -862,7 +887,7 @@ extern "C" size_t vcg_conv_dgrad_workspace(const int32_t* cd) {
   ConvP p; fill_params(g, p);
   int bm, bn, nsplit, kt_per;
   dgrad_setup(g, p, bm, bn, nsplit, kt_per);
-  return nsplit > 1 ? (size_t)nsplit * p.Mc * p.NB * sizeof(float) + 256 : 0;
+  return nsplit > 1 ? (size_t)nsplit * g.N * g.H * g.W * g.Cin * sizeof(float) + 256 : 0;
 }
 
 extern "C" int vcg_conv_dgrad(const float* dy, const float* wf, float* dx, const int32_t* cd, void* ws,
@@ -885,8 +910,9 @@ extern "C" int vcg_conv_dgrad(const float* dy, const float* wf, float* dx, const
   hipStream_t st = (hipStream_t)stream;
   DISPATCH_TILE(k_conv_dgrad, bm, bn, grid, st, p);
   if (nsplit > 1)
-    hipLaunchKernelGGL(k_splitk_finish, dim3(ew_grid((size_t)p.Mc * p.NB / 4)), dim3(256), 0, st, (const float*)ws,
-                       (const float*)nullptr, dx, (size_t)p.Mc, p.NB, nsplit, p.NB, (int)VCG_ACT_NONE);
+    hipLaunchKernelGGL(k_splitk_finish, dim3(ew_grid((size_t)g.N * g.H * g.W * g.Cin / 4)), dim3(256), 0, st,
+                       (const float*)ws, (const float*)nullptr, dx, (size_t)g.N * g.H * g.W, g.Cin, nsplit, g.Cin,
+                       (int)VCG_ACT_NONE);
   VCG_LAUNCH_CHECK("vcg_conv_dgrad");
   return 0;
 }
@@ -921,17 +947,35 @@ static void colsum_plan(const ConvGeom& g, int& tc, int& cgroups, int& rows, int
   nchunk = (g.M + rows - 1) / rows;
 }
 
+static bool wgrad_swapped_ok(const ConvGeom& g);
+static ConvGeom swapped_geom(const ConvGeom& g);
+
 extern "C" size_t vcg_conv_wgrad_workspace(const int32_t* cd) {
   ConvGeom g;
   if (vcg_conv_geom(cd, &g, "vcg_conv_wgrad_workspace")) return 0;
+  const ConvGeom gorig = g;
+  if (wgrad_swapped_ok(g)) g = swapped_geom(g);
   int bm, bn, nsplit, per, total;
   wgrad_plan(g, bm, bn, nsplit, per, total);
   size_t slabs = (size_t)nsplit * g.K * g.Cout * sizeof(float);
   size_t groups = (size_t)16 * g.K * g.Cout * sizeof(float);     // k_slab_sum output (used when nsplit > 8)
   int tc, cgroups, rows, nchunk;
-  colsum_plan(g, tc, cgroups, rows, nchunk);
-  size_t cols = (size_t)nchunk * g.Cout * sizeof(float);
+  colsum_plan(gorig, tc, cgroups, rows, nchunk);
+  size_t cols = (size_t)nchunk * gorig.Cout * sizeof(float);
   return slabs + groups + cols + 1024;
+}
+
+// Thin Cout (the decoder head, 64 -> 3): dW[(tap,c)][co<4] as an MFMA GEMM wastes 15/16 of the tile.  With
+// the roles swapped — rows (tap, co) gathered from the 4-channel dy through the adjoint of the padding,
+// columns c from x, summed over INPUT pixels — it becomes a well-shaped 196 x 64 weight gradient.
+static bool wgrad_swapped_ok(const ConvGeom& g) {
+  return g.Cout == 4 && g.stride == 1 && g.ups == 1 && g.Ho == g.H && g.Wo == g.W && g.Cin >= 32;
+}
+static ConvGeom swapped_geom(const ConvGeom& g) {
+  ConvGeom s = g;
+  s.Cin = 4; s.Cout = g.Cin; s.cin_log = g.cout_log; s.cout_log = g.cin_log;
+  s.taps = g.KH * g.KW; s.K = s.taps * 4; s.M = g.N * g.H * g.W; s.act = 0;
+  return s;
 }
 
 extern "C" int vcg_conv_wgrad(const float* x, const float* dy, float* gw_oihw, float* gbias,
@@ -941,10 +985,14 @@ extern "C" int vcg_conv_wgrad(const float* x, const float* dy, float* gw_oihw, f
   VCG_CHECK_ARG(x && dy && gw_oihw && ws, "vcg_conv_wgrad: null pointer");
   size_t need = vcg_conv_wgrad_workspace(cd);
   VCG_CHECK_ARG(ws_bytes >= need, "vcg_conv_wgrad: workspace %zu < %zu", ws_bytes, need);
+  const bool swapped = wgrad_swapped_ok(g);
+  const ConvGeom gorig = g;
+  if (swapped) g = swapped_geom(g);
   ConvP p; fill_params(g, p);
   int bm, bn, nsplit, per, total;
   wgrad_plan(g, bm, bn, nsplit, per, total);
   p.a = x; p.b = dy; p.out = (float*)ws;
+  if (swapped) { p.a = dy; p.b = x; p.adjoint = 1; p.src_pitch = 4; }
   p.ktiles_per_split = per; p.ktiles_total = total;
   dim3 grid((g.K + bm - 1) / bm, (g.Cout + bn - 1) / bn, nsplit);
   hipStream_t st = (hipStream_t)stream;
@@ -969,7 +1017,11 @@ extern "C" int vcg_conv_wgrad(const float* x, const float* dy, float* gw_oihw, f
   }
   const int T = g.KH * g.KW * g.ups * g.ups;
   const size_t lds = (size_t)T * 8 * 33 * sizeof(float);
-  if (totalw < (1u << 20) || lds > 64 * 1024) {
+  if (swapped) {
+    int blocks = (int)((totalw + 255) / 256); if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(k_wgrad_scatter_swapped, dim3(blocks), dim3(256), 0, st, src, gw_oihw, g.KH * g.KW, g.Cout, ns,
+                       gorig.cin_log, gorig.cout_log);
+  } else if (totalw < (1u << 20) || lds > 64 * 1024) {
     int blocks = (int)((totalw + 255) / 256); if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(k_wgrad_scatter, dim3(blocks), dim3(256), 0, st, src, gw_oihw, p, ns, g.cin_log, g.cout_log);
   } else {
@@ -980,9 +1032,10 @@ extern "C" int vcg_conv_wgrad(const float* x, const float* dy, float* gw_oihw, f
   if (gbias) {
     float* part = (float*)((char*)ws + slab_bytes + (((size_t)16 * totalw * sizeof(float) + 255) / 256) * 256);
     int tc, cgroups, rows, nchunk;
-    colsum_plan(g, tc, cgroups, rows, nchunk);
-    hipLaunchKernelGGL(k_colsum_partial, dim3(cgroups, nchunk), dim3(256), 0, st, dy, part, g.M, g.Cout, rows, tc);
-    hipLaunchKernelGGL(k_colsum_final, dim3((g.cout_log + 63) / 64), dim3(64), 0, st, (const float*)part, gbias, g.Cout, nchunk, g.cout_log);
+    colsum_plan(gorig, tc, cgroups, rows, nchunk);
+    hipLaunchKernelGGL(k_colsum_partial, dim3(cgroups, nchunk), dim3(256), 0, st, dy, part, gorig.M, gorig.Cout, rows, tc);
+    hipLaunchKernelGGL(k_colsum_final, dim3((gorig.cout_log + 63) / 64), dim3(64), 0, st, (const float*)part, gbias,
+                       gorig.Cout, nchunk, gorig.cout_log);
     VCG_LAUNCH_CHECK("vcg_conv_wgrad(bias)");
   }
   return 0;
