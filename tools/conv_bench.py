@@ -1,0 +1,69 @@
+#!/usr/bin/env python3
+"""Micro-benchmark of the conv kernels on the shapes of the 256x256 training step (batch 8).
+    python tools/conv_bench.py [--reps R] [--layers d2,r,u3 ...]
+Prints per-kernel-family TFLOP/s from HIP events; run it under `rocprofv3 --pmc ...` for counters."""
+import argparse
+import importlib
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+pkg = importlib.import_module("vae-cyclegan-implementation_amd")
+ops = pkg.ops
+
+# name: (cin_logical, cout, k, stride, pad, ups, H_in_physical, C_in_physical)
+LAYERS = {
+    "stem": (3, 64, 7, 1, 3, 1, 256, 3),
+    "d1": (256, 128, 3, 1, 1, 2, 256, 64),
+    "d2": (512, 256, 3, 1, 1, 2, 128, 128),
+    "d3": (1024, 512, 3, 1, 1, 2, 64, 256),
+    "d4": (2048, 1024, 3, 1, 1, 2, 32, 512),
+    "r": (1024, 1024, 3, 1, 1, 1, 16, 1024),
+    "u1": (256, 512, 3, 1, 1, 1, 32, 256),
+    "u2": (128, 256, 3, 1, 1, 1, 64, 128),
+    "u3": (64, 128, 3, 1, 1, 1, 128, 64),
+    "u4": (32, 64, 3, 1, 1, 1, 256, 32),
+    "head": (64, 3, 7, 1, 3, 1, 256, 64),
+    "mu": (1024, 64, 3, 1, 1, 1, 16, 1024),
+    "vdb": (64, 1024, 3, 1, 1, 1, 16, 64),
+    "disc1": (64, 128, 4, 2, 1, 1, 128, 64),
+}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=8)
+    ap.add_argument("--layers", default="d1,d2,d3,d4,r,u1,u2,u3,u4")
+    args = ap.parse_args()
+    dev = torch.device("cuda:0")
+    for name in args.layers.split(","):
+        cin, cout, k, s, pad, ups, h, cphys = LAYERS[name]
+        spec = ops.ConvSpec(cin, cout, k, s, pad, True, ups)
+        w = torch.nn.Parameter(torch.randn(cout, cin, k, k, device=dev) * 0.05)
+        b = torch.nn.Parameter(torch.zeros(cout, device=dev))
+        x = ops.to_nhwc(torch.randn(args.batch, cphys, h, h, device=dev)).requires_grad_(True)
+        y = ops.conv_block(x, w, b, spec)
+        g = ops.to_nhwc(torch.randn(tuple(y.shape), device=dev))
+        y.backward(g)                                   # warm-up (also allocates workspaces)
+        ops.PROFILE = []
+        for _ in range(args.reps):
+            x.grad = None
+            y = ops.conv_block(x, w, b, spec)
+            y.backward(g)
+        torch.cuda.synchronize()
+        recs, ops.PROFILE = ops.PROFILE, None
+        fam = {}
+        for fname, flops, e0, e1, tag in recs:
+            f = fam.setdefault(fname, [0.0, 0.0])
+            f[0] += flops
+            f[1] += e0.elapsed_time(e1) * 1e-3
+        line = " ".join(f"{k_}: {v[1] / args.reps * 1e6:8.1f} us {v[0] / v[1] / 1e12:6.1f} TF |" for k_, v in sorted(fam.items()))
+        print(f"{name:6s} {recs[0][4]:34s} {line}", flush=True)
+
+
+if __name__ == "__main__":
+    main()

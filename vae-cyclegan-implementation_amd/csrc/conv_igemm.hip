@@ -90,34 +90,45 @@ __device__ __forceinline__ void decode_tap(const ConvP& p, uint32_t g, int& kh, 
 // input pixel (h, w): the adjoint of (reflect) padding.  A padded coordinate q folds onto h when
 // reflect(q) == h, so there are up to three source rows: h itself, -h near the top edge, 2(H-1)-h near the
 // bottom one (same for columns).  nHo = n * Ho.
-__device__ __forceinline__ float4 adjoint_gather(const ConvP& p, const float* __restrict__ src, int nHo, int h, int w,
-                                                 int kh, int kw, int co, int sshift) {
-  float4 acc4 = f4zero();
+// `main` gets the always-present source (the tap read at (h, w) itself) as a plain load with NO use, so
+// the caller can keep it in flight under the MFMAs; `extra` sums the fold sources, which exist only for
+// pixels within `pad` of an edge (that add forces a wait, but only in those few waves).
+__device__ __forceinline__ void adjoint_gather(const ConvP& p, const float* __restrict__ src, int nHo, int h, int w,
+                                               int kh, int kw, int co, int sshift, float4& main, float4& extra) {
+  main = f4zero();
+  extra = f4zero();
+  const bool edge = p.reflect && (h <= p.pad || h >= p.Hl - 1 - p.pad || w <= p.pad || w >= p.Wl - 1 - p.pad);
+  {
+    int numh = h - kh + p.pad, numw = w - kw + p.pad;
+    int oh = numh >> sshift, ow = numw >> sshift;
+    if (numh >= 0 && oh < p.Ho && numw >= 0 && ow < p.Wo)
+      main = ldg4(src + ((size_t)(nHo + oh) * p.Wo + ow) * p.src_pitch + co);
+  }
+  if (!edge) return;
 #pragma unroll
   for (int a = 0; a < 3; ++a) {
     int qh; bool okh;
     if (a == 0) { qh = h; okh = true; }
-    else if (a == 1) { qh = -h; okh = p.reflect && h >= 1 && h <= p.pad; }
-    else { qh = 2 * (p.Hl - 1) - h; okh = p.reflect && h >= p.Hl - 1 - p.pad && h <= p.Hl - 2; }
+    else if (a == 1) { qh = -h; okh = h >= 1 && h <= p.pad; }
+    else { qh = 2 * (p.Hl - 1) - h; okh = h >= p.Hl - 1 - p.pad && h <= p.Hl - 2; }
     int numh = qh - kh + p.pad;
     int oh = numh >> sshift;
     okh = okh && numh >= 0 && oh < p.Ho;
     if (!okh) continue;
 #pragma unroll
     for (int b = 0; b < 3; ++b) {
+      if (a == 0 && b == 0) continue;            // the main source
       int qw; bool okw;
       if (b == 0) { qw = w; okw = true; }
-      else if (b == 1) { qw = -w; okw = p.reflect && w >= 1 && w <= p.pad; }
-      else { qw = 2 * (p.Wl - 1) - w; okw = p.reflect && w >= p.Wl - 1 - p.pad && w <= p.Wl - 2; }
+      else if (b == 1) { qw = -w; okw = w >= 1 && w <= p.pad; }
+      else { qw = 2 * (p.Wl - 1) - w; okw = w >= p.Wl - 1 - p.pad && w <= p.Wl - 2; }
       int numw = qw - kw + p.pad;
       int ow = numw >> sshift;
       okw = okw && numw >= 0 && ow < p.Wo;
       if (!okw) continue;
-      size_t off = ((size_t)(nHo + oh) * p.Wo + ow) * p.src_pitch + co;
-      f4add(acc4, ldg4(src + off));
+      f4add(extra, ldg4(src + ((size_t)(nHo + oh) * p.Wo + ow) * p.src_pitch + co));
     }
   }
-  return acc4;
 }
 
 // ------------------------------------------------------------------ forward
@@ -326,7 +337,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_dgrad(ConvP p) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = tot[i][j][e] = 0.f;
 
-  float4 va[AR], vb[BR];
+  float4 va[AR], ve[AR], vb[BR];
   int nkt = (Kc + BK - 1) / BK;
   int kt0 = 0;
   if (p.ksplit > 1) {                      // stride 1 only: blockIdx.z is the K slice, not a parity class
@@ -344,9 +355,9 @@ __global__ __launch_bounds__(256, 2) void k_conv_dgrad(ConvP p) {
     int kh = kh0 + u * s, kw = kw0 + v_ * s;
 #pragma unroll
     for (int r = 0; r < AR; ++r) {
-      float4 acc4 = f4zero();
-      if (pv[r] && kv) acc4 = adjoint_gather(p, p.a, pnHo[r], ph[r], pw[r], kh, kw, co, sshift);
-      va[r] = acc4;
+      va[r] = f4zero();
+      ve[r] = f4zero();
+      if (pv[r] && kv) adjoint_gather(p, p.a, pnHo[r], ph[r], pw[r], kh, kw, co, sshift, va[r], ve[r]);
     }
     const int tapfull = kh * p.KW + kw;
 #pragma unroll
@@ -361,7 +372,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_dgrad(ConvP p) {
 #pragma unroll
     for (int r = 0; r < AR; ++r) {
       float* d = &As[(a_row + 32 * r) * AS_STRIDE + a_u * 4];
-      d[0] = va[r].x; d[1] = va[r].y; d[2] = va[r].z; d[3] = va[r].w;
+      d[0] = va[r].x + ve[r].x; d[1] = va[r].y + ve[r].y; d[2] = va[r].z + ve[r].z; d[3] = va[r].w + ve[r].w;
     }
 #pragma unroll
     for (int r = 0; r < BR; ++r) {
@@ -465,21 +476,44 @@ __global__ __launch_bounds__(256) void k_conv_wgrad(ConvP p) {
 
   float4 va[AP], vb[BE];
 
-  auto load_tiles = [&](int kt) {
+  // Pixel coordinates of this thread's K' slots, advanced incrementally (32 pixels per step): the two
+  // divisions per pixel per step of a from-scratch decode were most of this kernel's 8 VALU ops per MFMA.
+  uint32_t sm[AP];
+  int sn[AP], soh[AP], sow[AP];
+#pragma unroll
+  for (int a = 0; a < AP; ++a) {
+    uint32_t m = (uint32_t)(kt_begin * BK + ps + PS * a);
+    uint32_t n = fd_div(m, p.fd_howo);
+    uint32_t rem = m - n * (uint32_t)(p.Ho * p.Wo);
+    uint32_t oh = fd_div(rem, p.fd_wo);
+    sm[a] = m; sn[a] = (int)n; soh[a] = (int)oh; sow[a] = (int)(rem - oh * (uint32_t)p.Wo);
+  }
+  uint32_t bmrow[BE];
+  size_t boff[BE];
+  bool bcol[BE];
+#pragma unroll
+  for (int e = 0; e < BE; ++e) {
+    int idx = tid + 256 * e;
+    int pp = idx / (BN / 4), j4 = idx % (BN / 4);
+    bmrow[e] = (uint32_t)(kt_begin * BK + pp);
+    bcol[e] = n0 + j4 * 4 < p.Cout;
+    boff[e] = (size_t)bmrow[e] * p.Cout + n0 + j4 * 4;
+  }
+  const size_t bstep = (size_t)BK * p.Cout;
+
+  auto load_tiles = [&](int /*kt: tiles are visited strictly in order*/) {
 #pragma unroll
     for (int a = 0; a < AP; ++a) {
-      uint32_t m = (uint32_t)(kt * BK + ps + PS * a);
       float4 v = f4zero();
-      if (rv && m < (uint32_t)p.M) {
-        uint32_t n = fd_div(m, p.fd_howo);
-        uint32_t rem = m - n * (uint32_t)(p.Ho * p.Wo);
-        uint32_t oh = fd_div(rem, p.fd_wo);
-        uint32_t ow = rem - oh * (uint32_t)p.Wo;
+      if (rv && sm[a] < (uint32_t)p.M) {
+        const int n = sn[a], oh = soh[a], ow = sow[a];
         if (p.adjoint) {
           // swapped roles: this K' pixel is an INPUT pixel; its row entries come from the 4-channel dy
-          v = adjoint_gather(p, p.a, (int)n * p.Ho, (int)oh, (int)ow, kh, kw, 0, 0);
+          float4 ex;
+          adjoint_gather(p, p.a, n * p.Ho, oh, ow, kh, kw, 0, 0, v, ex);
+          f4add(v, ex);
         } else {
-          int ih = (int)oh * p.stride - p.pad + kh, iw = (int)ow * p.stride - p.pad + kw;
+          int ih = oh * p.stride - p.pad + kh, iw = ow * p.stride - p.pad + kw;
           bool ok = true;
           if (p.reflect) {
             ih = reflect_idx(ih, p.Hl);
@@ -488,22 +522,24 @@ __global__ __launch_bounds__(256) void k_conv_wgrad(ConvP p) {
             ok = (ih >= 0) && (ih < p.Hl) && (iw >= 0) && (iw < p.Wl);
           }
           if (ok) {
-            size_t off = ((size_t)((int)n * p.H + ih * p.ups + ii) * p.W + (iw * p.ups + jj)) * p.Cin + c;
-            v = ldg4(p.a + off);
+            const uint32_t pix = (uint32_t)((n * p.H + ih * p.ups + ii) * p.W + (iw * p.ups + jj));
+            v = ldg4(p.a + (size_t)pix * p.Cin + c);
           }
         }
       }
       va[a] = v;
+      sm[a] += BK;
+      sow[a] += BK;
+      while (sow[a] >= p.Wo) { sow[a] -= p.Wo; ++soh[a]; }
+      while (soh[a] >= p.Ho) { soh[a] -= p.Ho; ++sn[a]; }
     }
 #pragma unroll
     for (int e = 0; e < BE; ++e) {
-      int idx = tid + 256 * e;
-      int pp = idx / (BN / 4), j4 = idx % (BN / 4);
-      uint32_t m = (uint32_t)(kt * BK + pp);
-      int co = n0 + j4 * 4;
       float4 v = f4zero();
-      if (m < (uint32_t)p.M && co < p.Cout) v = ldg4(p.b + (size_t)m * p.Cout + co);
+      if (bmrow[e] < (uint32_t)p.M && bcol[e]) v = ldg4(p.b + boff[e]);
       vb[e] = v;
+      bmrow[e] += BK;
+      boff[e] += bstep;
     }
   };
   auto store_tiles = [&]() {
@@ -917,17 +953,35 @@ extern "C" int vcg_conv_dgrad(const float* dy, const float* wf, float* dx, const
   return 0;
 }
 
+// Weight-gradient launch plan.  K' (pixels) is split over blockIdx.z; the split count is chosen with a
+// small cost model instead of "enough workgroups", because the workgroup count is quantised in rounds
+// of (256 CUs x resident workgroups): 792 workgroups on 512 slots cost two full rounds.  Costs in us:
+// one 32-pixel K' step of a resident workgroup, per tile shape (measured on the D/R/U layers), plus the
+// slab write+read at ~3 TB/s.
 static void wgrad_plan(const ConvGeom& g, int& bm, int& bn, int& nsplit, int& per, int& total) {
-  bn = g.Cout >= 128 ? 128 : 64;
-  bm = g.K >= 128 ? 128 : 64;
-  long long tiles = (long long)((g.K + bm - 1) / bm) * ((g.Cout + bn - 1) / bn);
   total = (g.M + BK - 1) / BK;
-  long long want = (768 + tiles - 1) / tiles;
-  long long maxs = total / 4; if (maxs < 1) maxs = 1;
-  if (want > maxs) want = maxs;
-  if (want < 1) want = 1;
-  per = (int)((total + want - 1) / want);
-  nsplit = (total + per - 1) / per;
+  struct Cand { int bm, bn, resident; double t_step; };
+  const Cand cands[3] = {{128, 128, 2, 5.6}, {128, 64, 3, 4.4}, {64, 64, 5, 3.4}};
+  double best = 1e30;
+  bm = 128; bn = 128; nsplit = 1; per = total;
+  for (int ci = 0; ci < 3; ++ci) {
+    const Cand& c = cands[ci];
+    if (c.bn == 128 && g.Cout <= 64) continue;
+    if (c.bm == 128 && g.K <= 64) continue;
+    const long long tiles = (long long)((g.K + c.bm - 1) / c.bm) * ((g.Cout + c.bn - 1) / c.bn);
+    const long long slots = 256LL * c.resident;
+    for (int ns = 1; ns <= 512; ++ns) {
+      int kt = (total + ns - 1) / ns;
+      if (kt < 4 && ns > 1) break;
+      int real_ns = (total + kt - 1) / kt;
+      long long wgs = tiles * real_ns;
+      long long rounds = (wgs + slots - 1) / slots;
+      // partially filled last round still runs at full per-workgroup speed, never faster
+      double t = rounds * kt * c.t_step;
+      if (real_ns > 1) t += (double)real_ns * g.K * g.Cout * 8.0 / 3.0e6;
+      if (t < best * 0.97) { best = t; bm = c.bm; bn = c.bn; nsplit = real_ns; per = kt; }
+    }
+  }
 }
 
 static const int kMaxDirectSlabs = 8;
