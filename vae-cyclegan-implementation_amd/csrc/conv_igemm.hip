@@ -76,6 +76,36 @@ __device__ __forceinline__ void flush_acc(f32x16 (&acc)[MI][NI], f32x16 (&tot)[M
     }
 }
 
+// One K-step tile (BK = 32 -> 16 MFMA steps) with the operand fragments software-pipelined: the LDS reads of
+// step s+1 are issued before the MFMAs of step s.  Left to itself hipcc places each step's ds_reads right in
+// front of its MFMAs behind an s_waitcnt lgkmcnt(0), exposing the LDS latency every 4 MFMAs (~60 % MFMA
+// utilisation measured with SQ_VALU_MFMA_BUSY_CYCLES); the double-buffered fragments cost MI+NI registers.
+template <int MI, int NI, class FA, class FB>
+__device__ __forceinline__ void mma_ktile(f32x16 (&acc)[MI][NI], FA ldA, FB ldB, int lh) {
+  float a[2][MI], b[2][NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i) a[0][i] = ldA(lh, i);
+#pragma unroll
+  for (int j = 0; j < NI; ++j) b[0][j] = ldB(lh, j);
+#pragma unroll
+  for (int ks = 0; ks < BK / 2; ++ks) {
+    const int cur = ks & 1, nxt = cur ^ 1;
+    if (ks + 1 < BK / 2) {
+#pragma unroll
+      for (int i = 0; i < MI; ++i) a[nxt][i] = ldA((ks + 1) * 2 + lh, i);
+#pragma unroll
+      for (int j = 0; j < NI; ++j) b[nxt][j] = ldB((ks + 1) * 2 + lh, j);
+    }
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NI; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][i], b[cur][j], acc[i][j], 0, 0, 0);
+    __builtin_amdgcn_sched_group_barrier(0x100, MI + NI, 0);   // the next step's LDS reads ...
+    __builtin_amdgcn_sched_group_barrier(0x008, MI * NI, 0);   // ... then this step's MFMAs
+  }
+}
+
 // chunk g (4 consecutive k) of the forward K axis -> (kh, kw, i, j, c)
 __device__ __forceinline__ void decode_tap(const ConvP& p, uint32_t g, int& kh, int& kw, int& ii, int& jj, int& c) {
   uint32_t tap = fd_div(g, p.fd_cin4);
@@ -229,20 +259,9 @@ __global__ __launch_bounds__(256, 2) void k_conv_fwd(ConvP p) {   // 2 waves/SIM
   __syncthreads();
   for (int kt = kt0; kt < nkt; ++kt) {
     if (kt + 1 < nkt) load_tiles(kt + 1);
-#pragma unroll
-    for (int ks = 0; ks < BK / 2; ++ks) {
-      const int kk = ks * 2 + lh;
-      float a[MI], b[NI];
-#pragma unroll
-      for (int i = 0; i < MI; ++i) a[i] = As[(wm * (BM / 2) + i * 32 + l31) * AS_STRIDE + kk];
-#pragma unroll
-      for (int j = 0; j < NI; ++j) b[j] = Bs[kk * BN + wn * (BN / 2) + j * 32 + l31];
-#pragma unroll
-      for (int i = 0; i < MI; ++i)
-#pragma unroll
-        for (int j = 0; j < NI; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
-    }
+    mma_ktile<MI, NI>(
+        acc, [&](int kk, int i) { return As[(wm * (BM / 2) + i * 32 + l31) * AS_STRIDE + kk]; },
+        [&](int kk, int j) { return Bs[kk * BN + wn * (BN / 2) + j * 32 + l31]; }, lh);
     if (((kt - kt0 + 1) & (FLUSH_TILES - 1)) == 0 && kt + 1 < nkt) flush_acc<MI, NI>(acc, tot);
     __syncthreads();
     if (kt + 1 < nkt) {
@@ -388,20 +407,9 @@ __global__ __launch_bounds__(256, 2) void k_conv_dgrad(ConvP p) {
   __syncthreads();
   for (int kt = kt0; kt < nkt; ++kt) {
     if (kt + 1 < nkt) load_tiles(kt + 1);
-#pragma unroll
-    for (int ks = 0; ks < BK / 2; ++ks) {
-      const int kk = ks * 2 + lh;
-      float a[MI], b[NI];
-#pragma unroll
-      for (int i = 0; i < MI; ++i) a[i] = As[(wm * (BM / 2) + i * 32 + l31) * AS_STRIDE + kk];
-#pragma unroll
-      for (int j = 0; j < NI; ++j) b[j] = Bt[(wn * (BN / 2) + j * 32 + l31) * AS_STRIDE + kk];
-#pragma unroll
-      for (int i = 0; i < MI; ++i)
-#pragma unroll
-        for (int j = 0; j < NI; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
-    }
+    mma_ktile<MI, NI>(
+        acc, [&](int kk, int i) { return As[(wm * (BM / 2) + i * 32 + l31) * AS_STRIDE + kk]; },
+        [&](int kk, int j) { return Bt[(wn * (BN / 2) + j * 32 + l31) * AS_STRIDE + kk]; }, lh);
     if (((kt - kt0 + 1) & (FLUSH_TILES - 1)) == 0 && kt + 1 < nkt) flush_acc<MI, NI>(acc, tot);
     __syncthreads();
     if (kt + 1 < nkt) {
@@ -561,20 +569,9 @@ __global__ __launch_bounds__(256) void k_conv_wgrad(ConvP p) {
   __syncthreads();
   for (int kt = kt_begin; kt < kt_end; ++kt) {
     if (kt + 1 < kt_end) load_tiles(kt + 1);
-#pragma unroll
-    for (int ks = 0; ks < BK / 2; ++ks) {
-      const int kk = ks * 2 + lh;
-      float a[MI], b[NI];
-#pragma unroll
-      for (int i = 0; i < MI; ++i) a[i] = Xs[kk * BM + wm * (BM / 2) + i * 32 + l31];
-#pragma unroll
-      for (int j = 0; j < NI; ++j) b[j] = Ds[kk * BN + wn * (BN / 2) + j * 32 + l31];
-#pragma unroll
-      for (int i = 0; i < MI; ++i)
-#pragma unroll
-        for (int j = 0; j < NI; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
-    }
+    mma_ktile<MI, NI>(
+        acc, [&](int kk, int i) { return Xs[kk * BM + wm * (BM / 2) + i * 32 + l31]; },
+        [&](int kk, int j) { return Ds[kk * BN + wn * (BN / 2) + j * 32 + l31]; }, lh);
     __syncthreads();
     if (kt + 1 < kt_end) {
       store_tiles();
@@ -744,13 +741,23 @@ __global__ __launch_bounds__(256) void k_colsum_partial(const float* __restrict_
     *reinterpret_cast<float4*>(part + (size_t)blockIdx.y * C + c4 * 4) = s;
   }
 }
-__global__ void k_colsum_final(const float* __restrict__ part, float* __restrict__ out, int C, int nchunk,
-                               int c_log) {
-  int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= c_log) return;
+// 32 channels x 8 chunk lanes per block: the loop over chunk partials is a dependent chain of L2 round
+// trips (it cost 150 us per launch as one thread per channel), so it is split 8 ways and combined in LDS
+// in a fixed order
+__global__ __launch_bounds__(256) void k_colsum_final(const float* __restrict__ part, float* __restrict__ out, int C,
+                                                      int nchunk, int c_log) {
+  __shared__ float red[8][32];
+  const int il = threadIdx.x & 31, kl = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + il;
   float s = 0.f;
-  for (int k = 0; k < nchunk; ++k) s += part[(size_t)k * C + c];
-  out[c] += s;
+  if (c < c_log)
+    for (int k = kl; k < nchunk; k += 8) s += part[(size_t)k * C + c];
+  red[kl][il] = s;
+  __syncthreads();
+  if (kl == 0 && c < c_log) {
+    for (int k = 1; k < 8; ++k) s += red[k][il];
+    out[c] += s;
+  }
 }
 
 // ------------------------------------------------------------------ host side
@@ -961,7 +968,8 @@ extern "C" int vcg_conv_dgrad(const float* dy, const float* wf, float* dx, const
 static void wgrad_plan(const ConvGeom& g, int& bm, int& bn, int& nsplit, int& per, int& total) {
   total = (g.M + BK - 1) / BK;
   struct Cand { int bm, bn, resident; double t_step; };
-  const Cand cands[3] = {{128, 128, 2, 5.6}, {128, 64, 3, 4.4}, {64, 64, 5, 3.4}};
+  // t_step from measured rates: 128x128 ~105 TF, 128x64 ~85 TF, 64x64 ~70 TF at full residency
+  const Cand cands[3] = {{128, 128, 2, 5.1}, {128, 64, 3, 4.7}, {64, 64, 5, 4.8}};
   double best = 1e30;
   bm = 128; bn = 128; nsplit = 1; per = total;
   for (int ci = 0; ci < 3; ++ci) {
@@ -993,7 +1001,7 @@ static void colsum_plan(const ConvGeom& g, int& tc, int& cgroups, int& rows, int
   while (tc * 2 <= c4 && tc * 2 <= 256) tc *= 2;
   cgroups = (c4 + tc - 1) / tc;
   int tp = 256 / tc;
-  long long want = 1024 / cgroups;
+  long long want = 512 / cgroups;
   if (want < 1) want = 1;
   long long r = (g.M + want - 1) / want;
   if (r < 4LL * tp) r = 4LL * tp;
@@ -1088,7 +1096,7 @@ extern "C" int vcg_conv_wgrad(const float* x, const float* dy, float* gw_oihw, f
     int tc, cgroups, rows, nchunk;
     colsum_plan(gorig, tc, cgroups, rows, nchunk);
     hipLaunchKernelGGL(k_colsum_partial, dim3(cgroups, nchunk), dim3(256), 0, st, dy, part, gorig.M, gorig.Cout, rows, tc);
-    hipLaunchKernelGGL(k_colsum_final, dim3((gorig.cout_log + 63) / 64), dim3(64), 0, st, (const float*)part, gbias,
+    hipLaunchKernelGGL(k_colsum_final, dim3((gorig.cout_log + 31) / 32), dim3(256), 0, st, (const float*)part, gbias,
                        gorig.Cout, nchunk, gorig.cout_log);
     VCG_LAUNCH_CHECK("vcg_conv_wgrad(bias)");
   }
