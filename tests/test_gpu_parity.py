@@ -155,6 +155,8 @@ ORACLE_CONV_CASES = [
     ("CaSb", (64, 128, 4), {"stride": 2, "padding": 1, "activation": "LeakyReLU"}, (2, 64, 16, 24)),
     ("CaSb", (3, 64, 4), {"stride": 2, "padding": 1, "activation": "LeakyReLU", "use_norm": False}, (2, 3, 32, 32)),
     ("S", (8, 8), {}, (1, 8, 2, 2)),                  # smallest legal map for reflect pad 1
+    ("S", (8, 8), {}, (2, 8, 3, 3)),                  # 3x3 with pad 1: the centre pixel has a top AND a bottom mirror
+    ("R", (16,), {}, (1, 16, 3, 5)),
     ("D", (8, 8), {}, (3, 8, 4, 4)),                  # bottleneck of a 64x64 input: 2x2 output maps
 ]
 

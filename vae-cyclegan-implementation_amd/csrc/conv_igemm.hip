@@ -45,6 +45,8 @@ struct ConvP {
   // wgrad with swapped roles (thin Cout): rows are gathered from dy through the adjoint of the padding
   int adjoint;
   int src_pitch;   // channel pitch of the tensor adjoint_gather reads (dy)
+  uint32_t a_bytes, b_bytes;   // extents of a / b for the bounds-checked buffer loads (< 2 GiB each)
+  int dbl_mirror;              // dgrad: some pixel has BOTH a top and a bottom (or left and right) mirror
 };
 
 #define BK 32
@@ -106,6 +108,19 @@ __device__ __forceinline__ void mma_ktile(f32x16 (&acc)[MI][NI], FA ldA, FB ldB,
   }
 }
 
+// Bounds-checked 16-byte load through a buffer descriptor (SRD): a 32-bit byte offset per lane, and an
+// offset >= num_records returns zeros — so rows past M, K-tail columns and zero-padding taps need no
+// predication, no zero-initialised staging registers and no 64-bit address arithmetic.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+#define VCG_OOB 0x80000000u   // > any tensor we accept (host checks extents < 2 GiB)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_srd(const float* ptr, uint32_t bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc((void*)ptr, 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ float4 bload4(__amdgpu_buffer_rsrc_t r, uint32_t off) {
+  u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0);
+  return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+
 // chunk g (4 consecutive k) of the forward K axis -> (kh, kw, i, j, c)
 __device__ __forceinline__ void decode_tap(const ConvP& p, uint32_t g, int& kh, int& kw, int& ii, int& jj, int& c) {
   uint32_t tap = fd_div(g, p.fd_cin4);
@@ -161,6 +176,15 @@ __device__ __forceinline__ void adjoint_gather(const ConvP& p, const float* __re
   }
 }
 
+// fold sources only (everything adjoint_gather puts into `extra`); used when the main source is fetched by a
+// bounds-checked buffer load
+__device__ __forceinline__ float4 adjoint_extras(const ConvP& p, const float* __restrict__ src, int nHo, int h, int w,
+                                                 int kh, int kw, int co, int sshift) {
+  float4 m, e;
+  adjoint_gather(p, src, nHo, h, w, kh, kw, co, sshift, m, e);
+  return e;
+}
+
 // ------------------------------------------------------------------ forward
 template <int BM, int BN>
 __global__ __launch_bounds__(256, 2) void k_conv_fwd(ConvP p) {   // 2 waves/SIMD: acc + tot must fit 256 regs
@@ -172,6 +196,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_fwd(ConvP p) {   // 2 waves/SIM
   const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
   const int a_row = tid >> 3, a_u = tid & 7;
 
+  const __amdgpu_buffer_rsrc_t ra = make_srd(p.a, p.a_bytes), rb = make_srd(p.b, p.b_bytes);
   int pnH[AR], boh[AR], bow[AR];
   bool pv[AR];
 #pragma unroll
@@ -197,39 +222,61 @@ __global__ __launch_bounds__(256, 2) void k_conv_fwd(ConvP p) {   // 2 waves/SIM
 
   float4 va[AR], vb[BE];
   int nkt = (p.K + BK - 1) / BK;
+  int kt0 = 0;
+  if (p.ksplit > 1) {
+    kt0 = (int)blockIdx.z * p.kt_per;
+    int kt1 = kt0 + p.kt_per;
+    nkt = kt1 < nkt ? kt1 : nkt;
+  }
+
+  // byte offsets of this thread's rows for the CURRENT tap; recomputed only when the tap changes (every
+  // Cin/32 K-steps), so a steady-state K-step costs one add per row instead of the reflect arithmetic
+  uint32_t rowoff[AR];
+  int tap_cur = -1;
+  // weight tile: this thread's float4 slots walk down K by 32 rows per step
+  uint32_t boff[BE];
+#pragma unroll
+  for (int e = 0; e < BE; ++e) {
+    int idx = tid + 256 * e;
+    int kk = idx / (BN / 4), j4 = idx % (BN / 4);
+    int co = n0 + j4 * 4;
+    boff[e] = co < p.Cout ? (uint32_t)(((kt0 * BK + kk) * p.Cout + co) * 4) : VCG_OOB;
+  }
+  const uint32_t bstep = (uint32_t)(BK * p.Cout * 4);
 
   auto load_tiles = [&](int kt) {
-    uint32_t g = (uint32_t)(kt * 8 + a_u);
-    bool kv = (int)(g * 4) < p.K;
-    int kh, kw, ii, jj, c;
-    decode_tap(p, g, kh, kw, ii, jj, c);
+    const uint32_t g = (uint32_t)(kt * 8 + a_u);
+    const bool kv = (int)(g * 4) < p.K;
+    uint32_t tap = fd_div(g, p.fd_cin4);
+    const int c = (int)(g - tap * (uint32_t)p.cin4) * 4;
+    if ((int)tap != tap_cur) {
+      tap_cur = (int)tap;
+      int ii = 0, jj = 0;
+      if (p.ups == 2) { jj = tap & 1; ii = (tap >> 1) & 1; tap >>= 2; }
+      const uint32_t q = fd_div(tap, p.fd_kw);
+      const int kh = (int)q, kw = (int)(tap - q * (uint32_t)p.KW);
 #pragma unroll
-    for (int r = 0; r < AR; ++r) {
-      float4 v = f4zero();
-      if (pv[r] && kv) {
+      for (int r = 0; r < AR; ++r) {
         int ih = boh[r] + kh, iw = bow[r] + kw;
-        bool ok = true;
+        bool ok = pv[r];
         if (p.reflect) {
           ih = reflect_idx(ih, p.Hl);
           iw = reflect_idx(iw, p.Wl);
         } else {
-          ok = (ih >= 0) && (ih < p.Hl) && (iw >= 0) && (iw < p.Wl);
+          ok = ok && (ih >= 0) && (ih < p.Hl) && (iw >= 0) && (iw < p.Wl);
         }
-        if (ok) {
-          size_t off = ((size_t)(pnH[r] + ih * p.ups + ii) * p.W + (iw * p.ups + jj)) * p.Cin + c;
-          v = ldg4(p.a + off);
-        }
+        rowoff[r] = ok ? (uint32_t)(((pnH[r] + ih * p.ups + ii) * p.W + (iw * p.ups + jj)) * p.Cin) * 4u : VCG_OOB;
       }
-      va[r] = v;
+    }
+#pragma unroll
+    for (int r = 0; r < AR; ++r) {
+      const uint32_t off = (kv && rowoff[r] != VCG_OOB) ? rowoff[r] + (uint32_t)c * 4u : VCG_OOB;
+      va[r] = bload4(ra, off);
     }
 #pragma unroll
     for (int e = 0; e < BE; ++e) {
-      int idx = tid + 256 * e;
-      int kk = idx / (BN / 4), j4 = idx % (BN / 4);
-      int kg = kt * BK + kk, co = n0 + j4 * 4;
-      float4 v = f4zero();
-      if (kg < p.K && co < p.Cout) v = ldg4(p.b + (size_t)kg * p.Cout + co);
-      vb[e] = v;
+      vb[e] = bload4(rb, boff[e]);
+      if (boff[e] != VCG_OOB) boff[e] += bstep;
     }
   };
   auto store_tiles = [&]() {
@@ -246,12 +293,6 @@ __global__ __launch_bounds__(256, 2) void k_conv_fwd(ConvP p) {   // 2 waves/SIM
     }
   };
 
-  int kt0 = 0;
-  if (p.ksplit > 1) {
-    kt0 = (int)blockIdx.z * p.kt_per;
-    int kt1 = kt0 + p.kt_per;
-    nkt = kt1 < nkt ? kt1 : nkt;
-  }
   if (kt0 < nkt) {
     load_tiles(kt0);
     store_tiles();
@@ -365,33 +406,85 @@ __global__ __launch_bounds__(256, 2) void k_conv_dgrad(ConvP p) {
     nkt = kt1 < nkt ? kt1 : nkt;
   }
 
+  // Bounds-checked buffer loads + per-tap row offsets (see k_conv_fwd).  A pixel within `pad` of a border
+  // (but not on it) also receives the contributions that reflect padding folded onto it: one mirrored row
+  // coordinate eh and/or one mirrored column coordinate ew, i.e. up to three extra sources per tap, whose
+  // offsets are likewise computed once per tap.
+  const __amdgpu_buffer_rsrc_t ra = make_srd(p.a, p.a_bytes), rb = make_srd(p.b, p.b_bytes);
+  const int NONE = -(1 << 20);
+  int eh[AR], ew[AR];
+  bool edge[AR], any_edge = false;
+#pragma unroll
+  for (int r = 0; r < AR; ++r) {
+    const int h = ph[r], w = pw[r];
+    eh[r] = (h >= 1 && h <= p.pad) ? -h : (h >= p.Hl - 1 - p.pad && h <= p.Hl - 2) ? 2 * (p.Hl - 1) - h : NONE;
+    ew[r] = (w >= 1 && w <= p.pad) ? -w : (w >= p.Wl - 1 - p.pad && w <= p.Wl - 2) ? 2 * (p.Wl - 1) - w : NONE;
+    edge[r] = pv[r] && p.reflect && (eh[r] != NONE || ew[r] != NONE);
+    any_edge = any_edge || edge[r];
+    ve[r] = f4zero();
+  }
+  uint32_t rowoff[AR], xoff[AR][3], wbase[BR];
+  int tap_cur = -1;
+
   auto load_tiles = [&](int kt) {
-    uint32_t g = (uint32_t)(kt * 8 + a_u);
-    bool kv = (int)(g * 4) < Kc;
-    uint32_t tapc = fd_div(g, p.fd_cout4);
-    int co = (int)(g - tapc * (uint32_t)p.cout4) * 4;
-    int u = (int)tapc / nKW, v_ = (int)tapc % nKW;
-    int kh = kh0 + u * s, kw = kw0 + v_ * s;
+    const uint32_t g = (uint32_t)(kt * 8 + a_u);
+    const bool kv = (int)(g * 4) < Kc;
+    const uint32_t tapc = fd_div(g, p.fd_cout4);
+    const int co = (int)(g - tapc * (uint32_t)p.cout4) * 4;
+    if ((int)tapc != tap_cur) {
+      tap_cur = (int)tapc;
+      const int u = (int)tapc / nKW, v_ = (int)tapc % nKW;
+      const int kh = kh0 + u * s, kw = kw0 + v_ * s;
+      auto src = [&](int r, int qh, int qw) -> uint32_t {      // dy offset of the output pixel whose tap hits (qh, qw)
+        const int numh = qh - kh + p.pad, numw = qw - kw + p.pad;
+        const int oh = numh >> sshift, ow = numw >> sshift;
+        const bool ok = pv[r] && qh != NONE && qw != NONE && numh >= 0 && oh < p.Ho && numw >= 0 && ow < p.Wo;
+        return ok ? (uint32_t)(((pnHo[r] + oh) * p.Wo + ow) * p.Cout) * 4u : VCG_OOB;
+      };
 #pragma unroll
-    for (int r = 0; r < AR; ++r) {
-      va[r] = f4zero();
-      ve[r] = f4zero();
-      if (pv[r] && kv) adjoint_gather(p, p.a, pnHo[r], ph[r], pw[r], kh, kw, co, sshift, va[r], ve[r]);
-    }
-    const int tapfull = kh * p.KW + kw;
+      for (int r = 0; r < AR; ++r) {
+        rowoff[r] = src(r, ph[r], pw[r]);
+        if (any_edge) {
+          xoff[r][0] = edge[r] ? src(r, eh[r], pw[r]) : VCG_OOB;
+          xoff[r][1] = edge[r] ? src(r, ph[r], ew[r]) : VCG_OOB;
+          xoff[r][2] = edge[r] ? src(r, eh[r], ew[r]) : VCG_OOB;
+        }
+      }
+      const int tapfull = kh * p.KW + kw;
 #pragma unroll
-    for (int r = 0; r < BR; ++r) {
-      int J = n0 + a_row + 32 * r;
-      float4 v = f4zero();
-      if (kv && J < p.NB) v = ldg4(p.b + ((size_t)tapfull * p.NB + J) * p.Cout + co);
-      vb[r] = v;
+      for (int r = 0; r < BR; ++r) {
+        const int J = n0 + a_row + 32 * r;
+        wbase[r] = J < p.NB ? (uint32_t)((tapfull * p.NB + J) * p.Cout) * 4u : VCG_OOB;
+      }
     }
+    const uint32_t cb4 = (uint32_t)co * 4u;
+#pragma unroll
+    for (int r = 0; r < AR; ++r) va[r] = bload4(ra, (kv && rowoff[r] != VCG_OOB) ? rowoff[r] + cb4 : VCG_OOB);
+    if (p.dbl_mirror) {                      // tiny maps (e.g. 3x3 with pad 1): general 3x3 candidate search
+      const int u = tap_cur / nKW, v_ = tap_cur % nKW;
+#pragma unroll
+      for (int r = 0; r < AR; ++r)
+        ve[r] = (pv[r] && kv) ? adjoint_extras(p, p.a, pnHo[r], ph[r], pw[r], kh0 + u * s, kw0 + v_ * s, co, sshift) : f4zero();
+    } else if (any_edge) {
+#pragma unroll
+      for (int r = 0; r < AR; ++r) {
+        float4 e = f4zero();
+        if (edge[r] && kv) {
+#pragma unroll
+          for (int k = 0; k < 3; ++k)
+            if (xoff[r][k] != VCG_OOB) f4add(e, bload4(ra, xoff[r][k] + cb4));
+        }
+        ve[r] = e;
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < BR; ++r) vb[r] = bload4(rb, (kv && wbase[r] != VCG_OOB) ? wbase[r] + cb4 : VCG_OOB);
   };
   auto store_tiles = [&]() {
 #pragma unroll
     for (int r = 0; r < AR; ++r) {
       float* d = &As[(a_row + 32 * r) * AS_STRIDE + a_u * 4];
-      d[0] = va[r].x + ve[r].x; d[1] = va[r].y + ve[r].y; d[2] = va[r].z + ve[r].z; d[3] = va[r].w + ve[r].w;
+      d[0] = va[r].x + ve[r].x; d[1] = va[r].y + ve[r].y; d[2] = va[r].z + ve[r].z; d[3] = va[r].w + ve[r].w;   // ve == 0 off the edges
     }
 #pragma unroll
     for (int r = 0; r < BR; ++r) {
@@ -496,58 +589,77 @@ __global__ __launch_bounds__(256) void k_conv_wgrad(ConvP p) {
     uint32_t oh = fd_div(rem, p.fd_wo);
     sm[a] = m; sn[a] = (int)n; soh[a] = (int)oh; sow[a] = (int)(rem - oh * (uint32_t)p.Wo);
   }
-  uint32_t bmrow[BE];
-  size_t boff[BE];
-  bool bcol[BE];
+  const __amdgpu_buffer_rsrc_t ra = make_srd(p.a, p.a_bytes), rb = make_srd(p.b, p.b_bytes);
+  uint32_t boff[BE];
 #pragma unroll
   for (int e = 0; e < BE; ++e) {
     int idx = tid + 256 * e;
     int pp = idx / (BN / 4), j4 = idx % (BN / 4);
-    bmrow[e] = (uint32_t)(kt_begin * BK + pp);
-    bcol[e] = n0 + j4 * 4 < p.Cout;
-    boff[e] = (size_t)bmrow[e] * p.Cout + n0 + j4 * 4;
+    const int co = n0 + j4 * 4;
+    // rows past M fall off the end of the buffer (b_bytes = M * Cout * 4) and read as zeros
+    boff[e] = co < p.Cout ? (uint32_t)(((kt_begin * BK + pp) * p.Cout + co) * 4) : VCG_OOB;
   }
-  const size_t bstep = (size_t)BK * p.Cout;
+  const uint32_t bstep = (uint32_t)(BK * p.Cout * 4);
+
+  // When Wo % 32 == 0 the 32 pixels of a K' step lie in one image row: (n, oh) and the row part of the
+  // reflect/address arithmetic are shared by the thread's AP slots.
+  const bool row_aligned = !p.adjoint && (p.Wo % BK) == 0;
 
   auto load_tiles = [&](int /*kt: tiles are visited strictly in order*/) {
+    if (row_aligned) {
+      const int n = sn[0], oh = soh[0];
+      int ih = oh * p.stride - p.pad + kh;
+      bool okr = rv && sm[0] < (uint32_t)p.M;            // M % 32 == 0 here, so all slots agree
+      if (p.reflect) ih = reflect_idx(ih, p.Hl);
+      else okr = okr && ih >= 0 && ih < p.Hl;
+      const uint32_t rowbase = (uint32_t)(((n * p.H + ih * p.ups + ii) * p.W + jj) * p.Cin + c) * 4u;
+      const uint32_t colstep = (uint32_t)(p.ups * p.Cin) * 4u;
 #pragma unroll
-    for (int a = 0; a < AP; ++a) {
-      float4 v = f4zero();
-      if (rv && sm[a] < (uint32_t)p.M) {
+      for (int a = 0; a < AP; ++a) {
+        int iw = sow[a] * p.stride - p.pad + kw;
+        bool ok = okr;
+        if (p.reflect) iw = reflect_idx(iw, p.Wl);
+        else ok = ok && iw >= 0 && iw < p.Wl;
+        va[a] = bload4(ra, ok ? rowbase + (uint32_t)iw * colstep : VCG_OOB);
+        sm[a] += BK;
+        sow[a] += BK;
+        if (sow[a] >= p.Wo) { sow[a] -= p.Wo; ++soh[a]; if (soh[a] >= p.Ho) { soh[a] = 0; ++sn[a]; } }
+      }
+    } else {
+#pragma unroll
+      for (int a = 0; a < AP; ++a) {
         const int n = sn[a], oh = soh[a], ow = sow[a];
         if (p.adjoint) {
           // swapped roles: this K' pixel is an INPUT pixel; its row entries come from the 4-channel dy
-          float4 ex;
-          adjoint_gather(p, p.a, n * p.Ho, oh, ow, kh, kw, 0, 0, v, ex);
-          f4add(v, ex);
+          float4 v = f4zero();
+          if (rv && sm[a] < (uint32_t)p.M) {
+            float4 ex;
+            adjoint_gather(p, p.a, n * p.Ho, oh, ow, kh, kw, 0, 0, v, ex);
+            f4add(v, ex);
+          }
+          va[a] = v;
         } else {
           int ih = oh * p.stride - p.pad + kh, iw = ow * p.stride - p.pad + kw;
-          bool ok = true;
+          bool ok = rv && sm[a] < (uint32_t)p.M;
           if (p.reflect) {
             ih = reflect_idx(ih, p.Hl);
             iw = reflect_idx(iw, p.Wl);
           } else {
-            ok = (ih >= 0) && (ih < p.Hl) && (iw >= 0) && (iw < p.Wl);
+            ok = ok && (ih >= 0) && (ih < p.Hl) && (iw >= 0) && (iw < p.Wl);
           }
-          if (ok) {
-            const uint32_t pix = (uint32_t)((n * p.H + ih * p.ups + ii) * p.W + (iw * p.ups + jj));
-            v = ldg4(p.a + (size_t)pix * p.Cin + c);
-          }
+          const uint32_t off = ok ? (uint32_t)(((n * p.H + ih * p.ups + ii) * p.W + (iw * p.ups + jj)) * p.Cin + c) * 4u : VCG_OOB;
+          va[a] = bload4(ra, off);
         }
+        sm[a] += BK;
+        sow[a] += BK;
+        while (sow[a] >= p.Wo) { sow[a] -= p.Wo; ++soh[a]; }
+        while (soh[a] >= p.Ho) { soh[a] -= p.Ho; ++sn[a]; }
       }
-      va[a] = v;
-      sm[a] += BK;
-      sow[a] += BK;
-      while (sow[a] >= p.Wo) { sow[a] -= p.Wo; ++soh[a]; }
-      while (soh[a] >= p.Ho) { soh[a] -= p.Ho; ++sn[a]; }
     }
 #pragma unroll
     for (int e = 0; e < BE; ++e) {
-      float4 v = f4zero();
-      if (bmrow[e] < (uint32_t)p.M && bcol[e]) v = ldg4(p.b + boff[e]);
-      vb[e] = v;
-      bmrow[e] += BK;
-      boff[e] += bstep;
+      vb[e] = bload4(rb, boff[e]);
+      if (boff[e] != VCG_OOB) boff[e] += bstep;
     }
   };
   auto store_tiles = [&]() {
@@ -811,6 +923,7 @@ static void fill_params(const ConvGeom& g, ConvP& p) {
   p.fd_hcwc = make_fastdiv(1); p.fd_wc = make_fastdiv(1);
   p.ktiles_per_split = p.ktiles_total = 0;
   p.ksplit = 1; p.kt_per = 0; p.slab = nullptr; p.adjoint = 0; p.src_pitch = g.Cout;
+  p.a_bytes = p.b_bytes = 0; p.dbl_mirror = 0;
   p.bias = nullptr;
 }
 
@@ -820,33 +933,29 @@ static void fill_params(const ConvGeom& g, ConvP& p) {
 // k_splitk_finish sums in a fixed order (+ bias + activation).
 static void gemm_plan(long long rows, long long cols, int nkt, bool allow_split, int& bm, int& bn, int& nsplit,
                       int& kt_per) {
-  const int cand[3][2] = {{128, 128}, {128, 64}, {64, 128}};
-  nsplit = 1;
-  kt_per = nkt;
-  for (int i = 0; i < 3; ++i) {
-    int m = cand[i][0], n = cand[i][1];
-    if (cols <= 64 && n == 128) continue;
-    if (rows <= 64 && m == 128) continue;
-    long long wgs = ((rows + m - 1) / m) * ((cols + n - 1) / n);
-    if (wgs >= 512) { bm = m; bn = n; return; }
-  }
-  // too few output tiles: slice K under the big tile (measured: 128x128 + 4 slices beats 64x64 tiles on the
-  // 1024->1024 convs at 16x16), unless K is too short to slice
-  if (allow_split) {
-    int m = rows > 64 ? 128 : 64, n = cols > 64 ? 128 : 64;
-    long long tiles = ((rows + m - 1) / m) * ((cols + n - 1) / n);
-    long long want = (512 + tiles - 1) / tiles;
-    long long maxs = nkt / 8;
-    if (want > maxs) want = maxs;
-    if (want > 32) want = 32;
-    if (want >= 2) {
-      bm = m; bn = n;
-      kt_per = (int)((nkt + want - 1) / want);
-      nsplit = (nkt + kt_per - 1) / kt_per;
-      return;
+  // cost model (us): rounds of resident workgroups x K-steps per workgroup x time per K-step of that tile,
+  // plus the slab write+read of a K-sliced launch.  Same constants as wgrad_plan.
+  struct Cand { int bm, bn, resident; double t_step; };
+  const Cand cands[4] = {{128, 128, 2, 5.1}, {128, 64, 3, 4.7}, {64, 128, 3, 4.7}, {64, 64, 4, 4.8}};
+  double best = 1e30;
+  bm = 64; bn = 64; nsplit = 1; kt_per = nkt;
+  for (int ci = 0; ci < 4; ++ci) {
+    const Cand& c = cands[ci];
+    if (c.bn == 128 && cols <= 64) continue;
+    if (c.bm == 128 && rows <= 64) continue;
+    const long long tiles = ((rows + c.bm - 1) / c.bm) * ((cols + c.bn - 1) / c.bn);
+    const long long slots = 256LL * c.resident;
+    const int max_ns = allow_split ? 32 : 1;
+    for (int ns = 1; ns <= max_ns; ++ns) {
+      int kt = (nkt + ns - 1) / ns;
+      if (ns > 1 && kt < 8) break;
+      int real_ns = (nkt + kt - 1) / kt;
+      long long rounds = (tiles * real_ns + slots - 1) / slots;
+      double t = rounds * kt * c.t_step;
+      if (real_ns > 1) t += (double)real_ns * rows * cols * 8.0 / 3.0e6 + 3.0;   // + one more launch
+      if (t < best * 0.97) { best = t; bm = c.bm; bn = c.bn; nsplit = real_ns; kt_per = kt; }
     }
   }
-  bm = 64; bn = 64;
 }
 
 #define DISPATCH_TILE(KERNEL, bm, bn, grid, stream, p)                                        \
@@ -896,6 +1005,11 @@ extern "C" int vcg_conv_fwd(const float* x, const float* wf, const float* bias, 
   if (vcg_thin_fwd_ok(g)) return vcg_thin_fwd(g, x, wf, bias, y, (hipStream_t)stream);
   ConvP p; fill_params(g, p);
   p.a = x; p.b = wf; p.bias = bias; p.out = y;
+  {
+    const unsigned long long ab = (unsigned long long)g.N * g.H * g.W * g.Cin * 4, bb = (unsigned long long)g.K * g.Cout * 4;
+    VCG_CHECK_ARG(ab < (1ull << 31) && bb < (1ull << 31), "vcg_conv_fwd: tensor extents must stay below 2 GiB");
+    p.a_bytes = (uint32_t)ab; p.b_bytes = (uint32_t)bb;
+  }
   int bm, bn, nsplit, kt_per;
   fwd_plan(g, bm, bn, nsplit, kt_per);
   if (nsplit > 1) {
@@ -943,6 +1057,15 @@ extern "C" int vcg_conv_dgrad(const float* dy, const float* wf, float* dx, const
   if (vcg_thin_dgrad_ok(g)) return vcg_thin_dgrad(g, dy, wf, dx, ws, ws_bytes, (hipStream_t)stream);
   ConvP p; fill_params(g, p);
   p.a = dy; p.b = wf; p.out = dx;
+  {
+    const unsigned long long ab = (unsigned long long)g.M * g.Cout * 4, bb = (unsigned long long)g.K * g.Cout * 4;
+    VCG_CHECK_ARG(ab < (1ull << 31) && bb < (1ull << 31), "vcg_conv_dgrad: tensor extents must stay below 2 GiB");
+    p.a_bytes = (uint32_t)ab; p.b_bytes = (uint32_t)bb;
+  }
+  {
+    auto dbl = [&](int L) { int lo = 1 > L - 1 - g.pad ? 1 : L - 1 - g.pad, hi = g.pad < L - 2 ? g.pad : L - 2; return lo <= hi; };
+    p.dbl_mirror = g.reflect && (dbl(g.Hl) || dbl(g.Wl));
+  }
   int bm, bn, nsplit, kt_per;
   dgrad_setup(g, p, bm, bn, nsplit, kt_per);
   if (nsplit > 1) {
@@ -1055,6 +1178,13 @@ extern "C" int vcg_conv_wgrad(const float* x, const float* dy, float* gw_oihw, f
   wgrad_plan(g, bm, bn, nsplit, per, total);
   p.a = x; p.b = dy; p.out = (float*)ws;
   if (swapped) { p.a = dy; p.b = x; p.adjoint = 1; p.src_pitch = 4; }
+  {
+    // a: the gathered side (x; dy in swapped mode), b: the plain [K' pixel][Cout] side
+    const unsigned long long ab = swapped ? (unsigned long long)gorig.M * 4 * 4 : (unsigned long long)g.N * g.H * g.W * g.Cin * 4;
+    const unsigned long long bb = (unsigned long long)g.M * g.Cout * 4;
+    VCG_CHECK_ARG(ab < (1ull << 31) && bb < (1ull << 31), "vcg_conv_wgrad: tensor extents must stay below 2 GiB");
+    p.a_bytes = (uint32_t)ab; p.b_bytes = (uint32_t)bb;
+  }
   p.ktiles_per_split = per; p.ktiles_total = total;
   dim3 grid((g.K + bm - 1) / bm, (g.Cout + bn - 1) / bn, nsplit);
   hipStream_t st = (hipStream_t)stream;
