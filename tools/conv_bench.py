@@ -13,6 +13,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 pkg = importlib.import_module("vae-cyclegan-implementation_amd")
 ops = pkg.ops
+if os.environ.get("VCG_LIBRARY"):            # A/B runs: bind another build of the library (e.g. tools/_build/libvcg_base.so)
+    pkg._native.LIB_PATH = os.path.abspath(os.environ["VCG_LIBRARY"])
 
 # name: (cin_logical, cout, k, stride, pad, ups, H_in_physical, C_in_physical)
 LAYERS = {

@@ -24,6 +24,7 @@
 //             blockIdx.z into fp32 slabs that a second kernel sums in a fixed order
 //             (bitwise reproducible, no float atomics) and scatters to OIHW.
 #include "vcg_common.h"
+#include <stdlib.h>
 
 struct ConvP {
   const float* a;
@@ -47,10 +48,34 @@ struct ConvP {
   int src_pitch;   // channel pitch of the tensor adjoint_gather reads (dy)
   uint32_t a_bytes, b_bytes;   // extents of a / b for the bounds-checked buffer loads (< 2 GiB each)
   int dbl_mirror;              // dgrad: some pixel has BOTH a top and a bottom (or left and right) mirror
+  int dbg;                     // diagnostic builds only (VCG_STAMP): knock out parts of the main loop, timing experiments
 };
 
 #define BK 32
 #define AS_STRIDE 33
+
+// Diagnostic build only (tools/stamp_probe.py compiles a private copy with -DVCG_STAMP; libvcg.so never has it):
+// per-workgroup wall-clock (100 MHz) and shader-clock stamps into a buffer of their own, so that launch skew,
+// workgroup duration spread and the clock the chip holds can be read off (MI355X_MICROARCH.md, DVFS item 6).
+#ifdef VCG_STAMP
+__device__ unsigned long long* g_vcg_stamp = nullptr;
+extern "C" int vcg_debug_set_stamp(void* buf) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_vcg_stamp), &buf, sizeof(buf)) == hipSuccess ? 0 : -1;
+}
+#define VCG_STAMP_AT(slot)                                                                                   \
+  do {                                                                                                       \
+    if (g_vcg_stamp && threadIdx.x == 0) {                                                                   \
+      unsigned long long* s__ = g_vcg_stamp + 8ull * (blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)); \
+      s__[slot] = __builtin_amdgcn_s_memrealtime();                                                          \
+      if (slot == 0) { s__[4] = __builtin_amdgcn_s_memtime(); s__[6] = __builtin_amdgcn_s_getreg(63492); s__[7] = __builtin_amdgcn_s_getreg(63508); } \
+      if (slot == 3) s__[5] = __builtin_amdgcn_s_memtime();                                                  \
+    }                                                                                                        \
+  } while (0)
+#define VCG_DBG(bit) (p.dbg & (bit))
+#else
+#define VCG_STAMP_AT(slot) do { } while (0)
+#define VCG_DBG(bit) false
+#endif
 
 __device__ __forceinline__ float4 ldg4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
@@ -68,6 +93,7 @@ __device__ __forceinline__ void f4add(float4& a, const float4& b) {
 
 template <int MI, int NI>
 __device__ __forceinline__ void flush_acc(f32x16 (&acc)[MI][NI], f32x16 (&tot)[MI][NI]) {
+  asm volatile("" ::: "memory");   // keeps this a real (rare) branch: if-converted it is 96 VALU ops in EVERY K-step
 #pragma unroll
   for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -82,8 +108,16 @@ __device__ __forceinline__ void flush_acc(f32x16 (&acc)[MI][NI], f32x16 (&tot)[M
 // step s+1 are issued before the MFMAs of step s.  Left to itself hipcc places each step's ds_reads right in
 // front of its MFMAs behind an s_waitcnt lgkmcnt(0), exposing the LDS latency every 4 MFMAs (~60 % MFMA
 // utilisation measured with SQ_VALU_MFMA_BUSY_CYCLES); the double-buffered fragments cost MI+NI registers.
-template <int MI, int NI, class FA, class FB>
-__device__ __forceinline__ void mma_ktile(f32x16 (&acc)[MI][NI], FA ldA, FB ldB, int lh) {
+//
+// `extra(ks)` (optional) is caller work to place after MFMA step ks, pinned there by a sched_barrier when FENCE.
+// Spreading the staging (LDS writes in the first steps, buffer loads in the last ones) over the MFMA shadows this
+// way was measured on k_conv_fwd: the two co-resident workgroups then finish together, but the launch takes the
+// same time ("what did not pay"), so the kernels keep the simpler load / multiply / store phases.
+struct NoExtra {
+  __device__ __forceinline__ void operator()(int) const {}
+};
+template <int MI, int NI, bool FENCE = false, class FA, class FB, class FX = NoExtra>
+__device__ __forceinline__ void mma_ktile(f32x16 (&acc)[MI][NI], FA ldA, FB ldB, int lh, FX extra = FX()) {
   float a[2][MI], b[2][NI];
 #pragma unroll
   for (int i = 0; i < MI; ++i) a[0][i] = ldA(lh, i);
@@ -103,8 +137,10 @@ __device__ __forceinline__ void mma_ktile(f32x16 (&acc)[MI][NI], FA ldA, FB ldB,
 #pragma unroll
       for (int j = 0; j < NI; ++j)
         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][i], b[cur][j], acc[i][j], 0, 0, 0);
+    extra(ks);
     __builtin_amdgcn_sched_group_barrier(0x100, MI + NI, 0);   // the next step's LDS reads ...
     __builtin_amdgcn_sched_group_barrier(0x008, MI * NI, 0);   // ... then this step's MFMAs
+    if (FENCE) __builtin_amdgcn_sched_barrier(0);              // ... then this step's share of the staging
   }
 }
 
@@ -188,6 +224,7 @@ __device__ __forceinline__ float4 adjoint_extras(const ConvP& p, const float* __
 // ------------------------------------------------------------------ forward
 template <int BM, int BN>
 __global__ __launch_bounds__(256, 2) void k_conv_fwd(ConvP p) {   // 2 waves/SIMD: acc + tot must fit 256 regs
+  VCG_STAMP_AT(0);
   constexpr int MI = BM / 64, NI = BN / 64, AR = BM / 32, BE = BN / 32;
   __shared__ __attribute__((aligned(16))) float As[BM * AS_STRIDE];
   __shared__ __attribute__((aligned(16))) float Bs[BK * BN];
@@ -298,6 +335,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_fwd(ConvP p) {   // 2 waves/SIM
     store_tiles();
   }
   __syncthreads();
+  VCG_STAMP_AT(1);
   for (int kt = kt0; kt < nkt; ++kt) {
     if (kt + 1 < nkt) load_tiles(kt + 1);
     mma_ktile<MI, NI>(
@@ -310,6 +348,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_fwd(ConvP p) {   // 2 waves/SIM
       __syncthreads();
     }
   }
+  VCG_STAMP_AT(2);
 #pragma unroll
   for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -334,6 +373,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_fwd(ConvP p) {   // 2 waves/SIM
       }
     }
   }
+  VCG_STAMP_AT(3);
 }
 
 // out[m][c] = act(sum_z slab[z][m][c] + bias[c]) — fixed summation order, float4 per lane
@@ -360,9 +400,10 @@ __global__ __launch_bounds__(256) void k_splitk_finish(const float* __restrict__
 // ------------------------------------------------------------------ dgrad
 template <int BM, int BN>
 __global__ __launch_bounds__(256, 2) void k_conv_dgrad(ConvP p) {
+  VCG_STAMP_AT(0);
   constexpr int MI = BM / 64, NI = BN / 64, AR = BM / 32, BR = BN / 32;
-  __shared__ __attribute__((aligned(16))) float As[BM * AS_STRIDE];
-  __shared__ __attribute__((aligned(16))) float Bt[BN * AS_STRIDE];
+  __shared__ __attribute__((aligned(16))) float As[2][BM * AS_STRIDE];   // double-buffered, see k_conv_fwd
+  __shared__ __attribute__((aligned(16))) float Bt[2][BN * AS_STRIDE];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid >> 1, wn = wid & 1, l31 = lane & 31, lh = lane >> 5;
   const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
@@ -480,36 +521,38 @@ __global__ __launch_bounds__(256, 2) void k_conv_dgrad(ConvP p) {
 #pragma unroll
     for (int r = 0; r < BR; ++r) vb[r] = bload4(rb, (kv && wbase[r] != VCG_OOB) ? wbase[r] + cb4 : VCG_OOB);
   };
-  auto store_tiles = [&]() {
+  auto store_tiles = [&](int buf) {
 #pragma unroll
     for (int r = 0; r < AR; ++r) {
-      float* d = &As[(a_row + 32 * r) * AS_STRIDE + a_u * 4];
+      float* d = &As[buf][(a_row + 32 * r) * AS_STRIDE + a_u * 4];
       d[0] = va[r].x + ve[r].x; d[1] = va[r].y + ve[r].y; d[2] = va[r].z + ve[r].z; d[3] = va[r].w + ve[r].w;   // ve == 0 off the edges
     }
 #pragma unroll
     for (int r = 0; r < BR; ++r) {
-      float* d = &Bt[(a_row + 32 * r) * AS_STRIDE + a_u * 4];
+      float* d = &Bt[buf][(a_row + 32 * r) * AS_STRIDE + a_u * 4];
       d[0] = vb[r].x; d[1] = vb[r].y; d[2] = vb[r].z; d[3] = vb[r].w;
     }
   };
 
   if (kt0 < nkt) {
     load_tiles(kt0);
-    store_tiles();
+    store_tiles(0);
   }
   __syncthreads();
+  VCG_STAMP_AT(1);
   for (int kt = kt0; kt < nkt; ++kt) {
+    const int cur = (kt - kt0) & 1;
+    const float* const Ac = As[cur];
+    const float* const Bc = Bt[cur];
     if (kt + 1 < nkt) load_tiles(kt + 1);
     mma_ktile<MI, NI>(
-        acc, [&](int kk, int i) { return As[(wm * (BM / 2) + i * 32 + l31) * AS_STRIDE + kk]; },
-        [&](int kk, int j) { return Bt[(wn * (BN / 2) + j * 32 + l31) * AS_STRIDE + kk]; }, lh);
+        acc, [&](int kk, int i) { return Ac[(wm * (BM / 2) + i * 32 + l31) * AS_STRIDE + kk]; },
+        [&](int kk, int j) { return Bc[(wn * (BN / 2) + j * 32 + l31) * AS_STRIDE + kk]; }, lh);
     if (((kt - kt0 + 1) & (FLUSH_TILES - 1)) == 0 && kt + 1 < nkt) flush_acc<MI, NI>(acc, tot);
+    if (kt + 1 < nkt) store_tiles(cur ^ 1);
     __syncthreads();
-    if (kt + 1 < nkt) {
-      store_tiles();
-      __syncthreads();
-    }
   }
+  VCG_STAMP_AT(2);
 #pragma unroll
   for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -543,15 +586,22 @@ __global__ __launch_bounds__(256, 2) void k_conv_dgrad(ConvP p) {
       }
     }
   }
+  VCG_STAMP_AT(3);
 }
 
 // ------------------------------------------------------------------ wgrad
-template <int BM, int BN>
-__global__ __launch_bounds__(256) void k_conv_wgrad(ConvP p) {
-  constexpr int MI = BM / 64, NI = BN / 64;
-  constexpr int RQ = BM / 4, PS = 256 / RQ, AP = BK / PS, BE = BN / 32;
-  __shared__ __attribute__((aligned(16))) float Xs[BK * BM];
-  __shared__ __attribute__((aligned(16))) float Ds[BK * BN];
+// NT = 256: four waves, two such workgroups per CU.  NT = 512: eight waves in lockstep on one 256-row tile, one
+// workgroup per CU — the two waves of a SIMD then advance together (the per-K-step barrier), where two independent
+// workgroups do not: the hardware favours wave slot 0, which finishes ~20 % early and leaves its partner alone on
+// the CU for the rest of the launch (tools/stamp_probe.py).
+template <int BM, int BN, int NT = 256>
+__global__ __launch_bounds__(NT) void k_conv_wgrad(ConvP p) {
+  VCG_STAMP_AT(0);
+  constexpr int WR = NT / 128;                                 // wave rows (x 2 wave columns)
+  constexpr int MI = BM / (32 * WR), NI = BN / 64;
+  constexpr int RQ = BM / 4, PS = NT / RQ, AP = BK / PS, BE = (BK * BN / 4) / NT;
+  __shared__ __attribute__((aligned(16))) float Xs[2][BK * BM];   // double-buffered, see k_conv_fwd
+  __shared__ __attribute__((aligned(16))) float Ds[2][BK * BN];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid >> 1, wn = wid & 1, l31 = lane & 31, lh = lane >> 5;
   const int r0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
@@ -593,7 +643,7 @@ __global__ __launch_bounds__(256) void k_conv_wgrad(ConvP p) {
   uint32_t boff[BE];
 #pragma unroll
   for (int e = 0; e < BE; ++e) {
-    int idx = tid + 256 * e;
+    int idx = tid + NT * e;
     int pp = idx / (BN / 4), j4 = idx % (BN / 4);
     const int co = n0 + j4 * 4;
     // rows past M fall off the end of the buffer (b_bytes = M * Cout * 4) and read as zeros
@@ -662,35 +712,37 @@ __global__ __launch_bounds__(256) void k_conv_wgrad(ConvP p) {
       if (boff[e] != VCG_OOB) boff[e] += bstep;
     }
   };
-  auto store_tiles = [&]() {
+  auto store_tiles = [&](int buf) {
 #pragma unroll
     for (int a = 0; a < AP; ++a)
-      *reinterpret_cast<float4*>(&Xs[(ps + PS * a) * BM + rq * 4]) = va[a];
+      *reinterpret_cast<float4*>(&Xs[buf][(ps + PS * a) * BM + rq * 4]) = va[a];
 #pragma unroll
     for (int e = 0; e < BE; ++e) {
-      int idx = tid + 256 * e;
+      int idx = tid + NT * e;
       int pp = idx / (BN / 4), j4 = idx % (BN / 4);
-      *reinterpret_cast<float4*>(&Ds[pp * BN + j4 * 4]) = vb[e];
+      *reinterpret_cast<float4*>(&Ds[buf][pp * BN + j4 * 4]) = vb[e];
     }
   };
 
   if (kt_begin < kt_end) {
     load_tiles(kt_begin);
-    store_tiles();
+    store_tiles(0);
   }
   __syncthreads();
+  VCG_STAMP_AT(1);
   for (int kt = kt_begin; kt < kt_end; ++kt) {
+    const int cur = (kt - kt_begin) & 1;
+    const float* const Xc = Xs[cur];
+    const float* const Dc = Ds[cur];
     if (kt + 1 < kt_end) load_tiles(kt + 1);
     mma_ktile<MI, NI>(
-        acc, [&](int kk, int i) { return Xs[kk * BM + wm * (BM / 2) + i * 32 + l31]; },
-        [&](int kk, int j) { return Ds[kk * BN + wn * (BN / 2) + j * 32 + l31]; }, lh);
+        acc, [&](int kk, int i) { return Xc[kk * BM + wm * (BM / WR) + i * 32 + l31]; },
+        [&](int kk, int j) { return Dc[kk * BN + wn * (BN / 2) + j * 32 + l31]; }, lh);
+    if (kt + 1 < kt_end) store_tiles(cur ^ 1);
     __syncthreads();
-    if (kt + 1 < kt_end) {
-      store_tiles();
-      __syncthreads();
-    }
   }
 
+  VCG_STAMP_AT(2);
   float* slab = p.out + (size_t)blockIdx.z * p.K * p.Cout;
 #pragma unroll
   for (int j = 0; j < NI; ++j) {
@@ -701,11 +753,12 @@ __global__ __launch_bounds__(256) void k_conv_wgrad(ConvP p) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int row = (e & 3) + 8 * (e >> 2) + 4 * lh;
-        const int Rr = r0 + wm * (BM / 2) + i * 32 + row;
+        const int Rr = r0 + wm * (BM / WR) + i * 32 + row;
         if (Rr < p.K) slab[(size_t)Rr * p.Cout + co] = acc[i][j][e];
       }
     }
   }
+  VCG_STAMP_AT(3);
 }
 
 // stage 0 when there are many slabs: out[g][idx] = sum over the g-th group of slabs (fixed order),
@@ -909,6 +962,11 @@ int vcg_conv_geom(const int32_t* cd, ConvGeom* g, const char* who) {
 }
 
 static void fill_params(const ConvGeom& g, ConvP& p) {
+#ifdef VCG_STAMP
+  { const char* e = getenv("VCG_DBG"); p.dbg = e ? atoi(e) : 0; }
+#else
+  p.dbg = 0;
+#endif
   p.N = g.N; p.H = g.H; p.W = g.W; p.Cin = g.Cin; p.Cout = g.Cout; p.KH = g.KH; p.KW = g.KW;
   p.stride = g.stride; p.pad = g.pad; p.reflect = g.reflect; p.ups = g.ups; p.act = g.act;
   p.Hl = g.Hl; p.Wl = g.Wl; p.Ho = g.Ho; p.Wo = g.Wo; p.M = g.M; p.K = g.K;
@@ -1091,14 +1149,21 @@ extern "C" int vcg_conv_dgrad(const float* dy, const float* wf, float* dx, const
 static void wgrad_plan(const ConvGeom& g, int& bm, int& bn, int& nsplit, int& per, int& total) {
   total = (g.M + BK - 1) / BK;
   struct Cand { int bm, bn, resident; double t_step; };
-  // t_step from measured rates: 128x128 ~105 TF, 128x64 ~85 TF, 64x64 ~70 TF at full residency
-  const Cand cands[3] = {{128, 128, 2, 5.1}, {128, 64, 3, 4.7}, {64, 64, 5, 4.8}};
+  // t_step from measured rates: 128x128 ~105 TF, 128x64 ~85 TF, 64x64 ~70 TF at full residency;
+  // bm = 256 is the eight-wave lockstep workgroup (one per CU)
+  const Cand cands[4] = {{256, 128, 1, 4.3}, {128, 128, 2, 5.1}, {128, 64, 3, 4.7}, {64, 64, 5, 4.8}};
   double best = 1e30;
   bm = 128; bn = 128; nsplit = 1; per = total;
-  for (int ci = 0; ci < 3; ++ci) {
+  int force = 0;
+#ifdef VCG_STAMP
+  { const char* e = getenv("VCG_WGRAD_BM"); force = e ? atoi(e) : 0; }
+#endif
+  for (int ci = 0; ci < 4; ++ci) {
     const Cand& c = cands[ci];
+    if (force ? c.bm != force : c.bm == 256) continue;    // the lockstep tile measured 0..10 % slower: diagnostics only
     if (c.bn == 128 && g.Cout <= 64) continue;
-    if (c.bm == 128 && g.K <= 64) continue;
+    if (c.bm >= 128 && g.K <= 64) continue;
+    if (c.bm == 256 && g.K < 512) continue;
     const long long tiles = (long long)((g.K + c.bm - 1) / c.bm) * ((g.Cout + c.bn - 1) / c.bn);
     const long long slots = 256LL * c.resident;
     for (int ns = 1; ns <= 512; ++ns) {
@@ -1188,7 +1253,8 @@ extern "C" int vcg_conv_wgrad(const float* x, const float* dy, float* gw_oihw, f
   p.ktiles_per_split = per; p.ktiles_total = total;
   dim3 grid((g.K + bm - 1) / bm, (g.Cout + bn - 1) / bn, nsplit);
   hipStream_t st = (hipStream_t)stream;
-  if (bm == 128 && bn == 128) hipLaunchKernelGGL((k_conv_wgrad<128, 128>), grid, dim3(256), 0, st, p);
+  if (bm == 256) hipLaunchKernelGGL((k_conv_wgrad<256, 128, 512>), grid, dim3(512), 0, st, p);
+  else if (bm == 128 && bn == 128) hipLaunchKernelGGL((k_conv_wgrad<128, 128>), grid, dim3(256), 0, st, p);
   else if (bm == 128 && bn == 64) hipLaunchKernelGGL((k_conv_wgrad<128, 64>), grid, dim3(256), 0, st, p);
   else if (bm == 64 && bn == 128) hipLaunchKernelGGL((k_conv_wgrad<64, 128>), grid, dim3(256), 0, st, p);
   else hipLaunchKernelGGL((k_conv_wgrad<64, 64>), grid, dim3(256), 0, st, p);
