@@ -38,8 +38,12 @@ struct ConvP {
   // dgrad
   int Hc, Wc, Mc, NB;
   FastDiv fd_hcwc, fd_wc;
-  // wgrad
-  int ktiles_per_split, ktiles_total;
+  // wgrad: "stream-K" work split.  The (tile, K' step) pairs are numbered tile-major; workgroup b owns the sk_len
+  // consecutive units [b * sk_len, (b + 1) * sk_len), i.e. the tail of one tile, whole tiles, the head of another.
+  // Every workgroup does the same number of MFMA steps whatever the tile count; a tile's partial sums go to
+  // slab[j], j = b - (first workgroup touching the tile), and the reduce kernels sum sk_parts(tile) of them in order.
+  int ktiles_total, sk_len, sk_units, sk_ntn, sk_bm_shift, sk_bn_shift;
+  FastDiv fd_sklen;
   // split-K of fwd / dgrad (stride 1): blockIdx.z = K slice, raw partial tiles go to slab[z][M][N]
   int ksplit, kt_per;
   float* slab;
@@ -604,18 +608,29 @@ __global__ __launch_bounds__(NT) void k_conv_wgrad(ConvP p) {
   __shared__ __attribute__((aligned(16))) float Ds[2][BK * BN];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid >> 1, wn = wid & 1, l31 = lane & 31, lh = lane >> 5;
-  const int r0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
   const int rq = tid % RQ, ps = tid / RQ;
+  const __amdgpu_buffer_rsrc_t ra = make_srd(p.a, p.a_bytes), rb = make_srd(p.b, p.b_bytes);
+  const uint32_t bstep = (uint32_t)(BK * p.Cout * 4);
+  // When Wo % 32 == 0 the 32 pixels of a K' step lie in one image row: (n, oh) and the row part of the
+  // reflect/address arithmetic are shared by the thread's AP slots.
+  const bool row_aligned = !p.adjoint && (p.Wo % BK) == 0;
 
-  // this thread's K-row quad (fixed for the whole kernel)
+  int unit = (int)blockIdx.x * p.sk_len;
+  int unit_end = unit + p.sk_len;
+  if (unit_end > p.sk_units) unit_end = p.sk_units;
+  while (unit < unit_end) {                       // one segment = one tile's K' range [kt_begin, kt_end)
+  const int tile = unit / p.ktiles_total;
+  const int kt_begin = unit - tile * p.ktiles_total;
+  int kt_end = kt_begin + (unit_end - unit);
+  if (kt_end > p.ktiles_total) kt_end = p.ktiles_total;
+  const int tr = tile / p.sk_ntn;
+  const int r0 = tr * BM, n0 = (tile - tr * p.sk_ntn) * BN;
+
+  // this thread's K-row quad (fixed for the segment)
   const int R = r0 + rq * 4;
   const bool rv = R < p.K;
   int kh, kw, ii, jj, c;
   decode_tap(p, (uint32_t)(R >> 2), kh, kw, ii, jj, c);
-
-  const int kt_begin = blockIdx.z * p.ktiles_per_split;
-  int kt_end = kt_begin + p.ktiles_per_split;
-  if (kt_end > p.ktiles_total) kt_end = p.ktiles_total;
 
   f32x16 acc[MI][NI];
 #pragma unroll
@@ -639,7 +654,6 @@ __global__ __launch_bounds__(NT) void k_conv_wgrad(ConvP p) {
     uint32_t oh = fd_div(rem, p.fd_wo);
     sm[a] = m; sn[a] = (int)n; soh[a] = (int)oh; sow[a] = (int)(rem - oh * (uint32_t)p.Wo);
   }
-  const __amdgpu_buffer_rsrc_t ra = make_srd(p.a, p.a_bytes), rb = make_srd(p.b, p.b_bytes);
   uint32_t boff[BE];
 #pragma unroll
   for (int e = 0; e < BE; ++e) {
@@ -649,11 +663,6 @@ __global__ __launch_bounds__(NT) void k_conv_wgrad(ConvP p) {
     // rows past M fall off the end of the buffer (b_bytes = M * Cout * 4) and read as zeros
     boff[e] = co < p.Cout ? (uint32_t)(((kt_begin * BK + pp) * p.Cout + co) * 4) : VCG_OOB;
   }
-  const uint32_t bstep = (uint32_t)(BK * p.Cout * 4);
-
-  // When Wo % 32 == 0 the 32 pixels of a K' step lie in one image row: (n, oh) and the row part of the
-  // reflect/address arithmetic are shared by the thread's AP slots.
-  const bool row_aligned = !p.adjoint && (p.Wo % BK) == 0;
 
   auto load_tiles = [&](int /*kt: tiles are visited strictly in order*/) {
     if (row_aligned) {
@@ -743,7 +752,8 @@ __global__ __launch_bounds__(NT) void k_conv_wgrad(ConvP p) {
   }
 
   VCG_STAMP_AT(2);
-  float* slab = p.out + (size_t)blockIdx.z * p.K * p.Cout;
+  const int part = (int)blockIdx.x - (int)fd_div((uint32_t)(tile * p.ktiles_total), p.fd_sklen);
+  float* slab = p.out + (size_t)part * p.K * p.Cout;
 #pragma unroll
   for (int j = 0; j < NI; ++j) {
     const int co = n0 + wn * (BN / 2) + j * 32 + l31;
@@ -758,18 +768,31 @@ __global__ __launch_bounds__(NT) void k_conv_wgrad(ConvP p) {
       }
     }
   }
+  unit += kt_end - kt_begin;
+  if (unit < unit_end) __syncthreads();           // the next segment's prologue overwrites LDS half 0
+  }
   VCG_STAMP_AT(3);
+}
+
+// number of partial sums the stream-K split left for the tile that holds element (R, co)
+__device__ __forceinline__ int sk_parts(const ConvP& p, int R, int co) {
+  const int tile = (R >> p.sk_bm_shift) * p.sk_ntn + (co >> p.sk_bn_shift);
+  const uint32_t u0 = (uint32_t)(tile * p.ktiles_total);
+  return (int)(fd_div(u0 + (uint32_t)p.ktiles_total - 1u, p.fd_sklen) - fd_div(u0, p.fd_sklen)) + 1;
 }
 
 // stage 0 when there are many slabs: out[g][idx] = sum over the g-th group of slabs (fixed order),
 // fully parallel over elements and groups
 __global__ __launch_bounds__(256) void k_slab_sum(const float* __restrict__ slabs, float* __restrict__ out,
-                                                  size_t total4, int nsplit, int per_group) {
+                                                  size_t total4, ConvP p, int per_group) {
   const int g = blockIdx.y;
   const int z0 = g * per_group;
-  int z1 = z0 + per_group;
-  if (z1 > nsplit) z1 = nsplit;
+  const int c4 = p.Cout / 4;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (size_t)gridDim.x * blockDim.x) {
+    const int R = (int)(i / c4), co = (int)(i - (size_t)R * c4) * 4;
+    int z1 = z0 + per_group;
+    const int np = sk_parts(p, R, co);            // slabs past a tile's part count were never written
+    if (z1 > np) z1 = np;
     float4 s = f4zero();
     for (int z = z0; z < z1; ++z) f4add(s, reinterpret_cast<const float4*>(slabs)[(size_t)z * total4 + i]);
     reinterpret_cast<float4*>(out)[(size_t)g * total4 + i] = s;
@@ -777,6 +800,7 @@ __global__ __launch_bounds__(256) void k_slab_sum(const float* __restrict__ slab
 }
 
 // small weights: one thread per (R, co), scattered OIHW read-modify-write (irrelevant at this size)
+// nsplit > 0: that many fully written slabs (pre-summed groups); nsplit == 0: the tile's own part count
 __global__ __launch_bounds__(256) void k_wgrad_scatter(const float* __restrict__ slabs, float* __restrict__ gw,
                                                        ConvP p, int nsplit, int cin_log, int cout_log) {
   const size_t total = (size_t)p.K * p.Cout;
@@ -789,15 +813,17 @@ __global__ __launch_bounds__(256) void k_wgrad_scatter(const float* __restrict__
     const int c = (int)(R - t * (uint32_t)p.Cin);
     if (co >= cout_log || c >= cin_log) continue;
     const int tap9 = (int)t / U2, ph = (int)t - tap9 * U2;
+    const int nz = nsplit ? nsplit : sk_parts(p, (int)R, co);
     float s = 0.f;
-    for (int z = 0; z < nsplit; ++z) s += slabs[(size_t)z * total + idx];
+    for (int z = 0; z < nz; ++z) s += slabs[(size_t)z * total + idx];
     gw[((size_t)co * (cin_log * U2) + (size_t)c * U2 + ph) * KK + tap9] += s;
   }
 }
 
 // swapped-role wgrad: slabs[z][(tap, j)][c] -> gw_oihw[j][c][tap] += sum_z
 __global__ __launch_bounds__(256) void k_wgrad_scatter_swapped(const float* __restrict__ slabs, float* __restrict__ gw,
-                                                               int T, int C, int nsplit, int cin_real, int cout_real) {
+                                                               ConvP p, int T, int C, int nsplit, int cin_real,
+                                                               int cout_real) {
   const size_t total = (size_t)T * 4 * C;
   for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
        idx += (size_t)gridDim.x * blockDim.x) {
@@ -805,8 +831,9 @@ __global__ __launch_bounds__(256) void k_wgrad_scatter_swapped(const float* __re
     const int R = (int)(idx / C);
     const int t = R >> 2, j = R & 3;
     if (j >= cout_real || c >= cin_real) continue;
+    const int nz = nsplit ? nsplit : sk_parts(p, R, c);
     float s = 0.f;
-    for (int z = 0; z < nsplit; ++z) s += slabs[(size_t)z * total + idx];
+    for (int z = 0; z < nz; ++z) s += slabs[(size_t)z * total + idx];
     gw[((size_t)j * cin_real + c) * T + t] += s;
   }
 }
@@ -829,7 +856,8 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ 
       float s = 0.f;
       if (ok) {
         const size_t idx = ((size_t)t * p.Cin + c) * p.Cout + co;
-        for (int z = 0; z < nsplit; ++z) s += slabs[(size_t)z * total + idx];
+        const int nz = nsplit ? nsplit : sk_parts(p, t * p.Cin + c, co);
+        for (int z = 0; z < nz; ++z) s += slabs[(size_t)z * total + idx];
       }
       tile[(t * 8 + cl_) * 33 + col] = s;
     }
@@ -979,7 +1007,8 @@ static void fill_params(const ConvGeom& g, ConvP& p) {
   p.fd_cin = make_fastdiv((uint32_t)g.Cin);
   p.Hc = p.Wc = p.Mc = p.NB = 0;
   p.fd_hcwc = make_fastdiv(1); p.fd_wc = make_fastdiv(1);
-  p.ktiles_per_split = p.ktiles_total = 0;
+  p.ktiles_total = 0; p.sk_len = 1; p.sk_units = 0; p.sk_ntn = 1; p.sk_bm_shift = p.sk_bn_shift = 7;
+  p.fd_sklen = make_fastdiv(1);
   p.ksplit = 1; p.kt_per = 0; p.slab = nullptr; p.adjoint = 0; p.src_pitch = g.Cout;
   p.a_bytes = p.b_bytes = 0; p.dbl_mirror = 0;
   p.bias = nullptr;
@@ -1141,19 +1170,21 @@ extern "C" int vcg_conv_dgrad(const float* dy, const float* wf, float* dx, const
   return 0;
 }
 
-// Weight-gradient launch plan.  K' (pixels) is split over blockIdx.z; the split count is chosen with a
-// small cost model instead of "enough workgroups", because the workgroup count is quantised in rounds
-// of (256 CUs x resident workgroups): 792 workgroups on 512 slots cost two full rounds.  Costs in us:
-// one 32-pixel K' step of a resident workgroup, per tile shape (measured on the D/R/U layers), plus the
-// slab write+read at ~3 TB/s.
-static void wgrad_plan(const ConvGeom& g, int& bm, int& bn, int& nsplit, int& per, int& total) {
-  total = (g.M + BK - 1) / BK;
+// Weight-gradient launch plan ("stream-K").  The (tile, K' step) units are dealt out in equal consecutive runs of
+// `len` to `grid` workgroups, so every workgroup does the same number of MFMA steps; with one workgroup per
+// (tile, split) the count is quantised in rounds of (256 CUs x resident workgroups) — 2304 workgroups on 512
+// slots cost five rounds for 4.5 rounds of work (the R blocks, -16 %).  Cost model in us: one 32-pixel K' step of
+// a resident workgroup per tile shape (measured on the D/R/U layers), plus the partial-tile write + read at
+// ~3 TB/s; every workgroup boundary that falls inside a tile adds one partial.
+struct WgradPlan { int bm, bn, grid, len, parts, total, ntr, ntn; };
+static WgradPlan wgrad_plan(const ConvGeom& g) {
+  WgradPlan best_p = {};
+  const int total = (g.M + BK - 1) / BK;
   struct Cand { int bm, bn, resident; double t_step; };
   // t_step from measured rates: 128x128 ~105 TF, 128x64 ~85 TF, 64x64 ~70 TF at full residency;
   // bm = 256 is the eight-wave lockstep workgroup (one per CU)
   const Cand cands[4] = {{256, 128, 1, 4.3}, {128, 128, 2, 5.1}, {128, 64, 3, 4.7}, {64, 64, 5, 4.8}};
   double best = 1e30;
-  bm = 128; bn = 128; nsplit = 1; per = total;
   int force = 0;
 #ifdef VCG_STAMP
   { const char* e = getenv("VCG_WGRAD_BM"); force = e ? atoi(e) : 0; }
@@ -1164,23 +1195,26 @@ static void wgrad_plan(const ConvGeom& g, int& bm, int& bn, int& nsplit, int& pe
     if (c.bn == 128 && g.Cout <= 64) continue;
     if (c.bm >= 128 && g.K <= 64) continue;
     if (c.bm == 256 && g.K < 512) continue;
-    const long long tiles = (long long)((g.K + c.bm - 1) / c.bm) * ((g.Cout + c.bn - 1) / c.bn);
+    const int ntr = (g.K + c.bm - 1) / c.bm, ntn = (g.Cout + c.bn - 1) / c.bn;
+    const long long tiles = (long long)ntr * ntn, units = tiles * total;
+    if (units >= (1LL << 30)) continue;
     const long long slots = 256LL * c.resident;
-    for (int ns = 1; ns <= 512; ++ns) {
-      int kt = (total + ns - 1) / ns;
-      if (kt < 4 && ns > 1) break;
-      int real_ns = (total + kt - 1) / kt;
-      long long wgs = tiles * real_ns;
-      long long rounds = (wgs + slots - 1) / slots;
-      // partially filled last round still runs at full per-workgroup speed, never faster
-      double t = rounds * kt * c.t_step;
-      if (real_ns > 1) t += (double)real_ns * g.K * g.Cout * 8.0 / 3.0e6;
-      if (t < best * 0.97) { best = t; bm = c.bm; bn = c.bn; nsplit = real_ns; per = kt; }
+    // one workgroup per resident slot: several shorter workgroups per slot measured 0..30 % slower (more partial
+    // tiles, more prologues), so the run length is simply units / slots
+    long long len = (units + slots - 1) / slots;
+    if (len < 8) len = units < 8 ? units : 8;
+    const long long grid = (units + len - 1) / len;
+    const int parts = (int)((total + len - 1) / len) + 1;
+    double t = (double)len * c.t_step + (double)(grid + tiles) * c.bm * c.bn * 8.0 / 3.0e6;
+    if (t < best * 0.97) {
+      best = t;
+      best_p = {c.bm, c.bn, (int)grid, (int)len, parts, total, ntr, ntn};
     }
   }
+  return best_p;
 }
 
-static const int kMaxDirectSlabs = 8;
+static const int kMaxDirectSlabs = 24;
 
 // bias-gradient column sums: TC channel quads per block, ~1024 blocks in flight
 static void colsum_plan(const ConvGeom& g, int& tc, int& cgroups, int& rows, int& nchunk) {
@@ -1205,8 +1239,8 @@ extern "C" size_t vcg_conv_wgrad_workspace(const int32_t* cd) {
   if (vcg_conv_geom(cd, &g, "vcg_conv_wgrad_workspace")) return 0;
   const ConvGeom gorig = g;
   if (wgrad_swapped_ok(g)) g = swapped_geom(g);
-  int bm, bn, nsplit, per, total;
-  wgrad_plan(g, bm, bn, nsplit, per, total);
+  const WgradPlan wp = wgrad_plan(g);
+  const int nsplit = wp.parts;
   size_t slabs = (size_t)nsplit * g.K * g.Cout * sizeof(float);
   size_t groups = (size_t)16 * g.K * g.Cout * sizeof(float);     // k_slab_sum output (used when nsplit > 8)
   int tc, cgroups, rows, nchunk;
@@ -1239,8 +1273,8 @@ extern "C" int vcg_conv_wgrad(const float* x, const float* dy, float* gw_oihw, f
   const ConvGeom gorig = g;
   if (swapped) g = swapped_geom(g);
   ConvP p; fill_params(g, p);
-  int bm, bn, nsplit, per, total;
-  wgrad_plan(g, bm, bn, nsplit, per, total);
+  const WgradPlan wp = wgrad_plan(g);
+  const int bm = wp.bm, bn = wp.bn, nsplit = wp.parts;
   p.a = x; p.b = dy; p.out = (float*)ws;
   if (swapped) { p.a = dy; p.b = x; p.adjoint = 1; p.src_pitch = 4; }
   {
@@ -1250,8 +1284,10 @@ extern "C" int vcg_conv_wgrad(const float* x, const float* dy, float* gw_oihw, f
     VCG_CHECK_ARG(ab < (1ull << 31) && bb < (1ull << 31), "vcg_conv_wgrad: tensor extents must stay below 2 GiB");
     p.a_bytes = (uint32_t)ab; p.b_bytes = (uint32_t)bb;
   }
-  p.ktiles_per_split = per; p.ktiles_total = total;
-  dim3 grid((g.K + bm - 1) / bm, (g.Cout + bn - 1) / bn, nsplit);
+  p.ktiles_total = wp.total; p.sk_len = wp.len; p.sk_units = wp.ntr * wp.ntn * wp.total; p.sk_ntn = wp.ntn;
+  p.sk_bm_shift = bm == 256 ? 8 : bm == 128 ? 7 : 6; p.sk_bn_shift = bn == 128 ? 7 : 6;
+  p.fd_sklen = make_fastdiv((uint32_t)wp.len);
+  dim3 grid(wp.grid);
   hipStream_t st = (hipStream_t)stream;
   if (bm == 256) hipLaunchKernelGGL((k_conv_wgrad<256, 128, 512>), grid, dim3(512), 0, st, p);
   else if (bm == 128 && bn == 128) hipLaunchKernelGGL((k_conv_wgrad<128, 128>), grid, dim3(256), 0, st, p);
@@ -1262,14 +1298,14 @@ extern "C" int vcg_conv_wgrad(const float* x, const float* dy, float* gw_oihw, f
   const size_t totalw = (size_t)g.K * g.Cout;
   const size_t slab_bytes = (((size_t)nsplit * totalw * sizeof(float) + 255) / 256) * 256;
   const float* src = (const float*)ws;
-  int ns = nsplit;
+  int ns = 0;                                  // 0: the final kernels sum each tile's own part count
   if (nsplit > kMaxDirectSlabs) {              // many thin slabs: parallel pre-sum into <= 16 group slabs
     float* grp = (float*)((char*)ws + slab_bytes);
     int per_group = (nsplit + 15) / 16;
     int G = (nsplit + per_group - 1) / per_group;
     size_t total4 = totalw / 4;
     int bx = (int)((total4 + 255) / 256); if (bx > 1024) bx = 1024;
-    hipLaunchKernelGGL(k_slab_sum, dim3(bx, G), dim3(256), 0, st, src, grp, total4, nsplit, per_group);
+    hipLaunchKernelGGL(k_slab_sum, dim3(bx, G), dim3(256), 0, st, src, grp, total4, p, per_group);
     src = grp;
     ns = G;
   }
@@ -1277,7 +1313,7 @@ extern "C" int vcg_conv_wgrad(const float* x, const float* dy, float* gw_oihw, f
   const size_t lds = (size_t)T * 8 * 33 * sizeof(float);
   if (swapped) {
     int blocks = (int)((totalw + 255) / 256); if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(k_wgrad_scatter_swapped, dim3(blocks), dim3(256), 0, st, src, gw_oihw, g.KH * g.KW, g.Cout, ns,
+    hipLaunchKernelGGL(k_wgrad_scatter_swapped, dim3(blocks), dim3(256), 0, st, src, gw_oihw, p, g.KH * g.KW, g.Cout, ns,
                        gorig.cin_log, gorig.cout_log);
   } else if (totalw < (1u << 20) || lds > 64 * 1024) {
     int blocks = (int)((totalw + 255) / 256); if (blocks > 4096) blocks = 4096;
