@@ -49,12 +49,20 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    # VCG_DIST_BACKEND=gloo + VCG_ONE_DEVICE=1: rehearsal of the N>1 path on a one-GPU box (all ranks on cuda:0,
+    # exchange through the host); the driver's runs use the default: one rank per GPU, nccl (= RCCL over xGMI)
+    backend = os.environ.get("VCG_DIST_BACKEND", "nccl")
+    if os.environ.get("VCG_ONE_DEVICE") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     pkg = importlib.import_module("vae-cyclegan-implementation_amd")
     ops, N = pkg.ops, pkg.Networks

@@ -127,7 +127,8 @@ int vcg_lincomb_fwd(const float* const* s, const float* w, int count, float* out
 
 /* spectral_norm(nn.Conv2d(512,1,16)) — Networks.py:248 ---------------------- */
 /* one power iteration exactly as torch.nn.utils.spectral_norm in train mode:
-   v<-normalize(W^T u), u<-normalize(W v), sigma=u.(W v); wsn (NHWC-K order) = W/sigma */
+   v<-normalize(W^T u), u<-normalize(W v), sigma=u.(W v); wsn (NHWC-K order) = W/sigma.
+   ws: >= 8 bytes of device scratch (two scalars handed from the reduction to the all-CU apply pass) */
 int vcg_sn_prepare(const float* w_orig_oihw, float* u, float* v, float* sigma, float* wsn_k,
                    int C, int KH, int KW, int update_uv, void* ws, size_t ws_bytes, void* stream);
 /* out[n] = <x[n,:], wsn_k> + bias[0]                                          */

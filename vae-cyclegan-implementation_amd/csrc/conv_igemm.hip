@@ -904,6 +904,37 @@ __global__ void k_pack_weight(const float* __restrict__ w, float* __restrict__ w
   }
 }
 
+// The same repack for large weights, transposed through LDS (the inverse of k_wgrad_reduce): a block owns 32 output
+// channels x 8 input channels x all taps; for every co its OIHW source [8 c][U*U][KH*KW] is one contiguous run, and
+// the Wf rows it writes are 128-B segments (co fastest).  The one-thread-per-element kernel reads OIHW at a stride of
+// Cin*KH*KW floats: 0.7 TB/s.  Dynamic LDS: T*8*33 floats.
+__global__ __launch_bounds__(256) void k_pack_weight_t(const float* __restrict__ w, float* __restrict__ wf, ConvP p,
+                                                       int cin_log, int cout_log) {
+  extern __shared__ __attribute__((aligned(16))) float tile[];
+  const int U2 = p.ups * p.ups, KK = p.KH * p.KW, T = KK * U2;
+  const int co0 = blockIdx.x * 32, c0 = blockIdx.y * 8;
+  const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int cinL = cin_log * U2;
+  const int run = 8 * U2 * KK;
+  for (int j = 0; j < 8; ++j) {
+    const int colw = wid * 8 + j, co = co0 + colw;
+    for (int q = lane; q < run; q += 64) {
+      const int clq = q / KK, tap9 = q - clq * KK;                 // clq = c_local*U2 + phase
+      const int c_local = clq / U2, ph = clq - c_local * U2;
+      const int c = c0 + c_local;
+      const int t = tap9 * U2 + ph;
+      float v = 0.f;
+      if (co < cout_log && c < cin_log) v = w[((size_t)co * cinL + (size_t)c * U2 + ph) * KK + tap9];
+      tile[(t * 8 + c_local) * 33 + colw] = v;
+    }
+  }
+  __syncthreads();
+  const int cl_ = threadIdx.x >> 5, col = threadIdx.x & 31;      // write mapping: 8 c x 32 co
+  const int c = c0 + cl_, co = co0 + col;
+  if (c < p.Cin && co < p.Cout)
+    for (int t = 0; t < T; ++t) wf[((size_t)t * p.Cin + c) * p.Cout + co] = tile[(t * 8 + cl_) * 33 + col];
+}
+
 // gbias[co] += sum_m dy[m][co]: per-chunk partials then a fixed-order final sum
 // float4 per lane (TC channel quads x TP row lanes per block), 4 independent rows in flight per lane
 __global__ __launch_bounds__(256) void k_colsum_partial(const float* __restrict__ dy, float* __restrict__ part,
@@ -934,21 +965,30 @@ __global__ __launch_bounds__(256) void k_colsum_partial(const float* __restrict_
     *reinterpret_cast<float4*>(part + (size_t)blockIdx.y * C + c4 * 4) = s;
   }
 }
-// 32 channels x 8 chunk lanes per block: the loop over chunk partials is a dependent chain of L2 round
-// trips (it cost 150 us per launch as one thread per channel), so it is split 8 ways and combined in LDS
-// in a fixed order
+// 8 channels x 32 chunk lanes per block: the loop over chunk partials is a dependent chain of L2 round trips
+// (150 us per launch as one thread per channel, 16 us split 8 ways), so it is split 32 ways with 4 loads in
+// flight per lane and combined in LDS in a fixed order
 __global__ __launch_bounds__(256) void k_colsum_final(const float* __restrict__ part, float* __restrict__ out, int C,
                                                       int nchunk, int c_log) {
-  __shared__ float red[8][32];
-  const int il = threadIdx.x & 31, kl = threadIdx.x >> 5;
-  const int c = blockIdx.x * 32 + il;
-  float s = 0.f;
-  if (c < c_log)
-    for (int k = kl; k < nchunk; k += 8) s += part[(size_t)k * C + c];
-  red[kl][il] = s;
+  __shared__ float red[32][8];
+  const int il = threadIdx.x & 7, kl = threadIdx.x >> 3;
+  const int c = blockIdx.x * 8 + il;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (c < c_log) {
+    int k = kl;
+    for (; k + 96 < nchunk; k += 128) {
+      s0 += part[(size_t)k * C + c];
+      s1 += part[(size_t)(k + 32) * C + c];
+      s2 += part[(size_t)(k + 64) * C + c];
+      s3 += part[(size_t)(k + 96) * C + c];
+    }
+    for (; k < nchunk; k += 32) s0 += part[(size_t)k * C + c];
+  }
+  red[kl][il] = (s0 + s1) + (s2 + s3);
   __syncthreads();
   if (kl == 0 && c < c_log) {
-    for (int k = 1; k < 8; ++k) s += red[k][il];
+    float s = red[0][il];
+    for (int k = 1; k < 32; ++k) s += red[k][il];
     out[c] += s;
   }
 }
@@ -1059,8 +1099,15 @@ extern "C" int vcg_pack_weight(const float* w_oihw, float* wf, const int32_t* cd
   VCG_CHECK_ARG(w_oihw && wf, "vcg_pack_weight: null pointer");
   ConvP p; fill_params(g, p);
   size_t total = (size_t)g.K * g.Cout;
-  int blocks = (int)((total + 255) / 256); if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(k_pack_weight, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w_oihw, wf, p, g.cin_log, g.cout_log);
+  const int T = g.KH * g.KW * g.ups * g.ups;
+  const size_t lds = (size_t)T * 8 * 33 * sizeof(float);
+  if (total < (1u << 20) || lds > 64 * 1024) {
+    int blocks = (int)((total + 255) / 256); if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(k_pack_weight, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w_oihw, wf, p, g.cin_log, g.cout_log);
+  } else {
+    hipLaunchKernelGGL(k_pack_weight_t, dim3((g.Cout + 31) / 32, (g.Cin + 7) / 8), dim3(256), lds, (hipStream_t)stream,
+                       w_oihw, wf, p, g.cin_log, g.cout_log);
+  }
   VCG_LAUNCH_CHECK("vcg_pack_weight");
   return 0;
 }
@@ -1328,7 +1375,7 @@ extern "C" int vcg_conv_wgrad(const float* x, const float* dy, float* gw_oihw, f
     int tc, cgroups, rows, nchunk;
     colsum_plan(gorig, tc, cgroups, rows, nchunk);
     hipLaunchKernelGGL(k_colsum_partial, dim3(cgroups, nchunk), dim3(256), 0, st, dy, part, gorig.M, gorig.Cout, rows, tc);
-    hipLaunchKernelGGL(k_colsum_final, dim3((gorig.cout_log + 31) / 32), dim3(256), 0, st, (const float*)part, gbias,
+    hipLaunchKernelGGL(k_colsum_final, dim3((gorig.cout_log + 7) / 8), dim3(256), 0, st, (const float*)part, gbias,
                        gorig.Cout, nchunk, gorig.cout_log);
     VCG_LAUNCH_CHECK("vcg_conv_wgrad(bias)");
   }

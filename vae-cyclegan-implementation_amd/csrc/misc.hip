@@ -387,48 +387,70 @@ extern "C" int vcg_lincomb_fwd(const float* const* s, const float* w, int count,
 // W is (1, C, KH, KW): a 1 x K matrix, so the power iteration collapses to two dot products.
 // v stays in OIHW order (state_dict parity); wsn_k is W/sigma permuted to (kh, kw, c) = the
 // NHWC order of the 16x16x512 feature map it is dotted with.
-__global__ __launch_bounds__(1024) void k_sn_prepare(const float* __restrict__ w, float* __restrict__ u,
-                                                     float* __restrict__ v, float* __restrict__ sigma,
-                                                     float* __restrict__ wsn_k, int C, int KH, int KW,
-                                                     int update_uv) {
+// Stage 1 (one block, the two dependent reductions): sigma, the new u, and scal = {u0 * vnorm_inv, 1 / sigma}.
+__global__ __launch_bounds__(1024) void k_sn_reduce(const float* __restrict__ w, float* __restrict__ u,
+                                                    const float* __restrict__ v, float* __restrict__ sigma,
+                                                    float* __restrict__ scal, int K, int update_uv) {
   __shared__ float red[16];
-  const int K = C * KH * KW, KK = KH * KW;
   const float u0 = u[0];
-  float wv_sum;
-  float vnorm_inv = 0.f;
+  const float4* w4 = reinterpret_cast<const float4*>(w);
+  const int K4 = K / 4;
+  float wv_sum, vnorm_inv = 0.f;
   if (update_uv) {
     float s = 0.f;
-    for (int k = threadIdx.x; k < K; k += blockDim.x) { float x = w[k] * u0; s += x * x; }
-    float nrm = sqrtf(block_sum(s, red));
+    for (int k = threadIdx.x; k < K4; k += blockDim.x) {
+      const float4 a = w4[k];
+      const float x0 = a.x * u0, x1 = a.y * u0, x2 = a.z * u0, x3 = a.w * u0;
+      s += x0 * x0 + x1 * x1 + x2 * x2 + x3 * x3;
+    }
+    for (int k = K4 * 4 + threadIdx.x; k < K; k += blockDim.x) { const float x = w[k] * u0; s += x * x; }
+    const float nrm = sqrtf(block_sum(s, red));
     vnorm_inv = 1.0f / fmaxf(nrm, 1e-12f);
     float t = 0.f;
-    for (int k = threadIdx.x; k < K; k += blockDim.x) { float vk = w[k] * u0 * vnorm_inv; t += w[k] * vk; }
+    for (int k = threadIdx.x; k < K4; k += blockDim.x) {
+      const float4 a = w4[k];
+      t += a.x * (a.x * u0 * vnorm_inv) + a.y * (a.y * u0 * vnorm_inv) + a.z * (a.z * u0 * vnorm_inv) +
+           a.w * (a.w * u0 * vnorm_inv);
+    }
+    for (int k = K4 * 4 + threadIdx.x; k < K; k += blockDim.x) t += w[k] * (w[k] * u0 * vnorm_inv);
     wv_sum = block_sum(t, red);
   } else {
     float t = 0.f;
     for (int k = threadIdx.x; k < K; k += blockDim.x) t += w[k] * v[k];
     wv_sum = block_sum(t, red);
   }
-  float un = update_uv ? wv_sum / fmaxf(fabsf(wv_sum), 1e-12f) : u0;
-  float sg = un * wv_sum;
-  for (int k = threadIdx.x; k < K; k += blockDim.x) {
-    float wk = w[k];
-    if (update_uv) v[k] = wk * u0 * vnorm_inv;
-    int c = k / KK, r = k - c * KK;  // r = kh*KW + kw
-    wsn_k[(size_t)r * C + c] = wk / sg;
-  }
+  const float un = update_uv ? wv_sum / fmaxf(fabsf(wv_sum), 1e-12f) : u0;
+  const float sg = un * wv_sum;
   __syncthreads();
   if (threadIdx.x == 0) {
     sigma[0] = sg;
+    scal[0] = u0 * vnorm_inv;
+    scal[1] = sg;
     if (update_uv) u[0] = un;
+  }
+}
+// Stage 2 (all CUs): v = w * u0 / ||w u0|| in OIHW order, wsn_k = w / sigma permuted to (kh, kw, c)
+__global__ __launch_bounds__(256) void k_sn_apply(const float* __restrict__ w, float* __restrict__ v,
+                                                  const float* __restrict__ scal, float* __restrict__ wsn_k, int C,
+                                                  int KK, int update_uv) {
+  const int K = C * KK;
+  const float vs = scal[0], sg = scal[1];
+  for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < K; k += gridDim.x * blockDim.x) {
+    const float wk = w[k];
+    if (update_uv) v[k] = wk * vs;
+    const int c = k / KK, r = k - c * KK;  // r = kh*KW + kw
+    wsn_k[(size_t)r * C + c] = wk / sg;
   }
 }
 extern "C" int vcg_sn_prepare(const float* w_orig_oihw, float* u, float* v, float* sigma, float* wsn_k, int C,
                               int KH, int KW, int update_uv, void* ws, size_t ws_bytes, void* stream) {
-  (void)ws; (void)ws_bytes;
   VCG_CHECK_ARG(w_orig_oihw && u && v && sigma && wsn_k && C > 0 && KH > 0 && KW > 0, "vcg_sn_prepare: bad args");
-  hipLaunchKernelGGL(k_sn_prepare, dim3(1), dim3(1024), 0, (hipStream_t)stream, w_orig_oihw, u, v, sigma, wsn_k, C,
-                     KH, KW, update_uv);
+  VCG_CHECK_ARG(ws && ws_bytes >= 2 * sizeof(float), "vcg_sn_prepare: needs an 8-byte workspace");
+  const int K = C * KH * KW;
+  hipLaunchKernelGGL(k_sn_reduce, dim3(1), dim3(1024), 0, (hipStream_t)stream, w_orig_oihw, u, (const float*)v, sigma,
+                     (float*)ws, K, update_uv);
+  hipLaunchKernelGGL(k_sn_apply, dim3((K + 255) / 256 < 1024 ? (K + 255) / 256 : 1024), dim3(256), 0, (hipStream_t)stream,
+                     w_orig_oihw, v, (const float*)ws, wsn_k, C, KH * KW, update_uv);
   VCG_LAUNCH_CHECK("vcg_sn_prepare");
   return 0;
 }

@@ -617,8 +617,9 @@ class _FullMapSNFn(torch.autograd.Function):
         sigma = torch.empty(1, dtype=torch.float32, device=dev)
         wsn = torch.empty(k, dtype=torch.float32, device=dev)
         wo = weight_orig.detach().contiguous()
+        ws = workspace(64, dev)
         _native.check(lib.vcg_sn_prepare(_ptr(wo), _ptr(u), _ptr(v), _ptr(sigma), _ptr(wsn), c, kh, kw, int(training),
-                                         None, 0, _stream()), "vcg_sn_prepare")
+                                         _ptr(ws), 64, _stream()), "vcg_sn_prepare")
         out = torch.empty(n, dtype=torch.float32, device=dev)
         _native.check(lib.vcg_fullmap_fwd(_ptr(xp), _ptr(wsn), _ptr(bias), _ptr(out), n, k, _stream()), "vcg_fullmap_fwd")
         ctx.save_for_backward(xp, wsn, sigma, u.clone(), v.clone())
