@@ -61,7 +61,10 @@ int vcg_fill(float* dst, float value, size_t n, void* stream);
 
 /* nn.Conv2d(padding_mode='reflect') — Networks.py:60,87,101,104,122,136,145 -- */
 /* OIHW -> Wf[K][Cout], K ordered (kh,kw,i,j,c) so PixelUnshuffle (Networks.py:86)
-   needs no data movement.                                                      */
+   needs no data movement; for the 3x3 / stride-1 layers the buffer continues with the
+   Winograd F(2x2,3x3) transform U[16][(i,j,c)][Cout] that vcg_conv_fwd multiplies with.
+   vcg_pack_weight_floats: floats the caller must provide for `wf` (spatial fields of cd are ignored). */
+size_t vcg_pack_weight_floats(const int32_t* cd);
 int vcg_pack_weight(const float* w_oihw, float* wf, const int32_t* cd, void* stream);
 /* y = act(conv(x) + bias): implicit GEMM on v_mfma_f32_32x32x2_f32.  Layers with few output
    tiles slice K across workgroups into fp32 slabs in `ws` (vcg_conv_fwd_workspace bytes, may be 0). */

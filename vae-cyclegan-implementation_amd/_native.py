@@ -10,7 +10,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(_HERE, "libvcg.so")
-SOURCES = ["conv_igemm.hip", "conv_thin.hip", "norm.hip", "misc.hip"]
+SOURCES = ["conv_igemm.hip", "conv_thin.hip", "conv_wino.hip", "norm.hip", "misc.hip"]
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "vcg.h")
 
 _c = ctypes
@@ -28,6 +28,7 @@ SIGNATURES = {
     "vcg_nchw_to_nhwc": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "vcg_nhwc_to_nchw": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "vcg_fill": (_I, [_P, _F, _Z, _P]),
+    "vcg_pack_weight_floats": (_Z, [_I32P]),
     "vcg_pack_weight": (_I, [_P, _P, _I32P, _P]),
     "vcg_conv_fwd_workspace": (_Z, [_I32P]),
     "vcg_conv_fwd": (_I, [_P, _P, _P, _P, _I32P, _P, _Z, _P]),

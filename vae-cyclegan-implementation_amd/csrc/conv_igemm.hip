@@ -53,6 +53,10 @@ struct ConvP {
   uint32_t a_bytes, b_bytes;   // extents of a / b for the bounds-checked buffer loads (< 2 GiB each)
   int dbl_mirror;              // dgrad: some pixel has BOTH a top and a bottom (or left and right) mirror
   int dbg;                     // diagnostic builds only (VCG_STAMP): knock out parts of the main loop, timing experiments
+  // batched launch of the forward kernel (the 16 GEMMs of a Winograd conv): blockIdx.z selects the batch
+  int nbatch;
+  uint32_t a_bstride, b_bstride;   // floats between consecutive batches of a / b
+  size_t out_bstride;
 };
 
 #define BK 32
@@ -237,7 +241,9 @@ __global__ __launch_bounds__(256, 2) void k_conv_fwd(ConvP p) {   // 2 waves/SIM
   const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
   const int a_row = tid >> 3, a_u = tid & 7;
 
-  const __amdgpu_buffer_rsrc_t ra = make_srd(p.a, p.a_bytes), rb = make_srd(p.b, p.b_bytes);
+  const int zb = p.nbatch > 1 ? (int)blockIdx.z : 0;
+  const __amdgpu_buffer_rsrc_t ra = make_srd(p.a + (size_t)zb * p.a_bstride, p.a_bytes),
+                               rb = make_srd(p.b + (size_t)zb * p.b_bstride, p.b_bytes);
   int pnH[AR], boh[AR], bow[AR];
   bool pv[AR];
 #pragma unroll
@@ -360,7 +366,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_fwd(ConvP p) {   // 2 waves/SIM
 
   // epilogue: bias + activation, NHWC store (32 consecutive channels per half-wave);
   // a K slice stores its raw partial tile instead (bias/activation happen in k_splitk_finish)
-  float* const dst = p.ksplit > 1 ? p.slab + (size_t)blockIdx.z * p.M * p.Cout : p.out;
+  float* const dst = p.ksplit > 1 ? p.slab + (size_t)blockIdx.z * p.M * p.Cout : p.out + (size_t)zb * p.out_bstride;
   const int act = p.ksplit > 1 ? VCG_ACT_NONE : p.act;
 #pragma unroll
   for (int j = 0; j < NI; ++j) {
@@ -1047,6 +1053,7 @@ static void fill_params(const ConvGeom& g, ConvP& p) {
   p.fd_cin = make_fastdiv((uint32_t)g.Cin);
   p.Hc = p.Wc = p.Mc = p.NB = 0;
   p.fd_hcwc = make_fastdiv(1); p.fd_wc = make_fastdiv(1);
+  p.nbatch = 1; p.a_bstride = p.b_bstride = 0; p.out_bstride = 0;
   p.ktiles_total = 0; p.sk_len = 1; p.sk_units = 0; p.sk_ntn = 1; p.sk_bm_shift = p.sk_bn_shift = 7;
   p.fd_sklen = make_fastdiv(1);
   p.ksplit = 1; p.kt_per = 0; p.slab = nullptr; p.adjoint = 0; p.src_pitch = g.Cout;
@@ -1059,7 +1066,7 @@ static void fill_params(const ConvGeom& g, ConvP& p) {
 // tile and slice K across blockIdx.z instead of shrinking the tile: partial tiles go to fp32 slabs that
 // k_splitk_finish sums in a fixed order (+ bias + activation).
 static void gemm_plan(long long rows, long long cols, int nkt, bool allow_split, int& bm, int& bn, int& nsplit,
-                      int& kt_per) {
+                      int& kt_per, int batches = 1) {
   // cost model (us): rounds of resident workgroups x K-steps per workgroup x time per K-step of that tile,
   // plus the slab write+read of a K-sliced launch.  Same constants as wgrad_plan.
   struct Cand { int bm, bn, resident; double t_step; };
@@ -1070,7 +1077,7 @@ static void gemm_plan(long long rows, long long cols, int nkt, bool allow_split,
     const Cand& c = cands[ci];
     if (c.bn == 128 && cols <= 64) continue;
     if (c.bm == 128 && rows <= 64) continue;
-    const long long tiles = ((rows + c.bm - 1) / c.bm) * ((cols + c.bn - 1) / c.bn);
+    const long long tiles = ((rows + c.bm - 1) / c.bm) * ((cols + c.bn - 1) / c.bn) * batches;
     const long long slots = 256LL * c.resident;
     const int max_ns = allow_split ? 32 : 1;
     for (int ns = 1; ns <= max_ns; ++ns) {
@@ -1093,10 +1100,42 @@ static void gemm_plan(long long rows, long long cols, int nkt, bool allow_split,
     else hipLaunchKernelGGL((KERNEL<64, 64>), grid, dim3(256), 0, stream, p);                  \
   } while (0)
 
+// C[z][m][n] = sum_k A[z][m][k] * B[z][k][n]   (row-major, k and n multiples of 4) — the forward kernel run as a
+// 1x1 convolution over `rows` pixels, one batch per blockIdx.z.  Used by the Winograd path (conv_wino.hip).
+int vcg_gemm_batched(const float* A, const float* B, float* C, int rows, int K, int Ncols, int batches, hipStream_t st) {
+  ConvGeom g = {};
+  g.N = 1; g.H = 1; g.W = rows; g.Cin = K; g.Cout = Ncols; g.KH = g.KW = 1; g.stride = 1; g.pad = 0; g.reflect = 0;
+  g.ups = 1; g.act = VCG_ACT_NONE; g.cin_log = K; g.cout_log = Ncols;
+  g.Hl = 1; g.Wl = rows; g.Ho = 1; g.Wo = rows; g.M = rows; g.K = K; g.taps = 1;
+  ConvP p; fill_params(g, p);
+  p.a = A; p.b = B; p.bias = nullptr; p.out = C;
+  VCG_CHECK_ARG((unsigned long long)rows * K * 4 < (1ull << 31) && (unsigned long long)K * Ncols * 4 < (1ull << 31),
+                "vcg_gemm_batched: operand extents must stay below 2 GiB per batch");
+  p.a_bytes = (uint32_t)((size_t)rows * K * 4); p.b_bytes = (uint32_t)((size_t)K * Ncols * 4);
+  p.nbatch = batches; p.a_bstride = (uint32_t)((size_t)rows * K); p.b_bstride = (uint32_t)((size_t)K * Ncols);
+  p.out_bstride = (size_t)rows * Ncols;
+  VCG_CHECK_ARG((unsigned long long)rows * K * (unsigned long long)batches < (1ull << 32), "vcg_gemm_batched: batch stride overflow");
+  int bm, bn, nsplit, kt_per;
+  gemm_plan(rows, Ncols, (K + BK - 1) / BK, false, bm, bn, nsplit, kt_per, batches);
+  dim3 grid((rows + bm - 1) / bm, (Ncols + bn - 1) / bn, batches);
+  DISPATCH_TILE(k_conv_fwd, bm, bn, grid, st, p);
+  VCG_LAUNCH_CHECK("vcg_gemm_batched");
+  return 0;
+}
+
+// floats of the packed-weight buffer: Wf[K][Cout], then (3x3 stride-1 layers) the Winograd-transformed U[16][Kc][Cout]
+static size_t wf_floats(const ConvGeom& g) { return (((size_t)g.K * g.Cout + 63) / 64) * 64; }
+extern "C" size_t vcg_pack_weight_floats(const int32_t* cd) {
+  ConvGeom g;
+  if (vcg_conv_geom(cd, &g, "vcg_pack_weight_floats")) return 0;
+  return wf_floats(g) + (vcg_wino_weight_ok(g) ? vcg_wino_weight_floats(g) : 0);
+}
+
 extern "C" int vcg_pack_weight(const float* w_oihw, float* wf, const int32_t* cd, void* stream) {
   ConvGeom g;
   if (vcg_conv_geom(cd, &g, "vcg_pack_weight")) return -1;
   VCG_CHECK_ARG(w_oihw && wf, "vcg_pack_weight: null pointer");
+  if (vcg_wino_weight_ok(g) && vcg_wino_weight(g, w_oihw, wf + wf_floats(g), (hipStream_t)stream)) return -2;
   ConvP p; fill_params(g, p);
   size_t total = (size_t)g.K * g.Cout;
   const int T = g.KH * g.KW * g.ups * g.ups;
@@ -1120,6 +1159,7 @@ extern "C" size_t vcg_conv_fwd_workspace(const int32_t* cd) {
   ConvGeom g;
   if (vcg_conv_geom(cd, &g, "vcg_conv_fwd_workspace")) return 0;
   if (vcg_thin_fwd_ok(g)) return 0;
+  if (vcg_wino_fwd_ok(g)) return vcg_wino_fwd_workspace(g);
   int bm, bn, nsplit, kt_per;
   fwd_plan(g, bm, bn, nsplit, kt_per);
   return nsplit > 1 ? (size_t)nsplit * g.M * g.Cout * sizeof(float) + 256 : 0;
@@ -1137,6 +1177,7 @@ extern "C" int vcg_conv_fwd(const float* x, const float* wf, const float* bias, 
   if (vcg_conv_geom(cd, &g, "vcg_conv_fwd")) return -1;
   VCG_CHECK_ARG(x && wf && y, "vcg_conv_fwd: null pointer");
   if (vcg_thin_fwd_ok(g)) return vcg_thin_fwd(g, x, wf, bias, y, (hipStream_t)stream);
+  if (vcg_wino_fwd_ok(g)) return vcg_wino_fwd(g, x, wf + wf_floats(g), bias, y, ws, ws_bytes, (hipStream_t)stream);
   ConvP p; fill_params(g, p);
   p.a = x; p.b = wf; p.bias = bias; p.out = y;
   {

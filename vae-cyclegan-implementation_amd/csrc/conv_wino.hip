@@ -1,0 +1,226 @@
+// Winograd F(2x2, 3x3) for the 3x3 / stride-1 / pad-1 convolutions of the D, R and U blocks
+// (Networks.py:87-136): 2.25x fewer multiplications than the direct form.  On gfx950 fp32 MFMA has no
+// faster low-precision sibling that keeps fp32 results, so cutting the multiplication count is the one lever left
+// once the implicit-GEMM kernels sit at ~75 % of what the matrix pipe sustains.
+//
+//   V[xi][t][k]  = (B^T d B)[xi]       input transform of the 4x4 patch of output tile t (2x2 outputs), k = (i, j, c)
+//   U[xi][k][co] = (G g G^T)[xi]       weight transform, once per optimizer step (vcg_pack_weight)
+//   M[xi][t][co] = sum_k V U           16 independent GEMMs: the forward MFMA kernel run as a batched 1x1 convolution
+//   y            = A^T M A + bias, activation
+//
+// Padding (reflect or zero) and the folded PixelUnshuffle of the D blocks live in the input transform's gather, so
+// the GEMMs are dense.  V and M are 4x the activation they come from; they stay in the caller's workspace.
+// Rounding: the transforms add a few ulp to the fp32 sums (measured in tests/test_gpu_parity.py against the
+// oracle at the same 1e-4 bound as the direct kernels).
+#include "vcg_common.h"
+#include <stdlib.h>
+
+int vcg_gemm_batched(const float* A, const float* B, float* C, int rows, int K, int Ncols, int batches, hipStream_t st);
+
+struct WinoP {
+  const float* x;
+  float* v;
+  const float* m;
+  const float* bias;
+  float* y;
+  int N, H, W, Cin, Cout, Hl, Wl, ups, reflect, act, cout_log;
+  int th, tw, T, Kc;
+  FastDiv fd_k4, fd_tw, fd_thtw, fd_c4, fd_co4;
+};
+
+__device__ __forceinline__ float4 f4sub(const float4& a, const float4& b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
+__device__ __forceinline__ float4 f4sum(const float4& a, const float4& b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+
+// one thread: one tile x 4 consecutive k (same unshuffle phase (i, j), channels c..c+3)
+__global__ __launch_bounds__(256) void k_wino_in(WinoP p) {
+  const uint32_t k4n = (uint32_t)p.Kc / 4;
+  const size_t total = (size_t)p.T * k4n;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    const uint32_t t = (uint32_t)(idx / k4n);
+    const uint32_t k4 = (uint32_t)(idx - (size_t)t * k4n);
+    const uint32_t ph = fd_div(k4, p.fd_c4);                      // unshuffle phase i*2 + j (0 when ups == 1)
+    const int c = (int)(k4 - ph * (uint32_t)(p.Cin / 4)) * 4;
+    const int pi = (int)(ph >> 1), pj = (int)(ph & 1);
+    const uint32_t n = fd_div(t, p.fd_thtw);
+    const uint32_t rem = t - n * (uint32_t)(p.th * p.tw);
+    const uint32_t ty = fd_div(rem, p.fd_tw);
+    const int tx = (int)(rem - ty * (uint32_t)p.tw);
+    const float* xn = p.x + (size_t)n * p.H * p.W * p.Cin;
+    float4 d[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      int ih = 2 * (int)ty - 1 + r;
+      bool okh = true;
+      if (p.reflect) ih = reflect_idx(ih, p.Hl);
+      else okh = ih >= 0 && ih < p.Hl;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        int iw = 2 * tx - 1 + s;
+        bool ok = okh;
+        if (p.reflect) iw = reflect_idx(iw, p.Wl);
+        else ok = ok && iw >= 0 && iw < p.Wl;
+        d[r][s] = ok ? *reinterpret_cast<const float4*>(xn + ((size_t)(ih * p.ups + pi) * p.W + (iw * p.ups + pj)) * p.Cin + c)
+                     : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+    // B^T d: rows (d0 - d2, d1 + d2, d2 - d1, d1 - d3); then the same on the columns
+    float4 e[4][4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      e[0][s] = f4sub(d[0][s], d[2][s]);
+      e[1][s] = f4sum(d[1][s], d[2][s]);
+      e[2][s] = f4sub(d[2][s], d[1][s]);
+      e[3][s] = f4sub(d[1][s], d[3][s]);
+    }
+    float* vb = p.v + (size_t)t * p.Kc + (size_t)k4 * 4;
+    const size_t plane = (size_t)p.T * p.Kc;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      *reinterpret_cast<float4*>(vb + (size_t)(a * 4 + 0) * plane) = f4sub(e[a][0], e[a][2]);
+      *reinterpret_cast<float4*>(vb + (size_t)(a * 4 + 1) * plane) = f4sum(e[a][1], e[a][2]);
+      *reinterpret_cast<float4*>(vb + (size_t)(a * 4 + 2) * plane) = f4sub(e[a][2], e[a][1]);
+      *reinterpret_cast<float4*>(vb + (size_t)(a * 4 + 3) * plane) = f4sub(e[a][1], e[a][3]);
+    }
+  }
+}
+
+// one thread: one tile x 4 output channels; y = A^T m A, A^T = [[1, 1, 1, 0], [0, 1, -1, -1]]
+__global__ __launch_bounds__(256) void k_wino_out(WinoP p) {
+  const uint32_t c4n = (uint32_t)p.Cout / 4;
+  const size_t total = (size_t)p.T * c4n;
+  const size_t plane = (size_t)p.T * p.Cout;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    const uint32_t t = (uint32_t)(idx / c4n);
+    const int co = (int)(idx - (size_t)t * c4n) * 4;
+    const uint32_t n = fd_div(t, p.fd_thtw);
+    const uint32_t rem = t - n * (uint32_t)(p.th * p.tw);
+    const uint32_t ty = fd_div(rem, p.fd_tw);
+    const int tx = (int)(rem - ty * (uint32_t)p.tw);
+    const float* mb = p.m + (size_t)t * p.Cout + co;
+    float4 s0[4], s1[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const float4 m0 = *reinterpret_cast<const float4*>(mb + (size_t)(0 + b) * plane);
+      const float4 m1 = *reinterpret_cast<const float4*>(mb + (size_t)(4 + b) * plane);
+      const float4 m2 = *reinterpret_cast<const float4*>(mb + (size_t)(8 + b) * plane);
+      const float4 m3 = *reinterpret_cast<const float4*>(mb + (size_t)(12 + b) * plane);
+      s0[b] = f4sum(f4sum(m0, m1), m2);
+      s1[b] = f4sub(f4sub(m1, m2), m3);
+    }
+    float4 y[2][2];
+    y[0][0] = f4sum(f4sum(s0[0], s0[1]), s0[2]);
+    y[0][1] = f4sub(f4sub(s0[1], s0[2]), s0[3]);
+    y[1][0] = f4sum(f4sum(s1[0], s1[1]), s1[2]);
+    y[1][1] = f4sub(f4sub(s1[1], s1[2]), s1[3]);
+    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p.bias) {
+      if (co + 0 < p.cout_log) bv.x = p.bias[co + 0];
+      if (co + 1 < p.cout_log) bv.y = p.bias[co + 1];
+      if (co + 2 < p.cout_log) bv.z = p.bias[co + 2];
+      if (co + 3 < p.cout_log) bv.w = p.bias[co + 3];
+    }
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const int oh = 2 * (int)ty + r, ow = 2 * tx + s;
+        if (oh < p.Hl && ow < p.Wl) {
+          float4 o = y[r][s];
+          o.x = act_apply(o.x + bv.x, p.act); o.y = act_apply(o.y + bv.y, p.act);
+          o.z = act_apply(o.z + bv.z, p.act); o.w = act_apply(o.w + bv.w, p.act);
+          *reinterpret_cast<float4*>(p.y + (((size_t)n * p.Hl + oh) * p.Wl + ow) * p.Cout + co) = o;
+        }
+      }
+  }
+}
+
+// U[xi][k][co] = (G g G^T)[xi], G = [[1, 0, 0], [.5, .5, .5], [.5, -.5, .5], [0, 0, 1]]; k = (phase, c) as in Wf.
+// One thread per (k, co), co fastest: coalesced stores into the 16 planes, 36-byte OIHW reads.
+__global__ __launch_bounds__(256) void k_wino_weight(const float* __restrict__ w, float* __restrict__ u, int Cin, int Cout,
+                                                     int ups, int cin_log, int cout_log) {
+  const int U2 = ups * ups, Kc = U2 * Cin;
+  const size_t total = (size_t)Kc * Cout;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    const int k = (int)(idx / Cout), co = (int)(idx - (size_t)k * Cout);
+    const int ph = k / Cin, c = k - ph * Cin;
+    float g[3][3];
+    const bool ok = co < cout_log && c < cin_log;
+    const float* wp = w + ((size_t)co * (cin_log * U2) + (size_t)c * U2 + ph) * 9;
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+      for (int b = 0; b < 3; ++b) g[a][b] = ok ? wp[a * 3 + b] : 0.f;
+    float h[4][3];
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+      h[0][b] = g[0][b];
+      h[1][b] = 0.5f * (g[0][b] + g[1][b] + g[2][b]);
+      h[2][b] = 0.5f * (g[0][b] - g[1][b] + g[2][b]);
+      h[3][b] = g[2][b];
+    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      u[(size_t)(a * 4 + 0) * total + idx] = h[a][0];
+      u[(size_t)(a * 4 + 1) * total + idx] = 0.5f * (h[a][0] + h[a][1] + h[a][2]);
+      u[(size_t)(a * 4 + 2) * total + idx] = 0.5f * (h[a][0] - h[a][1] + h[a][2]);
+      u[(size_t)(a * 4 + 3) * total + idx] = h[a][2];
+    }
+  }
+}
+
+// ------------------------------------------------------------------ host side
+static int wino_blocks(size_t work) {
+  size_t b = (work + 255) / 256;
+  if (b > 8192) b = 8192;
+  return b < 1 ? 1 : (int)b;
+}
+
+// shape class the packed weights carry a transformed copy for (no spatial condition: packing sees no image size)
+bool vcg_wino_weight_ok(const ConvGeom& g) {
+  return g.KH == 3 && g.KW == 3 && g.stride == 1 && g.pad == 1 && g.ups * g.ups * g.Cin >= 128 && g.Cout >= 64 &&
+         g.Cin % 4 == 0 && g.Cout % 4 == 0;
+}
+bool vcg_wino_fwd_ok(const ConvGeom& g) {
+  if (!vcg_wino_weight_ok(g)) return false;
+#ifdef VCG_STAMP
+  if (getenv("VCG_NO_WINOGRAD")) return false;     // A/B timing in the diagnostic build only
+#endif
+  if (g.Ho < 4 || g.Wo < 4 || (g.Ho & 1) || (g.Wo & 1)) return false;
+  const unsigned long long T = (unsigned long long)g.N * (g.Ho / 2) * (g.Wo / 2);
+  const unsigned long long Kc = (unsigned long long)g.ups * g.ups * g.Cin;
+  return T * Kc * 4 < (1ull << 31) && T * g.Cout * 4 < (1ull << 31) && T * Kc * 16 < (1ull << 32);
+}
+size_t vcg_wino_weight_floats(const ConvGeom& g) { return (size_t)16 * g.ups * g.ups * g.Cin * g.Cout; }
+size_t vcg_wino_fwd_workspace(const ConvGeom& g) {
+  const size_t T = (size_t)g.N * (g.Ho / 2) * (g.Wo / 2);
+  return (size_t)16 * T * ((size_t)g.ups * g.ups * g.Cin + g.Cout) * sizeof(float) + 512;
+}
+int vcg_wino_weight(const ConvGeom& g, const float* w_oihw, float* u, hipStream_t st) {
+  const size_t total = (size_t)g.ups * g.ups * g.Cin * g.Cout;
+  hipLaunchKernelGGL(k_wino_weight, dim3(wino_blocks(total)), dim3(256), 0, st, w_oihw, u, g.Cin, g.Cout, g.ups, g.cin_log,
+                     g.cout_log);
+  VCG_LAUNCH_CHECK("vcg_wino_weight");
+  return 0;
+}
+
+int vcg_wino_fwd(const ConvGeom& g, const float* x, const float* u, const float* bias, float* y, void* ws, size_t ws_bytes,
+                 hipStream_t st) {
+  VCG_CHECK_ARG(ws && ws_bytes >= vcg_wino_fwd_workspace(g), "vcg_conv_fwd: workspace too small for the Winograd path (%zu)",
+                ws_bytes);
+  WinoP p;
+  p.N = g.N; p.H = g.H; p.W = g.W; p.Cin = g.Cin; p.Cout = g.Cout; p.Hl = g.Hl; p.Wl = g.Wl; p.ups = g.ups;
+  p.reflect = g.reflect; p.act = g.act; p.cout_log = g.cout_log;
+  p.th = g.Ho / 2; p.tw = g.Wo / 2; p.T = g.N * p.th * p.tw; p.Kc = g.ups * g.ups * g.Cin;
+  p.fd_k4 = make_fastdiv((uint32_t)p.Kc / 4); p.fd_tw = make_fastdiv((uint32_t)p.tw);
+  p.fd_thtw = make_fastdiv((uint32_t)(p.th * p.tw)); p.fd_c4 = make_fastdiv((uint32_t)g.Cin / 4);
+  p.fd_co4 = make_fastdiv((uint32_t)g.Cout / 4);
+  float* V = (float*)ws;
+  float* M = V + (((size_t)16 * p.T * p.Kc + 63) / 64) * 64;
+  p.x = x; p.v = V; p.m = M; p.bias = bias; p.y = y;
+  hipLaunchKernelGGL(k_wino_in, dim3(wino_blocks((size_t)p.T * p.Kc / 4)), dim3(256), 0, st, p);
+  VCG_LAUNCH_CHECK("vcg_conv_fwd(winograd input transform)");
+  if (vcg_gemm_batched(V, u, M, p.T, p.Kc, g.Cout, 16, st)) return -2;
+  hipLaunchKernelGGL(k_wino_out, dim3(wino_blocks((size_t)p.T * g.Cout / 4)), dim3(256), 0, st, p);
+  VCG_LAUNCH_CHECK("vcg_conv_fwd(winograd output transform)");
+  return 0;
+}

@@ -107,3 +107,12 @@ size_t vcg_thin_dgrad_workspace(const ConvGeom& g);
 int vcg_thin_fwd(const ConvGeom& g, const float* x, const float* wf, const float* bias, float* y, hipStream_t st);
 int vcg_thin_dgrad(const ConvGeom& g, const float* dy, const float* wf, float* dx, void* ws, size_t ws_bytes,
                    hipStream_t st);
+
+// conv_wino.hip: Winograd F(2x2,3x3) forward for the 3x3 / stride-1 / pad-1 layers
+bool vcg_wino_weight_ok(const ConvGeom& g);
+bool vcg_wino_fwd_ok(const ConvGeom& g);
+size_t vcg_wino_weight_floats(const ConvGeom& g);
+size_t vcg_wino_fwd_workspace(const ConvGeom& g);
+int vcg_wino_weight(const ConvGeom& g, const float* w_oihw, float* u, hipStream_t st);
+int vcg_wino_fwd(const ConvGeom& g, const float* x, const float* u, const float* bias, float* y, void* ws, size_t ws_bytes,
+                 hipStream_t st);

@@ -190,13 +190,15 @@ class ConvSpec:
         """Wf[K][Cout] for the current parameter values (repacked once per optimizer step)."""
         key = (PARAM_EPOCH[0], weight._version, weight.data_ptr())
         if self._packed is None or self._packed_key != key or self._packed.device != weight.device:
-            kdim = self.k * self.k * self.ups * self.ups * self.cin_pitch
+            cd = self.desc(1, max(self.ups * self.k, 2 * self.ups * (self.pad + 1)), max(self.ups * self.k, 2 * self.ups * (self.pad + 1)))
             if self._packed is None or self._packed.device != weight.device:
-                self._packed = torch.empty(kdim * self.cout_pitch, dtype=torch.float32, device=weight.device)
+                nfl = int(_native.lib().vcg_pack_weight_floats(cd))
+                if nfl <= 0:
+                    raise RuntimeError(f"vcg_pack_weight_floats failed: {_native.lib().vcg_last_error().decode()}")
+                self._packed = torch.empty(nfl, dtype=torch.float32, device=weight.device)
             w = weight.detach()
             if not w.is_contiguous():
                 w = w.contiguous()
-            cd = self.desc(1, max(self.ups * self.k, 2 * self.ups * (self.pad + 1)), max(self.ups * self.k, 2 * self.ups * (self.pad + 1)))
             _native.check(_native.lib().vcg_pack_weight(_ptr(w), _ptr(self._packed), cd, _stream()), "vcg_pack_weight")
             self._packed_key = key
         return self._packed
