@@ -43,6 +43,7 @@ struct ConvP {
   // Every workgroup does the same number of MFMA steps whatever the tile count; a tile's partial sums go to
   // slab[j], j = b - (first workgroup touching the tile), and the reduce kernels sum sk_parts(tile) of them in order.
   int ktiles_total, sk_len, sk_units, sk_ntn, sk_bm_shift, sk_bn_shift;
+  int sk_ntr_pb;               // row tiles per batch (batched wgrad: the row tiles of batch z follow those of z-1)
   FastDiv fd_sklen;
   // split-K of fwd / dgrad (stride 1): blockIdx.z = K slice, raw partial tiles go to slab[z][M][N]
   int ksplit, kt_per;
@@ -615,7 +616,6 @@ __global__ __launch_bounds__(NT) void k_conv_wgrad(ConvP p) {
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid >> 1, wn = wid & 1, l31 = lane & 31, lh = lane >> 5;
   const int rq = tid % RQ, ps = tid / RQ;
-  const __amdgpu_buffer_rsrc_t ra = make_srd(p.a, p.a_bytes), rb = make_srd(p.b, p.b_bytes);
   const uint32_t bstep = (uint32_t)(BK * p.Cout * 4);
   // When Wo % 32 == 0 the 32 pixels of a K' step lie in one image row: (n, oh) and the row part of the
   // reflect/address arithmetic are shared by the thread's AP slots.
@@ -630,7 +630,10 @@ __global__ __launch_bounds__(NT) void k_conv_wgrad(ConvP p) {
   int kt_end = kt_begin + (unit_end - unit);
   if (kt_end > p.ktiles_total) kt_end = p.ktiles_total;
   const int tr = tile / p.sk_ntn;
-  const int r0 = tr * BM, n0 = (tile - tr * p.sk_ntn) * BN;
+  const int zb = tr / p.sk_ntr_pb;                 // batch (0 unless this is a batched launch)
+  const int r0 = (tr - zb * p.sk_ntr_pb) * BM, n0 = (tile - tr * p.sk_ntn) * BN;
+  const __amdgpu_buffer_rsrc_t ra = make_srd(p.a + (size_t)zb * p.a_bstride, p.a_bytes),
+                               rb = make_srd(p.b + (size_t)zb * p.b_bstride, p.b_bytes);
 
   // this thread's K-row quad (fixed for the segment)
   const int R = r0 + rq * 4;
@@ -759,7 +762,7 @@ __global__ __launch_bounds__(NT) void k_conv_wgrad(ConvP p) {
 
   VCG_STAMP_AT(2);
   const int part = (int)blockIdx.x - (int)fd_div((uint32_t)(tile * p.ktiles_total), p.fd_sklen);
-  float* slab = p.out + (size_t)part * p.K * p.Cout;
+  float* slab = p.out + ((size_t)part * p.nbatch + zb) * p.K * p.Cout;      // slab[part][batch][K][Cout]
 #pragma unroll
   for (int j = 0; j < NI; ++j) {
     const int co = n0 + wn * (BN / 2) + j * 32 + l31;
@@ -883,6 +886,67 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ 
       const int t = tap9 * U2 + ph;
       const size_t o = ((size_t)co * cinL + (size_t)c * U2 + ph) * KK + tap9;
       gw[o] += tile[(t * 8 + c_local) * 33 + colw];
+    }
+  }
+}
+
+// Winograd weight gradient, last stage: slabs[part][xi][k][co] hold dU = sum_t V^T dM per transform point xi.
+// dg (3x3) = G^T dU G is the adjoint of U = G g G^T; the sum over parts runs in fixed order first.  Block layout and
+// the coalesced OIHW read-modify-write are those of k_wgrad_reduce (32 co x 8 c x all taps through LDS).
+__global__ __launch_bounds__(256) void k_wino_wgrad_reduce(const float* __restrict__ slabs, float* __restrict__ gw, ConvP p,
+                                                           int Cin, int ups, int cin_log, int cout_log) {
+  extern __shared__ __attribute__((aligned(16))) float tile[];
+  const int U2 = ups * ups, KK = 9;
+  const int co0 = blockIdx.x * 32, c0 = blockIdx.y * 8;
+  const int cl_ = threadIdx.x >> 5, col = threadIdx.x & 31;
+  const size_t plane = (size_t)p.nbatch * p.K * p.Cout;          // one part: [16][Kc][Cout]
+  {
+    const int c = c0 + cl_, co = co0 + col;
+    const bool ok = c < Cin && co < p.Cout;
+    for (int ph = 0; ph < U2; ++ph) {
+      float s[16];
+#pragma unroll
+      for (int xi = 0; xi < 16; ++xi) {
+        float a = 0.f;
+        if (ok) {
+          const int R = xi * p.K + ph * Cin + c;
+          const int nz = sk_parts(p, R, co);
+          const size_t idx = (size_t)R * p.Cout + co;
+          for (int z = 0; z < nz; ++z) a += slabs[(size_t)z * plane + idx];
+        }
+        s[xi] = a;
+      }
+      float h[3][4];
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        h[0][b] = s[0 + b] + 0.5f * (s[4 + b] + s[8 + b]);
+        h[1][b] = 0.5f * (s[4 + b] - s[8 + b]);
+        h[2][b] = 0.5f * (s[4 + b] + s[8 + b]) + s[12 + b];
+      }
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        const float d0 = h[a][0] + 0.5f * (h[a][1] + h[a][2]);
+        const float d1 = 0.5f * (h[a][1] - h[a][2]);
+        const float d2 = 0.5f * (h[a][1] + h[a][2]) + h[a][3];
+        tile[(((a * 3 + 0) * U2 + ph) * 8 + cl_) * 33 + col] = d0;
+        tile[(((a * 3 + 1) * U2 + ph) * 8 + cl_) * 33 + col] = d1;
+        tile[(((a * 3 + 2) * U2 + ph) * 8 + cl_) * 33 + col] = d2;
+      }
+    }
+  }
+  __syncthreads();
+  const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int cinL = cin_log * U2;
+  const int run = 8 * U2 * KK;
+  for (int j = 0; j < 8; ++j) {
+    const int colw = wid * 8 + j, co = co0 + colw;
+    if (co >= cout_log) continue;
+    for (int q = lane; q < run; q += 64) {
+      const int clq = q / KK, tap9 = q - clq * KK;
+      const int c_local = clq / U2, ph = clq - c_local * U2;
+      const int c = c0 + c_local;
+      if (c >= cin_log) continue;
+      gw[((size_t)co * cinL + (size_t)c * U2 + ph) * KK + tap9] += tile[((tap9 * U2 + ph) * 8 + c_local) * 33 + colw];
     }
   }
 }
@@ -1054,7 +1118,7 @@ static void fill_params(const ConvGeom& g, ConvP& p) {
   p.Hc = p.Wc = p.Mc = p.NB = 0;
   p.fd_hcwc = make_fastdiv(1); p.fd_wc = make_fastdiv(1);
   p.nbatch = 1; p.a_bstride = p.b_bstride = 0; p.out_bstride = 0;
-  p.ktiles_total = 0; p.sk_len = 1; p.sk_units = 0; p.sk_ntn = 1; p.sk_bm_shift = p.sk_bn_shift = 7;
+  p.ktiles_total = 0; p.sk_len = 1; p.sk_units = 0; p.sk_ntn = 1; p.sk_bm_shift = p.sk_bn_shift = 7; p.sk_ntr_pb = 1 << 30;
   p.fd_sklen = make_fastdiv(1);
   p.ksplit = 1; p.kt_per = 0; p.slab = nullptr; p.adjoint = 0; p.src_pitch = g.Cout;
   p.a_bytes = p.b_bytes = 0; p.dbl_mirror = 0;
@@ -1265,7 +1329,7 @@ extern "C" int vcg_conv_dgrad(const float* dy, const float* wf, float* dx, const
 // a resident workgroup per tile shape (measured on the D/R/U layers), plus the partial-tile write + read at
 // ~3 TB/s; every workgroup boundary that falls inside a tile adds one partial.
 struct WgradPlan { int bm, bn, grid, len, parts, total, ntr, ntn; };
-static WgradPlan wgrad_plan(const ConvGeom& g) {
+static WgradPlan wgrad_plan(const ConvGeom& g, int batches = 1) {
   WgradPlan best_p = {};
   const int total = (g.M + BK - 1) / BK;
   struct Cand { int bm, bn, resident; double t_step; };
@@ -1283,7 +1347,8 @@ static WgradPlan wgrad_plan(const ConvGeom& g) {
     if (c.bn == 128 && g.Cout <= 64) continue;
     if (c.bm >= 128 && g.K <= 64) continue;
     if (c.bm == 256 && g.K < 512) continue;
-    const int ntr = (g.K + c.bm - 1) / c.bm, ntn = (g.Cout + c.bn - 1) / c.bn;
+    if (batches > 1 && g.K % c.bm) continue;               // batched: the row tiles of batch z follow those of z-1
+    const int ntr = ((g.K + c.bm - 1) / c.bm) * batches, ntn = (g.Cout + c.bn - 1) / c.bn;
     const long long tiles = (long long)ntr * ntn, units = tiles * total;
     if (units >= (1LL << 30)) continue;
     const long long slots = 256LL * c.resident;
@@ -1322,18 +1387,62 @@ static void colsum_plan(const ConvGeom& g, int& tc, int& cgroups, int& rows, int
 static bool wgrad_swapped_ok(const ConvGeom& g);
 static ConvGeom swapped_geom(const ConvGeom& g);
 
+// Winograd weight gradient core (conv_wino.hip provides V = B^T x B and dM = A dy A^T): the 16 reductions
+// dU[xi] = V[xi]^T dM[xi] over the T tiles run as ONE stream-K launch of the wgrad kernel (a 1x1 "convolution" whose
+// row tiles enumerate (xi, k-tile)), then k_wino_wgrad_reduce transforms back and accumulates into the OIHW gradient.
+static ConvGeom wino_gemm_geom(const ConvGeom& g, int T) {
+  ConvGeom q = {};
+  q.N = 1; q.H = 1; q.W = T; q.Cin = g.ups * g.ups * g.Cin; q.Cout = g.Cout; q.KH = q.KW = 1; q.stride = 1; q.pad = 0;
+  q.reflect = 0; q.ups = 1; q.act = VCG_ACT_NONE; q.cin_log = q.Cin; q.cout_log = g.Cout;
+  q.Hl = 1; q.Wl = T; q.Ho = 1; q.Wo = T; q.M = T; q.K = q.Cin; q.taps = 1;
+  return q;
+}
+size_t vcg_wino_wgrad_core_workspace(const ConvGeom& g, int T) {
+  const ConvGeom q = wino_gemm_geom(g, T);
+  const WgradPlan wp = wgrad_plan(q, 16);
+  return (size_t)wp.parts * 16 * q.K * q.Cout * sizeof(float) + 256;
+}
+int vcg_wino_wgrad_core(const ConvGeom& g, const float* V, const float* dM, int T, float* gw_oihw, void* ws, size_t ws_bytes,
+                        hipStream_t st) {
+  const ConvGeom q = wino_gemm_geom(g, T);
+  const WgradPlan wp = wgrad_plan(q, 16);
+  VCG_CHECK_ARG(wp.grid > 0, "vcg_conv_wgrad: no launch plan for the Winograd path");
+  VCG_CHECK_ARG(ws_bytes >= vcg_wino_wgrad_core_workspace(g, T), "vcg_conv_wgrad: Winograd slab workspace too small");
+  ConvP p; fill_params(q, p);
+  p.a = V; p.b = dM; p.out = (float*)ws;
+  p.a_bytes = (uint32_t)((size_t)T * q.K * 4); p.b_bytes = (uint32_t)((size_t)T * q.Cout * 4);
+  p.nbatch = 16; p.a_bstride = (uint32_t)((size_t)T * q.K); p.b_bstride = (uint32_t)((size_t)T * q.Cout);
+  p.ktiles_total = wp.total; p.sk_len = wp.len; p.sk_units = wp.ntr * wp.ntn * wp.total; p.sk_ntn = wp.ntn;
+  p.sk_bm_shift = wp.bm == 256 ? 8 : wp.bm == 128 ? 7 : 6; p.sk_bn_shift = wp.bn == 128 ? 7 : 6;
+  p.sk_ntr_pb = wp.ntr / 16;
+  p.fd_sklen = make_fastdiv((uint32_t)wp.len);
+  dim3 grid(wp.grid);
+  if (wp.bm == 128 && wp.bn == 128) hipLaunchKernelGGL((k_conv_wgrad<128, 128>), grid, dim3(256), 0, st, p);
+  else if (wp.bm == 128 && wp.bn == 64) hipLaunchKernelGGL((k_conv_wgrad<128, 64>), grid, dim3(256), 0, st, p);
+  else if (wp.bm == 64 && wp.bn == 128) hipLaunchKernelGGL((k_conv_wgrad<64, 128>), grid, dim3(256), 0, st, p);
+  else hipLaunchKernelGGL((k_conv_wgrad<64, 64>), grid, dim3(256), 0, st, p);
+  VCG_LAUNCH_CHECK("vcg_conv_wgrad(winograd gemm)");
+  const int U2 = g.ups * g.ups;
+  const size_t lds = (size_t)9 * U2 * 8 * 33 * sizeof(float);
+  hipLaunchKernelGGL(k_wino_wgrad_reduce, dim3((g.Cout + 31) / 32, (g.Cin + 7) / 8), dim3(256), lds, st, (const float*)ws,
+                     gw_oihw, p, g.Cin, g.ups, g.cin_log, g.cout_log);
+  VCG_LAUNCH_CHECK("vcg_conv_wgrad(winograd reduce)");
+  return 0;
+}
+
 extern "C" size_t vcg_conv_wgrad_workspace(const int32_t* cd) {
   ConvGeom g;
   if (vcg_conv_geom(cd, &g, "vcg_conv_wgrad_workspace")) return 0;
   const ConvGeom gorig = g;
+  int tc, cgroups, rows, nchunk;
+  colsum_plan(gorig, tc, cgroups, rows, nchunk);
+  size_t cols = (size_t)nchunk * gorig.Cout * sizeof(float);
+  if (vcg_wino_wgrad_ok(g)) return ((vcg_wino_wgrad_workspace(g) + 255) / 256) * 256 + cols + 1024;
   if (wgrad_swapped_ok(g)) g = swapped_geom(g);
   const WgradPlan wp = wgrad_plan(g);
   const int nsplit = wp.parts;
   size_t slabs = (size_t)nsplit * g.K * g.Cout * sizeof(float);
   size_t groups = (size_t)16 * g.K * g.Cout * sizeof(float);     // k_slab_sum output (used when nsplit > 8)
-  int tc, cgroups, rows, nchunk;
-  colsum_plan(gorig, tc, cgroups, rows, nchunk);
-  size_t cols = (size_t)nchunk * gorig.Cout * sizeof(float);
   return slabs + groups + cols + 1024;
 }
 
@@ -1350,6 +1459,16 @@ static ConvGeom swapped_geom(const ConvGeom& g) {
   return s;
 }
 
+static int launch_colsum(const ConvGeom& gorig, const float* dy, float* gbias, float* part, hipStream_t st) {
+  int tc, cgroups, rows, nchunk;
+  colsum_plan(gorig, tc, cgroups, rows, nchunk);
+  hipLaunchKernelGGL(k_colsum_partial, dim3(cgroups, nchunk), dim3(256), 0, st, dy, part, gorig.M, gorig.Cout, rows, tc);
+  hipLaunchKernelGGL(k_colsum_final, dim3((gorig.cout_log + 7) / 8), dim3(256), 0, st, (const float*)part, gbias,
+                     gorig.Cout, nchunk, gorig.cout_log);
+  VCG_LAUNCH_CHECK("vcg_conv_wgrad(bias)");
+  return 0;
+}
+
 extern "C" int vcg_conv_wgrad(const float* x, const float* dy, float* gw_oihw, float* gbias,
                               const int32_t* cd, void* ws, size_t ws_bytes, void* stream) {
   ConvGeom g;
@@ -1357,6 +1476,12 @@ extern "C" int vcg_conv_wgrad(const float* x, const float* dy, float* gw_oihw, f
   VCG_CHECK_ARG(x && dy && gw_oihw && ws, "vcg_conv_wgrad: null pointer");
   size_t need = vcg_conv_wgrad_workspace(cd);
   VCG_CHECK_ARG(ws_bytes >= need, "vcg_conv_wgrad: workspace %zu < %zu", ws_bytes, need);
+  if (vcg_wino_wgrad_ok(g)) {
+    const size_t wbytes = vcg_wino_wgrad_workspace(g);
+    if (vcg_wino_wgrad(g, x, dy, gw_oihw, ws, wbytes, (hipStream_t)stream)) return -2;
+    if (gbias) return launch_colsum(g, dy, gbias, (float*)((char*)ws + ((wbytes + 255) / 256) * 256), (hipStream_t)stream);
+    return 0;
+  }
   const bool swapped = wgrad_swapped_ok(g);
   const ConvGeom gorig = g;
   if (swapped) g = swapped_geom(g);
@@ -1413,12 +1538,7 @@ extern "C" int vcg_conv_wgrad(const float* x, const float* dy, float* gw_oihw, f
   VCG_LAUNCH_CHECK("vcg_conv_wgrad(reduce)");
   if (gbias) {
     float* part = (float*)((char*)ws + slab_bytes + (((size_t)16 * totalw * sizeof(float) + 255) / 256) * 256);
-    int tc, cgroups, rows, nchunk;
-    colsum_plan(gorig, tc, cgroups, rows, nchunk);
-    hipLaunchKernelGGL(k_colsum_partial, dim3(cgroups, nchunk), dim3(256), 0, st, dy, part, gorig.M, gorig.Cout, rows, tc);
-    hipLaunchKernelGGL(k_colsum_final, dim3((gorig.cout_log + 7) / 8), dim3(256), 0, st, (const float*)part, gbias,
-                       gorig.Cout, nchunk, gorig.cout_log);
-    VCG_LAUNCH_CHECK("vcg_conv_wgrad(bias)");
+    return launch_colsum(gorig, dy, gbias, part, st);
   }
   return 0;
 }

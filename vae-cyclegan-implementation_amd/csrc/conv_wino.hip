@@ -168,6 +168,40 @@ __global__ __launch_bounds__(256) void k_wino_weight(const float* __restrict__ w
   }
 }
 
+// dM = A dy A^T (the adjoint of y = A^T M A), A = [[1, 0], [1, 1], [1, -1], [0, -1]]; one thread: one tile x 4 channels
+__global__ __launch_bounds__(256) void k_wino_dy(const float* __restrict__ dy, float* __restrict__ dm, WinoP p) {
+  const uint32_t c4n = (uint32_t)p.Cout / 4;
+  const size_t total = (size_t)p.T * c4n;
+  const size_t plane = (size_t)p.T * p.Cout;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    const uint32_t t = (uint32_t)(idx / c4n);
+    const int co = (int)(idx - (size_t)t * c4n) * 4;
+    const uint32_t n = fd_div(t, p.fd_thtw);
+    const uint32_t rem = t - n * (uint32_t)(p.th * p.tw);
+    const uint32_t ty = fd_div(rem, p.fd_tw);
+    const int tx = (int)(rem - ty * (uint32_t)p.tw);
+    const float* base = dy + (((size_t)n * p.Hl + 2 * ty) * p.Wl + 2 * tx) * p.Cout + co;
+    const float4 y00 = *reinterpret_cast<const float4*>(base);
+    const float4 y01 = *reinterpret_cast<const float4*>(base + p.Cout);
+    const float4 y10 = *reinterpret_cast<const float4*>(base + (size_t)p.Wl * p.Cout);
+    const float4 y11 = *reinterpret_cast<const float4*>(base + (size_t)p.Wl * p.Cout + p.Cout);
+    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 z[4][2];
+    z[0][0] = y00;              z[0][1] = y01;
+    z[1][0] = f4sum(y00, y10);  z[1][1] = f4sum(y01, y11);
+    z[2][0] = f4sub(y00, y10);  z[2][1] = f4sub(y01, y11);
+    z[3][0] = f4sub(zero, y10); z[3][1] = f4sub(zero, y11);
+    float* mb = dm + (size_t)t * p.Cout + co;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      *reinterpret_cast<float4*>(mb + (size_t)(a * 4 + 0) * plane) = z[a][0];
+      *reinterpret_cast<float4*>(mb + (size_t)(a * 4 + 1) * plane) = f4sum(z[a][0], z[a][1]);
+      *reinterpret_cast<float4*>(mb + (size_t)(a * 4 + 2) * plane) = f4sub(z[a][0], z[a][1]);
+      *reinterpret_cast<float4*>(mb + (size_t)(a * 4 + 3) * plane) = f4sub(zero, z[a][1]);
+    }
+  }
+}
+
 // ------------------------------------------------------------------ host side
 static int wino_blocks(size_t work) {
   size_t b = (work + 255) / 256;
@@ -203,17 +237,48 @@ int vcg_wino_weight(const ConvGeom& g, const float* w_oihw, float* u, hipStream_
   return 0;
 }
 
-int vcg_wino_fwd(const ConvGeom& g, const float* x, const float* u, const float* bias, float* y, void* ws, size_t ws_bytes,
-                 hipStream_t st) {
-  VCG_CHECK_ARG(ws && ws_bytes >= vcg_wino_fwd_workspace(g), "vcg_conv_fwd: workspace too small for the Winograd path (%zu)",
-                ws_bytes);
+static WinoP wino_params(const ConvGeom& g) {
   WinoP p;
+  p.x = nullptr; p.v = nullptr; p.m = nullptr; p.bias = nullptr; p.y = nullptr;
   p.N = g.N; p.H = g.H; p.W = g.W; p.Cin = g.Cin; p.Cout = g.Cout; p.Hl = g.Hl; p.Wl = g.Wl; p.ups = g.ups;
   p.reflect = g.reflect; p.act = g.act; p.cout_log = g.cout_log;
   p.th = g.Ho / 2; p.tw = g.Wo / 2; p.T = g.N * p.th * p.tw; p.Kc = g.ups * g.ups * g.Cin;
   p.fd_k4 = make_fastdiv((uint32_t)p.Kc / 4); p.fd_tw = make_fastdiv((uint32_t)p.tw);
   p.fd_thtw = make_fastdiv((uint32_t)(p.th * p.tw)); p.fd_c4 = make_fastdiv((uint32_t)g.Cin / 4);
   p.fd_co4 = make_fastdiv((uint32_t)g.Cout / 4);
+  return p;
+}
+
+// weight gradient: V = B^T x B (recomputed: keeping the forward's copy would hold 4x every activation), dM = A dy A^T,
+// then the batched reduction over tiles and the back-transform (conv_igemm.hip)
+bool vcg_wino_wgrad_ok(const ConvGeom& g) {
+  // the transforms move 16 T (Kc + Cout) floats each way while the GEMMs save ~ T Kc Cout multiplications: it pays
+  // from Kc Cout / (Kc + Cout) ~ 128 on (measured: 171 -> 1.46x, 85 -> 0.9x)
+  const long long kc = (long long)g.ups * g.ups * g.Cin;
+  return vcg_wino_fwd_ok(g) && kc % 128 == 0 && kc * g.Cout >= 128 * (kc + g.Cout);
+}
+size_t vcg_wino_wgrad_workspace(const ConvGeom& g) {
+  const int T = g.N * (g.Ho / 2) * (g.Wo / 2);
+  return vcg_wino_fwd_workspace(g) + vcg_wino_wgrad_core_workspace(g, T);
+}
+int vcg_wino_wgrad(const ConvGeom& g, const float* x, const float* dy, float* gw_oihw, void* ws, size_t ws_bytes, hipStream_t st) {
+  VCG_CHECK_ARG(ws && ws_bytes >= vcg_wino_wgrad_workspace(g), "vcg_conv_wgrad: workspace too small for the Winograd path");
+  WinoP p = wino_params(g);
+  float* V = (float*)ws;
+  float* dM = V + (((size_t)16 * p.T * p.Kc + 63) / 64) * 64;
+  const size_t tbytes = vcg_wino_fwd_workspace(g);
+  p.x = x; p.v = V;
+  hipLaunchKernelGGL(k_wino_in, dim3(wino_blocks((size_t)p.T * p.Kc / 4)), dim3(256), 0, st, p);
+  hipLaunchKernelGGL(k_wino_dy, dim3(wino_blocks((size_t)p.T * g.Cout / 4)), dim3(256), 0, st, dy, dM, p);
+  VCG_LAUNCH_CHECK("vcg_conv_wgrad(winograd transforms)");
+  return vcg_wino_wgrad_core(g, V, dM, p.T, gw_oihw, (char*)ws + tbytes, ws_bytes - tbytes, st);
+}
+
+int vcg_wino_fwd(const ConvGeom& g, const float* x, const float* u, const float* bias, float* y, void* ws, size_t ws_bytes,
+                 hipStream_t st) {
+  VCG_CHECK_ARG(ws && ws_bytes >= vcg_wino_fwd_workspace(g), "vcg_conv_fwd: workspace too small for the Winograd path (%zu)",
+                ws_bytes);
+  WinoP p = wino_params(g);
   float* V = (float*)ws;
   float* M = V + (((size_t)16 * p.T * p.Kc + 63) / 64) * 64;
   p.x = x; p.v = V; p.m = M; p.bias = bias; p.y = y;
