@@ -1192,14 +1192,17 @@ static size_t wf_floats(const ConvGeom& g) { return (((size_t)g.K * g.Cout + 63)
 extern "C" size_t vcg_pack_weight_floats(const int32_t* cd) {
   ConvGeom g;
   if (vcg_conv_geom(cd, &g, "vcg_pack_weight_floats")) return 0;
-  return wf_floats(g) + (vcg_wino_weight_ok(g) ? vcg_wino_weight_floats(g) : 0);
+  return wf_floats(g) + (vcg_wino_weight_ok(g) ? 2 * vcg_wino_weight_floats(g) : 0);   // + U (forward) + Ud (data gradient)
 }
 
 extern "C" int vcg_pack_weight(const float* w_oihw, float* wf, const int32_t* cd, void* stream) {
   ConvGeom g;
   if (vcg_conv_geom(cd, &g, "vcg_pack_weight")) return -1;
   VCG_CHECK_ARG(w_oihw && wf, "vcg_pack_weight: null pointer");
-  if (vcg_wino_weight_ok(g) && vcg_wino_weight(g, w_oihw, wf + wf_floats(g), (hipStream_t)stream)) return -2;
+  if (vcg_wino_weight_ok(g)) {
+    if (vcg_wino_weight(g, w_oihw, wf + wf_floats(g), (hipStream_t)stream)) return -2;
+    if (vcg_wino_weight_dgrad(g, w_oihw, wf + wf_floats(g) + vcg_wino_weight_floats(g), (hipStream_t)stream)) return -2;
+  }
   ConvP p; fill_params(g, p);
   size_t total = (size_t)g.K * g.Cout;
   const int T = g.KH * g.KW * g.ups * g.ups;
@@ -1280,6 +1283,7 @@ extern "C" size_t vcg_conv_dgrad_workspace(const int32_t* cd) {
   if (vcg_conv_geom(cd, &g, "vcg_conv_dgrad_workspace")) return 0;
   if (g.Hl % g.stride || g.Wl % g.stride) return 0;
   if (vcg_thin_dgrad_ok(g)) return vcg_thin_dgrad_workspace(g);
+  if (vcg_wino_dgrad_ok(g)) return vcg_wino_dgrad_workspace(g);
   ConvP p; fill_params(g, p);
   int bm, bn, nsplit, kt_per;
   dgrad_setup(g, p, bm, bn, nsplit, kt_per);
@@ -1294,6 +1298,8 @@ extern "C" int vcg_conv_dgrad(const float* dy, const float* wf, float* dx, const
   VCG_CHECK_ARG(g.Hl % g.stride == 0 && g.Wl % g.stride == 0, "vcg_conv_dgrad: input %dx%d not divisible by stride", g.Hl, g.Wl);
   VCG_CHECK_ARG(g.stride == 1 || g.ups == 1, "vcg_conv_dgrad: stride 2 with ups 2 unsupported");
   if (vcg_thin_dgrad_ok(g)) return vcg_thin_dgrad(g, dy, wf, dx, ws, ws_bytes, (hipStream_t)stream);
+  if (vcg_wino_dgrad_ok(g))
+    return vcg_wino_dgrad(g, dy, wf + wf_floats(g) + vcg_wino_weight_floats(g), dx, ws, ws_bytes, (hipStream_t)stream);
   ConvP p; fill_params(g, p);
   p.a = dy; p.b = wf; p.out = dx;
   {

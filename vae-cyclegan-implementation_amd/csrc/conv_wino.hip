@@ -25,6 +25,7 @@ struct WinoP {
   float* y;
   int N, H, W, Cin, Cout, Hl, Wl, ups, reflect, act, cout_log;
   int th, tw, T, Kc;
+  int off;     // patch origin = 2 * tile - off: 1 (pad 1) forward, 2 for the data gradient over the padded domain
   FastDiv fd_k4, fd_tw, fd_thtw, fd_c4, fd_co4;
 };
 
@@ -49,13 +50,13 @@ __global__ __launch_bounds__(256) void k_wino_in(WinoP p) {
     float4 d[4][4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      int ih = 2 * (int)ty - 1 + r;
+      int ih = 2 * (int)ty - p.off + r;
       bool okh = true;
       if (p.reflect) ih = reflect_idx(ih, p.Hl);
       else okh = ih >= 0 && ih < p.Hl;
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
-        int iw = 2 * tx - 1 + s;
+        int iw = 2 * tx - p.off + s;
         bool ok = okh;
         if (p.reflect) iw = reflect_idx(iw, p.Wl);
         else ok = ok && iw >= 0 && iw < p.Wl;
@@ -168,6 +169,107 @@ __global__ __launch_bounds__(256) void k_wino_weight(const float* __restrict__ w
   }
 }
 
+// Data gradient.  dxp = correlation of the zero-extended dy with the flipped kernel over the PADDED domain
+// (Hl + 2) x (Wl + 2); dx then folds the halo back (adjoint of the reflect padding; a plain crop for zero padding) and
+// scatters the unshuffle phases.  Ud[xi][co][k] = (G g' G^T)[xi] with g'[a][b] = w[co][k][2 - a][2 - b].
+// One thread per (co, k), k fastest: coalesced stores, 36-byte OIHW reads that are contiguous along k for ups == 1.
+__global__ __launch_bounds__(256) void k_wino_weight_dgrad(const float* __restrict__ w, float* __restrict__ u, int Cin, int Cout,
+                                                           int ups, int cin_log, int cout_log) {
+  const int U2 = ups * ups, Kc = U2 * Cin;
+  const size_t total = (size_t)Kc * Cout;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    const int co = (int)(idx / Kc), k = (int)(idx - (size_t)co * Kc);
+    const int ph = k / Cin, c = k - ph * Cin;
+    float g[3][3];
+    const bool ok = co < cout_log && c < cin_log;
+    const float* wp = w + ((size_t)co * (cin_log * U2) + (size_t)c * U2 + ph) * 9;
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+      for (int b = 0; b < 3; ++b) g[a][b] = ok ? wp[(2 - a) * 3 + (2 - b)] : 0.f;
+    float h[4][3];
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+      h[0][b] = g[0][b];
+      h[1][b] = 0.5f * (g[0][b] + g[1][b] + g[2][b]);
+      h[2][b] = 0.5f * (g[0][b] - g[1][b] + g[2][b]);
+      h[3][b] = g[2][b];
+    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      u[(size_t)(a * 4 + 0) * total + idx] = h[a][0];
+      u[(size_t)(a * 4 + 1) * total + idx] = 0.5f * (h[a][0] + h[a][1] + h[a][2]);
+      u[(size_t)(a * 4 + 2) * total + idx] = 0.5f * (h[a][0] - h[a][1] + h[a][2]);
+      u[(size_t)(a * 4 + 3) * total + idx] = h[a][2];
+    }
+  }
+}
+
+// output transform of the data-gradient GEMMs: one thread = one padded-domain tile x 4 k; writes dxp[n][qh][qw][k]
+__global__ __launch_bounds__(256) void k_wino_out_pad(const float* __restrict__ m, float* __restrict__ dxp, WinoP p) {
+  const uint32_t k4n = (uint32_t)p.Kc / 4;
+  const size_t total = (size_t)p.T * k4n;
+  const size_t plane = (size_t)p.T * p.Kc;
+  const int Hp = 2 * p.th, Wp = 2 * p.tw;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    const uint32_t t = (uint32_t)(idx / k4n);
+    const int k = (int)(idx - (size_t)t * k4n) * 4;
+    const uint32_t n = fd_div(t, p.fd_thtw);
+    const uint32_t rem = t - n * (uint32_t)(p.th * p.tw);
+    const uint32_t ty = fd_div(rem, p.fd_tw);
+    const int tx = (int)(rem - ty * (uint32_t)p.tw);
+    const float* mb = m + (size_t)t * p.Kc + k;
+    float4 s0[4], s1[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const float4 m0 = *reinterpret_cast<const float4*>(mb + (size_t)(0 + b) * plane);
+      const float4 m1 = *reinterpret_cast<const float4*>(mb + (size_t)(4 + b) * plane);
+      const float4 m2 = *reinterpret_cast<const float4*>(mb + (size_t)(8 + b) * plane);
+      const float4 m3 = *reinterpret_cast<const float4*>(mb + (size_t)(12 + b) * plane);
+      s0[b] = f4sum(f4sum(m0, m1), m2);
+      s1[b] = f4sub(f4sub(m1, m2), m3);
+    }
+    float* o = dxp + (((size_t)n * Hp + 2 * ty) * Wp + 2 * tx) * p.Kc + k;
+    *reinterpret_cast<float4*>(o) = f4sum(f4sum(s0[0], s0[1]), s0[2]);
+    *reinterpret_cast<float4*>(o + p.Kc) = f4sub(f4sub(s0[1], s0[2]), s0[3]);
+    *reinterpret_cast<float4*>(o + (size_t)Wp * p.Kc) = f4sum(f4sum(s1[0], s1[1]), s1[2]);
+    *reinterpret_cast<float4*>(o + (size_t)Wp * p.Kc + p.Kc) = f4sub(f4sub(s1[1], s1[2]), s1[3]);
+  }
+}
+
+// dx[n][h*ups+i][w*ups+j][c] = sum over padded coordinates (qh, qw) that the padding maps onto (h, w) of dxp[n][qh][qw][(i,j,c)]
+// pad = 1: q = h + 1 always; with reflect padding the halo row q = 0 lands on h = 1 and q = Hl + 1 on h = Hl - 2.
+__global__ __launch_bounds__(256) void k_wino_fold(const float* __restrict__ dxp, float* __restrict__ dx, int N, int Hl, int Wl,
+                                                   int Cin, int ups, int reflect) {
+  const int U2 = ups * ups, Kc = U2 * Cin, c4n = Cin / 4;
+  const int Hp = Hl + 2, Wp = Wl + 2, W = Wl * ups;
+  const size_t total = (size_t)N * Hl * Wl * U2 * c4n;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(idx % c4n) * 4;
+    size_t r = idx / c4n;
+    const int ph = (int)(r % U2); r /= U2;
+    const int w = (int)(r % Wl); r /= Wl;
+    const int h = (int)(r % Hl);
+    const int n = (int)(r / Hl);
+    int qh[2], qw[2], nh = 1, nw = 1;
+    qh[0] = h + 1; qw[0] = w + 1;
+    if (reflect) {
+      if (h == 1) qh[nh++] = 0;
+      if (h == Hl - 2) qh[nh++] = Hl + 1;        // Hl >= 4: h == 1 and h == Hl - 2 are different rows
+      if (w == 1) qw[nw++] = 0;
+      if (w == Wl - 2) qw[nw++] = Wl + 1;
+    }
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int a = 0; a < nh; ++a)
+      for (int b = 0; b < nw; ++b) {
+        const float4 v = *reinterpret_cast<const float4*>(dxp + (((size_t)n * Hp + qh[a]) * Wp + qw[b]) * Kc + ph * Cin + c);
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+      }
+    const int pi = ph >> 1, pj = ph & 1;
+    *reinterpret_cast<float4*>(dx + (((size_t)n * Hl * ups + h * ups + pi) * W + (w * ups + pj)) * Cin + c) = s;
+  }
+}
+
 // dM = A dy A^T (the adjoint of y = A^T M A), A = [[1, 0], [1, 1], [1, -1], [0, -1]]; one thread: one tile x 4 channels
 __global__ __launch_bounds__(256) void k_wino_dy(const float* __restrict__ dy, float* __restrict__ dm, WinoP p) {
   const uint32_t c4n = (uint32_t)p.Cout / 4;
@@ -246,6 +348,7 @@ static WinoP wino_params(const ConvGeom& g) {
   p.fd_k4 = make_fastdiv((uint32_t)p.Kc / 4); p.fd_tw = make_fastdiv((uint32_t)p.tw);
   p.fd_thtw = make_fastdiv((uint32_t)(p.th * p.tw)); p.fd_c4 = make_fastdiv((uint32_t)g.Cin / 4);
   p.fd_co4 = make_fastdiv((uint32_t)g.Cout / 4);
+  p.off = 1;
   return p;
 }
 
@@ -272,6 +375,54 @@ int vcg_wino_wgrad(const ConvGeom& g, const float* x, const float* dy, float* gw
   hipLaunchKernelGGL(k_wino_dy, dim3(wino_blocks((size_t)p.T * g.Cout / 4)), dim3(256), 0, st, dy, dM, p);
   VCG_LAUNCH_CHECK("vcg_conv_wgrad(winograd transforms)");
   return vcg_wino_wgrad_core(g, V, dM, p.T, gw_oihw, (char*)ws + tbytes, ws_bytes - tbytes, st);
+}
+
+// data gradient over the padded domain (see k_wino_weight_dgrad)
+bool vcg_wino_dgrad_ok(const ConvGeom& g) {
+  if (!vcg_wino_fwd_ok(g)) return false;
+  const long long kc = (long long)g.ups * g.ups * g.Cin;
+  if (kc * g.Cout < 128 * (kc + g.Cout)) return false;            // same break-even as the weight gradient
+  const unsigned long long Tp = (unsigned long long)g.N * (g.Ho / 2 + 1) * (g.Wo / 2 + 1);
+  return Tp * kc * 4 < (1ull << 31) && Tp * g.Cout * 4 < (1ull << 31) && Tp * g.Cout * 16 < (1ull << 32);
+}
+size_t vcg_wino_dgrad_workspace(const ConvGeom& g) {
+  const size_t Tp = (size_t)g.N * (g.Ho / 2 + 1) * (g.Wo / 2 + 1);
+  const size_t kc = (size_t)g.ups * g.ups * g.Cin;
+  return ((size_t)16 * Tp * (kc + g.Cout) + (size_t)g.N * (g.Ho + 2) * (g.Wo + 2) * kc) * sizeof(float) + 1024;
+}
+int vcg_wino_weight_dgrad(const ConvGeom& g, const float* w_oihw, float* ud, hipStream_t st) {
+  const size_t total = (size_t)g.ups * g.ups * g.Cin * g.Cout;
+  hipLaunchKernelGGL(k_wino_weight_dgrad, dim3(wino_blocks(total)), dim3(256), 0, st, w_oihw, ud, g.Cin, g.Cout, g.ups,
+                     g.cin_log, g.cout_log);
+  VCG_LAUNCH_CHECK("vcg_wino_weight_dgrad");
+  return 0;
+}
+int vcg_wino_dgrad(const ConvGeom& g, const float* dy, const float* ud, float* dx, void* ws, size_t ws_bytes, hipStream_t st) {
+  VCG_CHECK_ARG(ws && ws_bytes >= vcg_wino_dgrad_workspace(g), "vcg_conv_dgrad: workspace too small for the Winograd path");
+  const int kc = g.ups * g.ups * g.Cin;
+  // input transform of dy: a plain (N, Ho, Wo, Cout) image, zero extension, patch origin 2 * tile - 2
+  WinoP p;
+  p.x = dy; p.bias = nullptr; p.y = nullptr;
+  p.N = g.N; p.H = g.Ho; p.W = g.Wo; p.Cin = g.Cout; p.Cout = kc; p.Hl = g.Ho; p.Wl = g.Wo; p.ups = 1;
+  p.reflect = 0; p.act = VCG_ACT_NONE; p.cout_log = kc;
+  p.th = g.Ho / 2 + 1; p.tw = g.Wo / 2 + 1; p.T = g.N * p.th * p.tw; p.Kc = g.Cout; p.off = 2;
+  p.fd_k4 = make_fastdiv((uint32_t)p.Kc / 4); p.fd_tw = make_fastdiv((uint32_t)p.tw);
+  p.fd_thtw = make_fastdiv((uint32_t)(p.th * p.tw)); p.fd_c4 = make_fastdiv((uint32_t)p.Cin / 4);
+  p.fd_co4 = make_fastdiv((uint32_t)kc / 4);
+  float* V = (float*)ws;
+  float* M = V + (((size_t)16 * p.T * g.Cout + 63) / 64) * 64;
+  float* dxp = M + (((size_t)16 * p.T * kc + 63) / 64) * 64;
+  p.v = V; p.m = M;
+  hipLaunchKernelGGL(k_wino_in, dim3(wino_blocks((size_t)p.T * g.Cout / 4)), dim3(256), 0, st, p);
+  VCG_LAUNCH_CHECK("vcg_conv_dgrad(winograd input transform)");
+  if (vcg_gemm_batched(V, ud, M, p.T, g.Cout, kc, 16, st)) return -2;
+  WinoP q = p;
+  q.Kc = kc;                                      // the output side: k columns
+  hipLaunchKernelGGL(k_wino_out_pad, dim3(wino_blocks((size_t)p.T * kc / 4)), dim3(256), 0, st, (const float*)M, dxp, q);
+  hipLaunchKernelGGL(k_wino_fold, dim3(wino_blocks((size_t)g.N * g.Hl * g.Wl * kc / 4)), dim3(256), 0, st, (const float*)dxp, dx,
+                     g.N, g.Hl, g.Wl, g.Cin, g.ups, g.reflect);
+  VCG_LAUNCH_CHECK("vcg_conv_dgrad(winograd output transform)");
+  return 0;
 }
 
 int vcg_wino_fwd(const ConvGeom& g, const float* x, const float* u, const float* bias, float* y, void* ws, size_t ws_bytes,

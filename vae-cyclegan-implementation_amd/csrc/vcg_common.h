@@ -123,3 +123,7 @@ int vcg_wino_wgrad(const ConvGeom& g, const float* x, const float* dy, float* gw
 size_t vcg_wino_wgrad_core_workspace(const ConvGeom& g, int T);
 int vcg_wino_wgrad_core(const ConvGeom& g, const float* V, const float* dM, int T, float* gw_oihw, void* ws, size_t ws_bytes,
                         hipStream_t st);
+bool vcg_wino_dgrad_ok(const ConvGeom& g);
+size_t vcg_wino_dgrad_workspace(const ConvGeom& g);
+int vcg_wino_weight_dgrad(const ConvGeom& g, const float* w_oihw, float* ud, hipStream_t st);
+int vcg_wino_dgrad(const ConvGeom& g, const float* dy, const float* ud, float* dx, void* ws, size_t ws_bytes, hipStream_t st);
