@@ -176,10 +176,18 @@ def measure_roofline(pkg, model, pool, wl, B, S, latent, ms_per_step):
                    "tflops": round(v[0] / max(v[1], 1e-12) / 1e12, 2) if v[0] else None} for k, v in sorted(fam.items())}
     # necessary conv FLOPs of one step: fwd + bwd-data + bwd-weight, nothing redundant
     step_flops = sum(v[0] for v in conv.values()) / 2
+    # one "launch" = one C-ABI call of that family; these are the device kernels it issues (rocprofv3 names)
+    symbols = {"conv_fwd": ["k_conv_fwd", "k_wino_in", "k_wino_out", "k_conv_thin<0>", "k_splitk_finish"],
+               "conv_dgrad": ["k_conv_dgrad", "k_wino_in", "k_conv_fwd (batched)", "k_wino_out_pad", "k_wino_fold", "k_conv_thin<1>",
+                              "k_fold_pad", "k_splitk_finish"],
+               "conv_wgrad": ["k_conv_wgrad", "k_wino_in", "k_wino_dy", "k_wino_wgrad_reduce", "k_wgrad_reduce", "k_wgrad_scatter",
+                              "k_slab_sum", "k_colsum_partial", "k_colsum_final"]}
     return {
         "roofline": {"bound": "mfma", "kernel": dom, "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
-                     "launches": n // 2, "avg_launch_ms": round(secs / n * 1e3, 4)},
+                     "launches": n // 2, "avg_launch_ms": round(secs / n * 1e3, 4),
+                     "flops_counted": "direct-convolution 2*M*Cout*K per call (the Winograd layers execute 2.25x fewer)",
+                     "device_kernels": symbols.get(dom, [])},
         "step_conv_tflops": round(step_flops / (ms_per_step * 1e-3) / 1e12, 2),
         "step_conv_frac_of_peak": round(step_flops / (ms_per_step * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
         "kernels": kernels,

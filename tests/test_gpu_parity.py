@@ -158,6 +158,12 @@ ORACLE_CONV_CASES = [
     ("S", (8, 8), {}, (2, 8, 3, 3)),                  # 3x3 with pad 1: the centre pixel has a top AND a bottom mirror
     ("R", (16,), {}, (1, 16, 3, 5)),
     ("D", (8, 8), {}, (3, 8, 4, 4)),                  # bottleneck of a 64x64 input: 2x2 output maps
+    # Winograd F(2x2,3x3) in all three directions (Kc*Cout/(Kc+Cout) >= 128, even maps); the cases above with
+    # Kc >= 128 and Cout >= 64 take it in the forward pass only
+    ("S", (256, 256), {}, (2, 256, 8, 8)),
+    ("D", (64, 256), {}, (1, 64, 16, 16)),            # + folded PixelUnshuffle: Kc = 256
+    ("R", (256,), {}, (1, 256, 6, 10)),               # non-square, two convs back to back, residual
+    ("S", (256, 256), {}, (1, 256, 5, 7)),            # odd map: same channels fall back to the direct kernels
 ]
 
 
