@@ -231,14 +231,16 @@ __device__ __forceinline__ float4 adjoint_extras(const ConvP& p, const float* __
 }
 
 // ------------------------------------------------------------------ forward
-template <int BM, int BN>
+// WN = wave columns: 2 (waves 2 x 2) or, for 32-column tiles, 1 (waves 4 x 1, each 32 rows x 32 columns)
+template <int BM, int BN, int WN = 2>
 __global__ __launch_bounds__(256, 2) void k_conv_fwd(ConvP p) {   // 2 waves/SIMD: acc + tot must fit 256 regs
   VCG_STAMP_AT(0);
-  constexpr int MI = BM / 64, NI = BN / 64, AR = BM / 32, BE = BN / 32;
+  constexpr int WM = 4 / WN;
+  constexpr int MI = BM / (32 * WM), NI = BN / (32 * WN), AR = BM / 32, BE = BN / 32;
   __shared__ __attribute__((aligned(16))) float As[BM * AS_STRIDE];
   __shared__ __attribute__((aligned(16))) float Bs[BK * BN];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int wm = wid >> 1, wn = wid & 1, l31 = lane & 31, lh = lane >> 5;
+  const int wm = wid / WN, wn = wid % WN, l31 = lane & 31, lh = lane >> 5;
   const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
   const int a_row = tid >> 3, a_u = tid & 7;
 
@@ -350,8 +352,8 @@ __global__ __launch_bounds__(256, 2) void k_conv_fwd(ConvP p) {   // 2 waves/SIM
   for (int kt = kt0; kt < nkt; ++kt) {
     if (kt + 1 < nkt) load_tiles(kt + 1);
     mma_ktile<MI, NI>(
-        acc, [&](int kk, int i) { return As[(wm * (BM / 2) + i * 32 + l31) * AS_STRIDE + kk]; },
-        [&](int kk, int j) { return Bs[kk * BN + wn * (BN / 2) + j * 32 + l31]; }, lh);
+        acc, [&](int kk, int i) { return As[(wm * (BM / WM) + i * 32 + l31) * AS_STRIDE + kk]; },
+        [&](int kk, int j) { return Bs[kk * BN + wn * (BN / WN) + j * 32 + l31]; }, lh);
     if (((kt - kt0 + 1) & (FLUSH_TILES - 1)) == 0 && kt + 1 < nkt) flush_acc<MI, NI>(acc, tot);
     __syncthreads();
     if (kt + 1 < nkt) {
@@ -371,7 +373,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_fwd(ConvP p) {   // 2 waves/SIM
   const int act = p.ksplit > 1 ? VCG_ACT_NONE : p.act;
 #pragma unroll
   for (int j = 0; j < NI; ++j) {
-    const int co = n0 + wn * (BN / 2) + j * 32 + l31;
+    const int co = n0 + wn * (BN / WN) + j * 32 + l31;
     if (co >= p.Cout) continue;
     const float bv = (p.ksplit <= 1 && p.bias && co < p.cout_log) ? p.bias[co] : 0.f;
 #pragma unroll
@@ -379,7 +381,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_fwd(ConvP p) {   // 2 waves/SIM
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int row = (e & 3) + 8 * (e >> 2) + 4 * lh;
-        const int m = m0 + wm * (BM / 2) + i * 32 + row;
+        const int m = m0 + wm * (BM / WM) + i * 32 + row;
         if (m < p.M) dst[(size_t)m * p.Cout + co] = act_apply(acc[i][j][e] + bv, act);
       }
     }
@@ -1130,15 +1132,16 @@ static void fill_params(const ConvGeom& g, ConvP& p) {
 // tile and slice K across blockIdx.z instead of shrinking the tile: partial tiles go to fp32 slabs that
 // k_splitk_finish sums in a fixed order (+ bias + activation).
 static void gemm_plan(long long rows, long long cols, int nkt, bool allow_split, int& bm, int& bn, int& nsplit,
-                      int& kt_per, int batches = 1) {
+                      int& kt_per, int batches = 1, bool allow_bn32 = false) {
   // cost model (us): rounds of resident workgroups x K-steps per workgroup x time per K-step of that tile,
   // plus the slab write+read of a K-sliced launch.  Same constants as wgrad_plan.
   struct Cand { int bm, bn, resident; double t_step; };
-  const Cand cands[4] = {{128, 128, 2, 5.1}, {128, 64, 3, 4.7}, {64, 128, 3, 4.7}, {64, 64, 4, 4.8}};
+  const Cand cands[5] = {{128, 128, 2, 5.1}, {128, 64, 3, 4.7}, {64, 128, 3, 4.7}, {64, 64, 4, 4.8}, {128, 32, 4, 3.6}};
   double best = 1e30;
   bm = 64; bn = 64; nsplit = 1; kt_per = nkt;
-  for (int ci = 0; ci < 4; ++ci) {
+  for (int ci = 0; ci < 5; ++ci) {
     const Cand& c = cands[ci];
+    if (c.bn == 32 && !(allow_bn32 && cols <= 32)) continue;
     if (c.bn == 128 && cols <= 64) continue;
     if (c.bm == 128 && rows <= 64) continue;
     const long long tiles = ((rows + c.bm - 1) / c.bm) * ((cols + c.bn - 1) / c.bn) * batches;
@@ -1156,6 +1159,11 @@ static void gemm_plan(long long rows, long long cols, int nkt, bool allow_split,
   }
 }
 
+#define DISPATCH_FWD(bm, bn, grid, stream, p)                                                 \
+  do {                                                                                        \
+    if (bn == 32) hipLaunchKernelGGL((k_conv_fwd<128, 32, 1>), grid, dim3(256), 0, stream, p); \
+    else DISPATCH_TILE(k_conv_fwd, bm, bn, grid, stream, p);                                   \
+  } while (0)
 #define DISPATCH_TILE(KERNEL, bm, bn, grid, stream, p)                                        \
   do {                                                                                        \
     if (bm == 128 && bn == 128) hipLaunchKernelGGL((KERNEL<128, 128>), grid, dim3(256), 0, stream, p); \
@@ -1182,23 +1190,40 @@ int vcg_gemm_batched(const float* A, const float* B, float* C, int rows, int K, 
   int bm, bn, nsplit, kt_per;
   gemm_plan(rows, Ncols, (K + BK - 1) / BK, false, bm, bn, nsplit, kt_per, batches);
   dim3 grid((rows + bm - 1) / bm, (Ncols + bn - 1) / bn, batches);
-  DISPATCH_TILE(k_conv_fwd, bm, bn, grid, st, p);
+  DISPATCH_FWD(bm, bn, grid, st, p);
   VCG_LAUNCH_CHECK("vcg_gemm_batched");
   return 0;
 }
 
 // floats of the packed-weight buffer: Wf[K][Cout], then (3x3 stride-1 layers) the Winograd-transformed U[16][Kc][Cout]
 static size_t wf_floats(const ConvGeom& g) { return (((size_t)g.K * g.Cout + 63) / 64) * 64; }
+// the forward kernel on a caller-built geometry (no bias, no activation, no K slicing): conv_thin.hip's kw-folded path
+int vcg_fwd_launch(const ConvGeom& g, const float* x, const float* wf, float* y, hipStream_t st) {
+  ConvP p; fill_params(g, p);
+  p.a = x; p.b = wf; p.bias = nullptr; p.out = y; p.act = VCG_ACT_NONE;
+  const unsigned long long ab = (unsigned long long)g.N * g.H * g.W * g.Cin * 4, bb = (unsigned long long)g.K * g.Cout * 4;
+  VCG_CHECK_ARG(ab < (1ull << 31) && bb < (1ull << 31), "vcg_conv_fwd: tensor extents must stay below 2 GiB");
+  p.a_bytes = (uint32_t)ab; p.b_bytes = (uint32_t)bb;
+  int bm, bn, nsplit, kt_per;
+  gemm_plan(g.M, g.Cout, (g.K + BK - 1) / BK, false, bm, bn, nsplit, kt_per, 1, true);
+  dim3 grid((g.M + bm - 1) / bm, (g.Cout + bn - 1) / bn, 1);
+  DISPATCH_FWD(bm, bn, grid, st, p);
+  VCG_LAUNCH_CHECK("vcg_conv_fwd(raw)");
+  return 0;
+}
+
 extern "C" size_t vcg_pack_weight_floats(const int32_t* cd) {
   ConvGeom g;
   if (vcg_conv_geom(cd, &g, "vcg_pack_weight_floats")) return 0;
-  return wf_floats(g) + (vcg_wino_weight_ok(g) ? 2 * vcg_wino_weight_floats(g) : 0);   // + U (forward) + Ud (data gradient)
+  return wf_floats(g) + (vcg_wino_weight_ok(g) ? 2 * vcg_wino_weight_floats(g) : 0)   // + U (forward) + Ud (data gradient)
+         + (vcg_thin_fold_ok(g) ? vcg_thin_fold_weight_floats(g) : 0);                  // + Wk (kw-folded thin forward)
 }
 
 extern "C" int vcg_pack_weight(const float* w_oihw, float* wf, const int32_t* cd, void* stream) {
   ConvGeom g;
   if (vcg_conv_geom(cd, &g, "vcg_pack_weight")) return -1;
   VCG_CHECK_ARG(w_oihw && wf, "vcg_pack_weight: null pointer");
+  if (vcg_thin_fold_ok(g) && vcg_thin_fold_pack(g, w_oihw, wf + wf_floats(g), (hipStream_t)stream)) return -2;
   if (vcg_wino_weight_ok(g)) {
     if (vcg_wino_weight(g, w_oihw, wf + wf_floats(g), (hipStream_t)stream)) return -2;
     if (vcg_wino_weight_dgrad(g, w_oihw, wf + wf_floats(g) + vcg_wino_weight_floats(g), (hipStream_t)stream)) return -2;
@@ -1219,12 +1244,13 @@ extern "C" int vcg_pack_weight(const float* w_oihw, float* wf, const int32_t* cd
 }
 
 static void fwd_plan(const ConvGeom& g, int& bm, int& bn, int& nsplit, int& kt_per) {
-  gemm_plan(g.M, g.Cout, (g.K + BK - 1) / BK, true, bm, bn, nsplit, kt_per);
+  gemm_plan(g.M, g.Cout, (g.K + BK - 1) / BK, true, bm, bn, nsplit, kt_per, 1, true);
 }
 
 extern "C" size_t vcg_conv_fwd_workspace(const int32_t* cd) {
   ConvGeom g;
   if (vcg_conv_geom(cd, &g, "vcg_conv_fwd_workspace")) return 0;
+  if (vcg_thin_fold_ok(g)) return vcg_thin_fold_workspace(g);
   if (vcg_thin_fwd_ok(g)) return 0;
   if (vcg_wino_fwd_ok(g)) return vcg_wino_fwd_workspace(g);
   int bm, bn, nsplit, kt_per;
@@ -1243,6 +1269,7 @@ extern "C" int vcg_conv_fwd(const float* x, const float* wf, const float* bias, 
   ConvGeom g;
   if (vcg_conv_geom(cd, &g, "vcg_conv_fwd")) return -1;
   VCG_CHECK_ARG(x && wf && y, "vcg_conv_fwd: null pointer");
+  if (vcg_thin_fold_ok(g)) return vcg_thin_fold_fwd(g, x, wf + wf_floats(g), bias, y, ws, ws_bytes, (hipStream_t)stream);
   if (vcg_thin_fwd_ok(g)) return vcg_thin_fwd(g, x, wf, bias, y, (hipStream_t)stream);
   if (vcg_wino_fwd_ok(g)) return vcg_wino_fwd(g, x, wf + wf_floats(g), bias, y, ws, ws_bytes, (hipStream_t)stream);
   ConvP p; fill_params(g, p);
@@ -1260,7 +1287,7 @@ extern "C" int vcg_conv_fwd(const float* x, const float* wf, const float* bias, 
   }
   dim3 grid((g.M + bm - 1) / bm, (g.Cout + bn - 1) / bn, nsplit);
   hipStream_t st = (hipStream_t)stream;
-  DISPATCH_TILE(k_conv_fwd, bm, bn, grid, st, p);
+  DISPATCH_FWD(bm, bn, grid, st, p);
   if (nsplit > 1)
     hipLaunchKernelGGL(k_splitk_finish, dim3(ew_grid((size_t)g.M * g.Cout / 4)), dim3(256), 0, st, (const float*)ws, bias,
                        y, (size_t)g.M, g.Cout, nsplit, g.cout_log, g.act);

@@ -127,3 +127,10 @@ bool vcg_wino_dgrad_ok(const ConvGeom& g);
 size_t vcg_wino_dgrad_workspace(const ConvGeom& g);
 int vcg_wino_weight_dgrad(const ConvGeom& g, const float* w_oihw, float* ud, hipStream_t st);
 int vcg_wino_dgrad(const ConvGeom& g, const float* dy, const float* ud, float* dx, void* ws, size_t ws_bytes, hipStream_t st);
+// conv_thin.hip: thin forward with kw folded into the GEMM's N (MFMA)
+bool vcg_thin_fold_ok(const ConvGeom& g);
+size_t vcg_thin_fold_weight_floats(const ConvGeom& g);
+size_t vcg_thin_fold_workspace(const ConvGeom& g);
+int vcg_thin_fold_pack(const ConvGeom& g, const float* w_oihw, float* wk, hipStream_t st);
+int vcg_thin_fold_fwd(const ConvGeom& g, const float* x, const float* wk, const float* bias, float* y, void* ws, size_t ws_bytes,
+                      hipStream_t st);
