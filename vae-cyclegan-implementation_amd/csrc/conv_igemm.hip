@@ -411,14 +411,15 @@ __global__ __launch_bounds__(256) void k_splitk_finish(const float* __restrict__
 }
 
 // ------------------------------------------------------------------ dgrad
-template <int BM, int BN>
+template <int BM, int BN, int WN = 2>
 __global__ __launch_bounds__(256, 2) void k_conv_dgrad(ConvP p) {
   VCG_STAMP_AT(0);
-  constexpr int MI = BM / 64, NI = BN / 64, AR = BM / 32, BR = BN / 32;
+  constexpr int WM = 4 / WN;                                   // wave rows x WN wave columns (see k_conv_fwd)
+  constexpr int MI = BM / (32 * WM), NI = BN / (32 * WN), AR = BM / 32, BR = BN / 32;
   __shared__ __attribute__((aligned(16))) float As[2][BM * AS_STRIDE];   // double-buffered, see k_conv_fwd
   __shared__ __attribute__((aligned(16))) float Bt[2][BN * AS_STRIDE];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int wm = wid >> 1, wn = wid & 1, l31 = lane & 31, lh = lane >> 5;
+  const int wm = wid / WN, wn = wid % WN, l31 = lane & 31, lh = lane >> 5;
   const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
   const int a_row = tid >> 3, a_u = tid & 7;
   const int s = p.stride, sshift = s - 1;
@@ -559,8 +560,8 @@ __global__ __launch_bounds__(256, 2) void k_conv_dgrad(ConvP p) {
     const float* const Bc = Bt[cur];
     if (kt + 1 < nkt) load_tiles(kt + 1);
     mma_ktile<MI, NI>(
-        acc, [&](int kk, int i) { return Ac[(wm * (BM / 2) + i * 32 + l31) * AS_STRIDE + kk]; },
-        [&](int kk, int j) { return Bc[(wn * (BN / 2) + j * 32 + l31) * AS_STRIDE + kk]; }, lh);
+        acc, [&](int kk, int i) { return Ac[(wm * (BM / WM) + i * 32 + l31) * AS_STRIDE + kk]; },
+        [&](int kk, int j) { return Bc[(wn * (BN / WN) + j * 32 + l31) * AS_STRIDE + kk]; }, lh);
     if (((kt - kt0 + 1) & (FLUSH_TILES - 1)) == 0 && kt + 1 < nkt) flush_acc<MI, NI>(acc, tot);
     if (kt + 1 < nkt) store_tiles(cur ^ 1);
     __syncthreads();
@@ -576,7 +577,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_dgrad(ConvP p) {
   float* const dst = p.ksplit > 1 ? p.slab + (size_t)blockIdx.z * p.N * p.H * p.W * p.Cin : p.out;
 #pragma unroll
   for (int j = 0; j < NI; ++j) {
-    const int J = n0 + wn * (BN / 2) + j * 32 + l31;
+    const int J = n0 + wn * (BN / WN) + j * 32 + l31;
     if (J >= p.NB) continue;
     int q = 0, c = J;
     if (p.ups == 2) { q = (int)fd_div((uint32_t)J, p.fd_cin); c = J - q * p.Cin; }
@@ -586,7 +587,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_dgrad(ConvP p) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int row = (e & 3) + 8 * (e >> 2) + 4 * lh;
-        const uint32_t m = (uint32_t)(m0 + wm * (BM / 2) + i * 32 + row);
+        const uint32_t m = (uint32_t)(m0 + wm * (BM / WM) + i * 32 + row);
         if (m < (uint32_t)p.Mc) {
           uint32_t n = fd_div(m, p.fd_hcwc);
           uint32_t rem = m - n * (uint32_t)(p.Hc * p.Wc);
@@ -1159,6 +1160,11 @@ static void gemm_plan(long long rows, long long cols, int nkt, bool allow_split,
   }
 }
 
+#define DISPATCH_DGRAD(bm, bn, grid, stream, p)                                               \
+  do {                                                                                        \
+    if (bn == 32) hipLaunchKernelGGL((k_conv_dgrad<128, 32, 1>), grid, dim3(256), 0, stream, p); \
+    else DISPATCH_TILE(k_conv_dgrad, bm, bn, grid, stream, p);                                 \
+  } while (0)
 #define DISPATCH_FWD(bm, bn, grid, stream, p)                                                 \
   do {                                                                                        \
     if (bn == 32) hipLaunchKernelGGL((k_conv_fwd<128, 32, 1>), grid, dim3(256), 0, stream, p); \
@@ -1301,7 +1307,7 @@ static int dgrad_setup(const ConvGeom& g, ConvP& p, int& bm, int& bn, int& nspli
   p.fd_hcwc = make_fastdiv((uint32_t)(p.Hc * p.Wc));
   p.fd_wc = make_fastdiv((uint32_t)p.Wc);
   // stride 2 uses blockIdx.z for its parity classes, so only stride 1 can slice K
-  gemm_plan(p.Mc, p.NB, (g.KH * g.KW * g.Cout + BK - 1) / BK, g.stride == 1, bm, bn, nsplit, kt_per);
+  gemm_plan(p.Mc, p.NB, (g.KH * g.KW * g.Cout + BK - 1) / BK, g.stride == 1, bm, bn, nsplit, kt_per, 1, true);
   return 0;
 }
 
@@ -1346,7 +1352,7 @@ extern "C" int vcg_conv_dgrad(const float* dy, const float* wf, float* dx, const
   }
   dim3 grid((p.Mc + bm - 1) / bm, (p.NB + bn - 1) / bn, nsplit > 1 ? nsplit : g.stride * g.stride);
   hipStream_t st = (hipStream_t)stream;
-  DISPATCH_TILE(k_conv_dgrad, bm, bn, grid, st, p);
+  DISPATCH_DGRAD(bm, bn, grid, st, p);
   if (nsplit > 1)
     hipLaunchKernelGGL(k_splitk_finish, dim3(ew_grid((size_t)g.N * g.H * g.W * g.Cin / 4)), dim3(256), 0, st,
                        (const float*)ws, (const float*)nullptr, dx, (size_t)g.N * g.H * g.W, g.Cin, nsplit, g.Cin,
