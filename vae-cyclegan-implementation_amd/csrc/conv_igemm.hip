@@ -232,8 +232,11 @@ __device__ __forceinline__ float4 adjoint_extras(const ConvP& p, const float* __
 
 // ------------------------------------------------------------------ forward
 // WN = wave columns: 2 (waves 2 x 2) or, for 32-column tiles, 1 (waves 4 x 1, each 32 rows x 32 columns)
-template <int BM, int BN, int WN = 2>
-__global__ __launch_bounds__(256, 2) void k_conv_fwd(ConvP p) {   // 2 waves/SIMD: acc + tot must fit 256 regs
+// TWO = two-level accumulation (see flush_acc).  The Winograd GEMMs have K <= 2048: a single chain of that length
+// rounds like the CPU's blocked kernels do, and without the second accumulator set the kernel fits three
+// workgroups per CU.
+template <int BM, int BN, int WN = 2, bool TWO = true>
+__global__ __launch_bounds__(256, TWO ? 2 : 3) void k_conv_fwd(ConvP p) {   // TWO: acc + tot must fit 256 regs at 2 waves/SIMD
   VCG_STAMP_AT(0);
   constexpr int WM = 4 / WN;
   constexpr int MI = BM / (32 * WM), NI = BN / (32 * WN), AR = BM / 32, BE = BN / 32;
@@ -262,13 +265,16 @@ __global__ __launch_bounds__(256, 2) void k_conv_fwd(ConvP p) {   // 2 waves/SIM
     bow[r] = (int)ow * p.stride - p.pad;
   }
 
-  f32x16 acc[MI][NI], tot[MI][NI];
+  f32x16 acc[MI][NI], tot[TWO ? MI : 1][TWO ? NI : 1];
 #pragma unroll
   for (int i = 0; i < MI; ++i)
 #pragma unroll
     for (int j = 0; j < NI; ++j)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = tot[i][j][e] = 0.f;
+      for (int e = 0; e < 16; ++e) {
+        acc[i][j][e] = 0.f;
+        if (TWO) tot[i][j][e] = 0.f;
+      }
 
   float4 va[AR], vb[BE];
   int nkt = (p.K + BK - 1) / BK;
@@ -354,7 +360,8 @@ __global__ __launch_bounds__(256, 2) void k_conv_fwd(ConvP p) {   // 2 waves/SIM
     mma_ktile<MI, NI>(
         acc, [&](int kk, int i) { return As[(wm * (BM / WM) + i * 32 + l31) * AS_STRIDE + kk]; },
         [&](int kk, int j) { return Bs[kk * BN + wn * (BN / WN) + j * 32 + l31]; }, lh);
-    if (((kt - kt0 + 1) & (FLUSH_TILES - 1)) == 0 && kt + 1 < nkt) flush_acc<MI, NI>(acc, tot);
+    if constexpr (TWO)
+      if (((kt - kt0 + 1) & (FLUSH_TILES - 1)) == 0 && kt + 1 < nkt) flush_acc<MI, NI>(acc, tot);
     __syncthreads();
     if (kt + 1 < nkt) {
       store_tiles();
@@ -362,10 +369,12 @@ __global__ __launch_bounds__(256, 2) void k_conv_fwd(ConvP p) {   // 2 waves/SIM
     }
   }
   VCG_STAMP_AT(2);
+  if constexpr (TWO) {
 #pragma unroll
-  for (int i = 0; i < MI; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
-    for (int j = 0; j < NI; ++j) acc[i][j] += tot[i][j];
+      for (int j = 0; j < NI; ++j) acc[i][j] += tot[i][j];
+  }
 
   // epilogue: bias + activation, NHWC store (32 consecutive channels per half-wave);
   // a K slice stores its raw partial tile instead (bias/activation happen in k_splitk_finish)
@@ -1196,7 +1205,8 @@ int vcg_gemm_batched(const float* A, const float* B, float* C, int rows, int K, 
   int bm, bn, nsplit, kt_per;
   gemm_plan(rows, Ncols, (K + BK - 1) / BK, false, bm, bn, nsplit, kt_per, batches);
   dim3 grid((rows + bm - 1) / bm, (Ncols + bn - 1) / bn, batches);
-  DISPATCH_FWD(bm, bn, grid, st, p);
+  if (bm == 128 && bn == 128 && K <= 2048) hipLaunchKernelGGL((k_conv_fwd<128, 128, 2, false>), grid, dim3(256), 0, st, p);
+  else DISPATCH_FWD(bm, bn, grid, st, p);
   VCG_LAUNCH_CHECK("vcg_gemm_batched");
   return 0;
 }
