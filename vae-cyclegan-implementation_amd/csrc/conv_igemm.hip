@@ -1303,7 +1303,8 @@ extern "C" int vcg_conv_fwd(const float* x, const float* wf, const float* bias, 
   }
   dim3 grid((g.M + bm - 1) / bm, (g.Cout + bn - 1) / bn, nsplit);
   hipStream_t st = (hipStream_t)stream;
-  DISPATCH_FWD(bm, bn, grid, st, p);
+  if (bm == 128 && bn == 128 && g.K <= 2048) hipLaunchKernelGGL((k_conv_fwd<128, 128, 2, false>), grid, dim3(256), 0, st, p);
+  else DISPATCH_FWD(bm, bn, grid, st, p);
   if (nsplit > 1)
     hipLaunchKernelGGL(k_splitk_finish, dim3(ew_grid((size_t)g.M * g.Cout / 4)), dim3(256), 0, st, (const float*)ws, bias,
                        y, (size_t)g.M, g.Cout, nsplit, g.cout_log, g.act);
