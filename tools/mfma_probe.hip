@@ -3,7 +3,9 @@
 //   0  operands in registers (no LDS)                  3  as 1 + one barrier per K-step
 //   1  ds_read_b32 fragments, the kernels' LDS layout  4  ds_read_b128 A fragments from an XOR-swizzled [m][32] image
 //   2  as 1 without the fragment pipelining fence      5  ds_read_b128 A and B fragments
-// each at 1 and 2 workgroups per CU.   Build + run: see tools/mfma_probe.sh
+// each at 1 and 2 workgroups per CU.
+// Build: C=vae-cyclegan-implementation_amd/csrc; hipcc --offload-arch=gfx950 -O3 -std=c++17 -o tools/_build/mfma_probe \
+//          tools/mfma_probe.hip $C/conv_thin.hip $C/conv_wino.hip $C/norm.hip $C/misc.hip
 #include "../vae-cyclegan-implementation_amd/csrc/conv_igemm.hip"
 
 #include <math.h>

@@ -44,8 +44,8 @@ def main():
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--warm", type=int, default=30, help="back-to-back launches before the stamped one")
     ap.add_argument("--build-only", action="store_true")
-    ap.add_argument("--dbg", default="", help="comma list of VCG_DBG knock-out masks to time instead of stamping "
-                    "(fwd: 1 no loads, 2 no LDS stores, 4 no barrier, 8 no tap recompute, 16 no flush; results are garbage)")
+    ap.add_argument("--dbg", default="", help="time instead of stamping: comma list of 'label[:ENV=VALUE[:ENV=VALUE]]' arms, "
+                    "each run with those environment switches of the diagnostic build (VCG_NO_WINOGRAD=1, VCG_WGRAD_BM=256)")
     args = ap.parse_args()
     path = build_stamped()
     if args.build_only:
@@ -84,8 +84,7 @@ def main():
             lib.vcg_debug_set_stamp(None)
             if args.dbg:
                 for item in args.dbg.split(","):
-                    mask, _, envs = item.partition(":")           # "mask[:NAME=VALUE[:NAME=VALUE]]"
-                    os.environ["VCG_DBG"] = mask
+                    _, _, envs = item.partition(":")              # "label[:NAME=VALUE[:NAME=VALUE]]"
                     for kv in filter(None, envs.split(":")):
                         os.environ[kv.split("=")[0]] = kv.split("=")[1]
                     for _ in range(5):
@@ -98,7 +97,6 @@ def main():
                     torch.cuda.synchronize()
                     us = e0.elapsed_time(e1) * 100.0
                     print(f"{name} {kind} dbg={item:24s}: {us:8.1f} us  {flops / us * 1e-6:6.1f} TF", flush=True)
-                os.environ["VCG_DBG"] = "0"
                 continue
             for _ in range(args.warm):
                 native.check(fn(), kind)

@@ -53,7 +53,6 @@ struct ConvP {
   int src_pitch;   // channel pitch of the tensor adjoint_gather reads (dy)
   uint32_t a_bytes, b_bytes;   // extents of a / b for the bounds-checked buffer loads (< 2 GiB each)
   int dbl_mirror;              // dgrad: some pixel has BOTH a top and a bottom (or left and right) mirror
-  int dbg;                     // diagnostic builds only (VCG_STAMP): knock out parts of the main loop, timing experiments
   // batched launch of the forward kernel (the 16 GEMMs of a Winograd conv): blockIdx.z selects the batch
   int nbatch;
   uint32_t a_bstride, b_bstride;   // floats between consecutive batches of a / b
@@ -80,10 +79,8 @@ extern "C" int vcg_debug_set_stamp(void* buf) {
       if (slot == 3) s__[5] = __builtin_amdgcn_s_memtime();                                                  \
     }                                                                                                        \
   } while (0)
-#define VCG_DBG(bit) (p.dbg & (bit))
 #else
 #define VCG_STAMP_AT(slot) do { } while (0)
-#define VCG_DBG(bit) false
 #endif
 
 __device__ __forceinline__ float4 ldg4(const float* p) { return *reinterpret_cast<const float4*>(p); }
@@ -118,15 +115,11 @@ __device__ __forceinline__ void flush_acc(f32x16 (&acc)[MI][NI], f32x16 (&tot)[M
 // front of its MFMAs behind an s_waitcnt lgkmcnt(0), exposing the LDS latency every 4 MFMAs (~60 % MFMA
 // utilisation measured with SQ_VALU_MFMA_BUSY_CYCLES); the double-buffered fragments cost MI+NI registers.
 //
-// `extra(ks)` (optional) is caller work to place after MFMA step ks, pinned there by a sched_barrier when FENCE.
-// Spreading the staging (LDS writes in the first steps, buffer loads in the last ones) over the MFMA shadows this
-// way was measured on k_conv_fwd: the two co-resident workgroups then finish together, but the launch takes the
-// same time ("what did not pay"), so the kernels keep the simpler load / multiply / store phases.
-struct NoExtra {
-  __device__ __forceinline__ void operator()(int) const {}
-};
-template <int MI, int NI, bool FENCE = false, class FA, class FB, class FX = NoExtra>
-__device__ __forceinline__ void mma_ktile(f32x16 (&acc)[MI][NI], FA ldA, FB ldB, int lh, FX extra = FX()) {
+// Spreading the staging over the MFMA shadows (LDS writes in the first steps, buffer loads in the last ones, pinned
+// with sched_barrier fences) was measured on k_conv_fwd: the two co-resident workgroups then finish together, but
+// the launch takes the same time ("what did not pay"), so the kernels keep the simpler phases.
+template <int MI, int NI, class FA, class FB>
+__device__ __forceinline__ void mma_ktile(f32x16 (&acc)[MI][NI], FA ldA, FB ldB, int lh) {
   float a[2][MI], b[2][NI];
 #pragma unroll
   for (int i = 0; i < MI; ++i) a[0][i] = ldA(lh, i);
@@ -146,10 +139,8 @@ __device__ __forceinline__ void mma_ktile(f32x16 (&acc)[MI][NI], FA ldA, FB ldB,
 #pragma unroll
       for (int j = 0; j < NI; ++j)
         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][i], b[cur][j], acc[i][j], 0, 0, 0);
-    extra(ks);
     __builtin_amdgcn_sched_group_barrier(0x100, MI + NI, 0);   // the next step's LDS reads ...
     __builtin_amdgcn_sched_group_barrier(0x008, MI * NI, 0);   // ... then this step's MFMAs
-    if (FENCE) __builtin_amdgcn_sched_barrier(0);              // ... then this step's share of the staging
   }
 }
 
@@ -1112,11 +1103,6 @@ int vcg_conv_geom(const int32_t* cd, ConvGeom* g, const char* who) {
 }
 
 static void fill_params(const ConvGeom& g, ConvP& p) {
-#ifdef VCG_STAMP
-  { const char* e = getenv("VCG_DBG"); p.dbg = e ? atoi(e) : 0; }
-#else
-  p.dbg = 0;
-#endif
   p.N = g.N; p.H = g.H; p.W = g.W; p.Cin = g.Cin; p.Cout = g.Cout; p.KH = g.KH; p.KW = g.KW;
   p.stride = g.stride; p.pad = g.pad; p.reflect = g.reflect; p.ups = g.ups; p.act = g.act;
   p.Hl = g.Hl; p.Wl = g.Wl; p.Ho = g.Ho; p.Wo = g.Wo; p.M = g.M; p.K = g.K;
