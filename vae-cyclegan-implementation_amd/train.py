@@ -20,7 +20,9 @@ import time
 from datetime import datetime
 from pathlib import Path
 
-import torch
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # RCCL across processes needs dmabuf IPC on this driver
+
+import torch  # noqa: E402
 
 if __package__ in (None, ""):
     import importlib
