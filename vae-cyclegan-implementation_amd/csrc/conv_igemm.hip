@@ -1128,11 +1128,13 @@ static void fill_params(const ConvGeom& g, ConvP& p) {
 // tile and slice K across blockIdx.z instead of shrinking the tile: partial tiles go to fp32 slabs that
 // k_splitk_finish sums in a fixed order (+ bias + activation).
 static void gemm_plan(long long rows, long long cols, int nkt, bool allow_split, int& bm, int& bn, int& nsplit,
-                      int& kt_per, int batches = 1, bool allow_bn32 = false) {
+                      int& kt_per, int batches = 1, bool allow_bn32 = false, bool single_level = false) {
   // cost model (us): rounds of resident workgroups x K-steps per workgroup x time per K-step of that tile,
   // plus the slab write+read of a K-sliced launch.  Same constants as wgrad_plan.
   struct Cand { int bm, bn, resident; double t_step; };
-  const Cand cands[5] = {{128, 128, 2, 5.1}, {128, 64, 3, 4.7}, {64, 128, 3, 4.7}, {64, 64, 4, 4.8}, {128, 32, 4, 3.6}};
+  // single_level: the 128x128 kernel without the second accumulator set keeps three workgroups per CU
+  const Cand cands[5] = {{128, 128, single_level ? 3 : 2, single_level ? 5.4 : 5.1}, {128, 64, 3, 4.7}, {64, 128, 3, 4.7},
+                         {64, 64, 4, 4.8}, {128, 32, 4, 3.6}};
   double best = 1e30;
   bm = 64; bn = 64; nsplit = 1; kt_per = nkt;
   for (int ci = 0; ci < 5; ++ci) {
@@ -1189,7 +1191,7 @@ int vcg_gemm_batched(const float* A, const float* B, float* C, int rows, int K, 
   p.out_bstride = (size_t)rows * Ncols;
   VCG_CHECK_ARG((unsigned long long)rows * K * (unsigned long long)batches < (1ull << 32), "vcg_gemm_batched: batch stride overflow");
   int bm, bn, nsplit, kt_per;
-  gemm_plan(rows, Ncols, (K + BK - 1) / BK, false, bm, bn, nsplit, kt_per, batches);
+  gemm_plan(rows, Ncols, (K + BK - 1) / BK, false, bm, bn, nsplit, kt_per, batches, false, K <= 2048);
   dim3 grid((rows + bm - 1) / bm, (Ncols + bn - 1) / bn, batches);
   if (bm == 128 && bn == 128 && K <= 2048) hipLaunchKernelGGL((k_conv_fwd<128, 128, 2, false>), grid, dim3(256), 0, st, p);
   else DISPATCH_FWD(bm, bn, grid, st, p);
