@@ -1201,6 +1201,8 @@ int vcg_gemm_batched(const float* A, const float* B, float* C, int rows, int K, 
 
 // floats of the packed-weight buffer: Wf[K][Cout], then (3x3 stride-1 layers) the Winograd-transformed U[16][Kc][Cout]
 static size_t wf_floats(const ConvGeom& g) { return (((size_t)g.K * g.Cout + 63) / 64) * 64; }
+// offset of Wkd (kw-folded thin data gradient) in the packed buffer: after Wf and, for a 4 -> 4 layer, after Wk
+static size_t wkd_offset(const ConvGeom& g) { return wf_floats(g) + (vcg_thin_fold_ok(g) ? vcg_thin_fold_weight_floats(g) : 0); }
 // the forward kernel on a caller-built geometry (no bias, no activation, no K slicing): conv_thin.hip's kw-folded path
 int vcg_fwd_launch(const ConvGeom& g, const float* x, const float* wf, float* y, hipStream_t st) {
   ConvP p; fill_params(g, p);
@@ -1220,7 +1222,8 @@ extern "C" size_t vcg_pack_weight_floats(const int32_t* cd) {
   ConvGeom g;
   if (vcg_conv_geom(cd, &g, "vcg_pack_weight_floats")) return 0;
   return wf_floats(g) + (vcg_wino_weight_ok(g) ? 2 * vcg_wino_weight_floats(g) : 0)   // + U (forward) + Ud (data gradient)
-         + (vcg_thin_fold_ok(g) ? vcg_thin_fold_weight_floats(g) : 0);                  // + Wk (kw-folded thin forward)
+         + (vcg_thin_fold_ok(g) ? vcg_thin_fold_weight_floats(g) : 0)                   // + Wk (kw-folded thin forward)
+         + (vcg_thin_fold_dgrad_ok(g) ? vcg_thin_fold_dgrad_weight_floats(g) : 0);      // + Wkd (kw-folded thin data gradient)
 }
 
 extern "C" int vcg_pack_weight(const float* w_oihw, float* wf, const int32_t* cd, void* stream) {
@@ -1228,6 +1231,7 @@ extern "C" int vcg_pack_weight(const float* w_oihw, float* wf, const int32_t* cd
   if (vcg_conv_geom(cd, &g, "vcg_pack_weight")) return -1;
   VCG_CHECK_ARG(w_oihw && wf, "vcg_pack_weight: null pointer");
   if (vcg_thin_fold_ok(g) && vcg_thin_fold_pack(g, w_oihw, wf + wf_floats(g), (hipStream_t)stream)) return -2;
+  if (vcg_thin_fold_dgrad_ok(g) && vcg_thin_fold_dgrad_pack(g, w_oihw, wf + wkd_offset(g), (hipStream_t)stream)) return -2;
   if (vcg_wino_weight_ok(g)) {
     if (vcg_wino_weight(g, w_oihw, wf + wf_floats(g), (hipStream_t)stream)) return -2;
     if (vcg_wino_weight_dgrad(g, w_oihw, wf + wf_floats(g) + vcg_wino_weight_floats(g), (hipStream_t)stream)) return -2;
@@ -1314,6 +1318,7 @@ extern "C" size_t vcg_conv_dgrad_workspace(const int32_t* cd) {
   ConvGeom g;
   if (vcg_conv_geom(cd, &g, "vcg_conv_dgrad_workspace")) return 0;
   if (g.Hl % g.stride || g.Wl % g.stride) return 0;
+  if (vcg_thin_fold_dgrad_ok(g)) return vcg_thin_fold_dgrad_workspace(g);
   if (vcg_thin_dgrad_ok(g)) return vcg_thin_dgrad_workspace(g);
   if (vcg_wino_dgrad_ok(g)) return vcg_wino_dgrad_workspace(g);
   ConvP p; fill_params(g, p);
@@ -1329,6 +1334,7 @@ extern "C" int vcg_conv_dgrad(const float* dy, const float* wf, float* dx, const
   VCG_CHECK_ARG(dy && wf && dx, "vcg_conv_dgrad: null pointer");
   VCG_CHECK_ARG(g.Hl % g.stride == 0 && g.Wl % g.stride == 0, "vcg_conv_dgrad: input %dx%d not divisible by stride", g.Hl, g.Wl);
   VCG_CHECK_ARG(g.stride == 1 || g.ups == 1, "vcg_conv_dgrad: stride 2 with ups 2 unsupported");
+  if (vcg_thin_fold_dgrad_ok(g)) return vcg_thin_fold_dgrad(g, dy, wf + wkd_offset(g), dx, ws, ws_bytes, (hipStream_t)stream);
   if (vcg_thin_dgrad_ok(g)) return vcg_thin_dgrad(g, dy, wf, dx, ws, ws_bytes, (hipStream_t)stream);
   if (vcg_wino_dgrad_ok(g))
     return vcg_wino_dgrad(g, dy, wf + wf_floats(g) + vcg_wino_weight_floats(g), dx, ws, ws_bytes, (hipStream_t)stream);

@@ -164,6 +164,43 @@ __global__ __launch_bounds__(256) void k_pack_kwfold(const float* __restrict__ w
     wk[idx] = v;
   }
 }
+// the data gradient of a thin-INPUT layer (the 3 -> 64 stem) is the same computation on dy with the kernel flipped and
+// the channel roles swapped:  Wkd[(kh, co)][kw * 4 + ci] = w[co][ci][KH-1-kh][KW-1-kw]
+__global__ __launch_bounds__(256) void k_pack_kwfold_dgrad(const float* __restrict__ w, float* __restrict__ wk, int Cout,
+                                                           int cin_log, int cout_log, int KH, int KW) {
+  const int total = KH * Cout * 32;
+  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+    const int col = idx & 31, row = idx >> 5;
+    const int kh = row / Cout, co = row - kh * Cout;
+    const int kw = col >> 2, ci = col & 3;
+    float v = 0.f;
+    if (kw < KW && ci < cin_log && co < cout_log) v = w[(((size_t)co * cin_log + ci) * KH + (KH - 1 - kh)) * KW + (KW - 1 - kw)];
+    wk[idx] = v;
+  }
+}
+bool vcg_thin_fold_dgrad_ok(const ConvGeom& g) { return vcg_thin_dgrad_ok(g) && g.KW * 4 <= 32 && g.cin_log <= 3; }
+size_t vcg_thin_fold_dgrad_weight_floats(const ConvGeom& g) { return (size_t)g.KH * g.Cout * 32; }
+int vcg_thin_fold_dgrad_pack(const ConvGeom& g, const float* w_oihw, float* wk, hipStream_t st) {
+  const int total = g.KH * g.Cout * 32;
+  hipLaunchKernelGGL(k_pack_kwfold_dgrad, dim3((total + 255) / 256), dim3(256), 0, st, w_oihw, wk, g.Cout, g.cin_log,
+                     g.cout_log, g.KH, g.KW);
+  VCG_LAUNCH_CHECK("vcg_pack_weight(kw-fold dgrad)");
+  return 0;
+}
+// geometry of the full correlation over the padded domain: dy (N, Ho, Wo, Cout) -> dxp (N, H + 2 pad, W + 2 pad, 4)
+static ConvGeom thin_dgrad_as_fwd(const ConvGeom& g) {
+  ConvGeom f = g;
+  f.H = g.Ho; f.W = g.Wo; f.Hl = g.Ho; f.Wl = g.Wo; f.Cin = g.Cout; f.cin_log = g.cout_log; f.Cout = 4; f.cout_log = g.cin_log;
+  f.pad = 2 * g.pad; f.reflect = 0; f.act = VCG_ACT_NONE;
+  f.Ho = g.H + 2 * g.pad; f.Wo = g.W + 2 * g.pad;
+  f.M = f.N * f.Ho * f.Wo; f.K = f.KH * f.KW * f.Cin; f.taps = f.KH * f.KW;
+  return f;
+}
+size_t vcg_thin_fold_dgrad_workspace(const ConvGeom& g) {
+  const ConvGeom f = thin_dgrad_as_fwd(g);
+  return vcg_thin_dgrad_workspace(g) + 256 + vcg_thin_fold_workspace(f);
+}
+
 int vcg_thin_fold_pack(const ConvGeom& g, const float* w_oihw, float* wk, hipStream_t st) {
   const int total = g.KH * g.Cin * 32;
   hipLaunchKernelGGL(k_pack_kwfold, dim3((total + 255) / 256), dim3(256), 0, st, w_oihw, wk, g.Cin, g.cin_log, g.cout_log, g.KH,
@@ -224,6 +261,22 @@ int vcg_thin_fwd(const ConvGeom& g, const float* x, const float* wf, const float
   dim3 grid((g.Wo + TT - 1) / TT, (g.Ho + TT - 1) / TT, g.N);
   hipLaunchKernelGGL(k_conv_thin<0>, grid, dim3(256), lds, st, p);
   VCG_LAUNCH_CHECK("vcg_conv_fwd(thin)");
+  return 0;
+}
+
+int vcg_thin_fold_dgrad(const ConvGeom& g, const float* dy, const float* wkd, float* dx, void* ws, size_t ws_bytes,
+                        hipStream_t st) {
+  VCG_CHECK_ARG(ws && ws_bytes >= vcg_thin_fold_dgrad_workspace(g), "vcg_conv_dgrad(kw-fold): workspace too small");
+  const ConvGeom f = thin_dgrad_as_fwd(g);
+  float* dxp = (float*)ws;
+  char* ws2 = (char*)ws + ((vcg_thin_dgrad_workspace(g) + 255) / 256) * 256;
+  if (vcg_thin_fold_fwd(f, dy, wkd, nullptr, dxp, ws2, ws_bytes - (size_t)(ws2 - (char*)ws), st)) return -2;
+  size_t total = (size_t)g.N * g.H * g.W;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(k_fold_pad, dim3(blocks), dim3(256), 0, st, (const float4*)dxp, (float4*)dx, g.N, g.H, g.W, g.pad,
+                     g.reflect);
+  VCG_LAUNCH_CHECK("vcg_conv_dgrad(kw-fold)");
   return 0;
 }
 

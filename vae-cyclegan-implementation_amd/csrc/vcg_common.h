@@ -134,3 +134,8 @@ size_t vcg_thin_fold_workspace(const ConvGeom& g);
 int vcg_thin_fold_pack(const ConvGeom& g, const float* w_oihw, float* wk, hipStream_t st);
 int vcg_thin_fold_fwd(const ConvGeom& g, const float* x, const float* wk, const float* bias, float* y, void* ws, size_t ws_bytes,
                       hipStream_t st);
+bool vcg_thin_fold_dgrad_ok(const ConvGeom& g);
+size_t vcg_thin_fold_dgrad_weight_floats(const ConvGeom& g);
+size_t vcg_thin_fold_dgrad_workspace(const ConvGeom& g);
+int vcg_thin_fold_dgrad_pack(const ConvGeom& g, const float* w_oihw, float* wk, hipStream_t st);
+int vcg_thin_fold_dgrad(const ConvGeom& g, const float* dy, const float* wkd, float* dx, void* ws, size_t ws_bytes, hipStream_t st);
