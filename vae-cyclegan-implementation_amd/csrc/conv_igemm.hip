@@ -235,10 +235,23 @@ __global__ __launch_bounds__(256, TWO ? 2 : 3) void k_conv_fwd(ConvP p) {   // T
   __shared__ __attribute__((aligned(16))) float Bs[BK * BN];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid / WN, wn = wid % WN, l31 = lane & 31, lh = lane >> 5;
-  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  // Tile assignment.  Batched GEMMs (XCD-aware, cdna_hip_programming.md T1): workgroup ids round-robin over the 8
+  // XCDs, each with its own L2, so the launch is cut into 8 contiguous runs of the N-fastest tile order — the N
+  // tiles that share an A tile then run back to back on ONE XCD instead of fetching it into eight L2s.
+  int mt = blockIdx.x, nt = blockIdx.y, zb = 0;
+  if (p.nbatch > 1) {
+    const uint32_t per = gridDim.x * gridDim.y, nwg = per * gridDim.z;
+    const uint32_t gid = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    const uint32_t q = nwg >> 3, r = nwg & 7, xcd = gid & 7;
+    const uint32_t swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (gid >> 3);   // bijective
+    zb = (int)(swz / per);
+    const uint32_t l = swz - (uint32_t)zb * per;
+    mt = (int)(l / gridDim.y);
+    nt = (int)(l - (uint32_t)mt * gridDim.y);
+  }
+  const int m0 = mt * BM, n0 = nt * BN;
   const int a_row = tid >> 3, a_u = tid & 7;
 
-  const int zb = p.nbatch > 1 ? (int)blockIdx.z : 0;
   const __amdgpu_buffer_rsrc_t ra = make_srd(p.a + (size_t)zb * p.a_bstride, p.a_bytes),
                                rb = make_srd(p.b + (size_t)zb * p.b_bstride, p.b_bytes);
   int pnH[AR], boh[AR], bow[AR];
