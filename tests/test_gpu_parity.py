@@ -197,6 +197,33 @@ def test_conv_blocks_match_oracle(case, pkg, oracle, device):
         assert_close(v, ref, f"{cls}{args} d{k}")
 
 
+@pytest.mark.parametrize("shape", [(2, 256, 256, 8, 8), (1, 128, 256, 6, 10), (1, 16, 16, 5, 7)])
+def test_zero_padded_conv_matches_torch(shape, pkg, device):
+    """The C ABI also takes zero padding (reflect = 0), which no reference module uses: checked against plain PyTorch
+    fp32 on the CPU — first two shapes through the Winograd path (crop instead of fold in the data gradient), the last
+    one through the direct kernels."""
+    n, cin, cout, h, w = shape
+    ops = pkg.ops
+    key = f"zp{cin}x{cout}x{h}"
+    x = torch.from_numpy(pkg.synth.normal((n, cin, h, w), SEED + 2, key + "/x"))
+    wt = torch.from_numpy(pkg.synth.normal((cout, cin, 3, 3), SEED + 2, key + "/w")) * (2.0 / (9 * cin)) ** 0.5
+    b = torch.from_numpy(pkg.synth.normal((cout,), SEED + 2, key + "/b")) * 0.1
+    g = torch.from_numpy(pkg.synth.normal((n, cout, h, w), SEED + 2, key + "/g"))
+    xr, wr, br = x.clone().requires_grad_(True), wt.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    yr = torch.nn.functional.conv2d(xr, wr, br, padding=1)
+    yr.backward(g)
+    spec = ops.ConvSpec(cin, cout, 3, 1, 1, False, 1)
+    xd = ops.to_nhwc(x.to(device)).requires_grad_(True)
+    wd = torch.nn.Parameter(wt.to(device))
+    bd = torch.nn.Parameter(b.to(device))
+    y = ops.conv_block(xd, wd, bd, spec)
+    y.backward(ops.to_nhwc(g.to(device)))
+    assert_close(ops.to_nchw_contiguous(y.detach()).cpu(), yr.detach(), "zero-pad y")
+    assert_close(ops.to_nchw_contiguous(xd.grad).cpu(), xr.grad, "zero-pad dx")
+    assert_close(wd.grad.cpu(), wr.grad, "zero-pad dw")
+    assert_close(bd.grad.cpu(), br.grad, "zero-pad db")
+
+
 def test_layout_round_trip_and_views(pkg, device):
     ops = pkg.ops
     for c in (3, 8):
