@@ -148,9 +148,11 @@ def measure_roofline(pkg, model, pool, wl, B, S, latent, ms_per_step):
     FLOPs / its summed launch time, against the fp32 MFMA peak."""
     ops = pkg.ops
     ops.PROFILE = []
-    for i in range(2):
-        model.training_step(pool[i % len(pool)])
+    overlap, ops.OVERLAP_ENABLED = ops.OVERLAP_ENABLED, False     # kernel rates are measured one family at a time:
+    for i in range(2):                                            # the timed steps above run the weight gradients on a
+        model.training_step(pool[i % len(pool)])                  # side stream, where co-running families stretch each other
     torch.cuda.synchronize()
+    ops.OVERLAP_ENABLED = overlap
     recs, ops.PROFILE = ops.PROFILE, None
     fam, shapes = {}, {}
     for name, flops, e0, e1, tag in recs:
@@ -189,6 +191,8 @@ def measure_roofline(pkg, model, pool, wl, B, S, latent, ms_per_step):
                      "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
                      "launches": n // 2, "avg_launch_ms": round(secs / n * 1e3, 4),
                      "flops_counted": "direct-convolution 2*M*Cout*K per call (the Winograd layers execute 2.25x fewer)",
+                     "measured": "HIP events around every call of the family in two extra steps run on ONE stream "
+                                 "(the timed steps overlap weight gradients with data gradients on a second stream)",
                      "device_kernels": symbols.get(dom, [])},
         "step_conv_tflops": round(step_flops / (ms_per_step * 1e-3) / 1e12, 2),
         "step_conv_frac_of_peak": round(step_flops / (ms_per_step * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),

@@ -326,7 +326,7 @@ class Autoencoder(_OptimizerStatesMixin, nn.Module):
             self.optimizer.zero_grad()
             return {"nan_detected": True, "G_loss": float("nan"), "loss_trans": float("nan"), "total_loss": float("nan")}
         self.optimizer.zero_grad()
-        loss_trans.backward()
+        ops.backward_overlapped(loss_trans)
         _reduced_step(self.optimizer, self.grad_reducer)
         return {"G_loss": value, "loss_trans": value, "total_loss": value}
 
@@ -394,7 +394,7 @@ class VariationalAutoencoder(_OptimizerStatesMixin, nn.Module):
         self._check_configured()
         _, G_loss, loss_trans, loss_kl = self._losses(batch)
         self.optimizer.zero_grad()
-        G_loss.backward()
+        ops.backward_overlapped(G_loss)
         _reduced_step(self.optimizer, self.grad_reducer)
         return _metrics_to_host({"G_loss": G_loss, "loss_trans": loss_trans, "loss_kl": loss_kl}, self.grad_reducer)
 
@@ -577,7 +577,7 @@ class CycleVAEGAN(nn.Module):
         t, _, _ = self._generator_losses(x, y)
         # generator gradients reach F and G only (the discriminators contribute their data gradient)
         with ops.no_wgrad(d_params):
-            t["G_loss"].backward(inputs=g_params, retain_graph=True)
+            ops.backward_overlapped(t["G_loss"], inputs=g_params, retain_graph=True)
         if red is not None:
             red.start(self.optimizer_G)          # F+G all-reduce runs under the D backward below
         # discriminator gradients from the same activations reach DX and DY only — what detaching
@@ -585,7 +585,7 @@ class CycleVAEGAN(nn.Module):
         # generator parameter, so running it before optimizer_G.step() changes nothing.
         self.optimizer_D.zero_grad()
         with ops.no_dgrad([self.DX.model[0]._spec, self.DY.model[0]._spec]):
-            t["D_loss"].backward(inputs=d_params)
+            ops.backward_overlapped(t["D_loss"], inputs=d_params)
         if red is not None:
             red.start(self.optimizer_D)
             red.finish(self.optimizer_G)

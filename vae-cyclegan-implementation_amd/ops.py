@@ -7,6 +7,7 @@ autograd graph only; every arithmetic op below is a HIP kernel.  There is no fal
 CPU tensors raise.
 """
 import ctypes
+import os
 import math
 
 import torch
@@ -70,14 +71,60 @@ _WS = {}
 
 
 def workspace(nbytes, device):
-    """One stream-ordered scratch buffer per device, grown on demand."""
-    key = device.index if device.index is not None else torch.cuda.current_device()
+    """One stream-ordered scratch buffer per (device, stream), grown on demand."""
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    key = (idx, torch.cuda.current_stream(device).cuda_stream)
     buf = _WS.get(key)
     if buf is None or buf.numel() * 4 < nbytes:
         n = max(int(nbytes * 1.25) // 4 + 64, 1 << 20)
         buf = torch.empty(n, dtype=torch.float32, device=device)
         _WS[key] = buf
     return buf
+
+
+# ------------------------------------------------------------------ weight-gradient side stream
+# Inside `with wgrad_overlap():` a conv block's weight gradient is issued on a second HIP stream while its data gradient
+# (and everything upstream of it) continues on the caller's stream: the two are independent, and one's HBM-bound
+# transforms / reduces and launch tails fall under the other's MFMA phases.  Weight gradients only ever accumulate
+# into the optimizer's flat buffer, so the one join is at the end of the block (before anything reads `.grad`).
+_SIDE = {}
+_OVERLAP = [False]
+OVERLAP_ENABLED = os.environ.get("VCG_WGRAD_OVERLAP", "1") != "0"     # what `backward_overlapped` does; off = one stream
+
+
+def _side_stream(device):
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    st = _SIDE.get(idx)
+    if st is None:
+        st = torch.cuda.Stream(device=device)
+        _SIDE[idx] = st
+    return st
+
+
+def join_side_streams():
+    for st in _SIDE.values():
+        torch.cuda.current_stream(st.device).wait_stream(st)
+
+
+class wgrad_overlap:
+    def __enter__(self):
+        self.prev = _OVERLAP[0]
+        _OVERLAP[0] = True
+        return self
+
+    def __exit__(self, *exc):
+        _OVERLAP[0] = self.prev
+        join_side_streams()
+        return False
+
+
+def backward_overlapped(loss, **kw):
+    """loss.backward(**kw) with the weight gradients on the side stream (joined before returning)."""
+    if OVERLAP_ENABLED:
+        with wgrad_overlap():
+            loss.backward(**kw)
+    else:
+        loss.backward(**kw)
 
 
 # ------------------------------------------------------------------ layout
@@ -329,10 +376,21 @@ class _ConvBlockFn(torch.autograd.Function):
             gw = _grad_buffer(wparam)
             gb = _grad_buffer(bparam) if (bparam is not None and bparam.requires_grad) else None
             wsb = lib.vcg_conv_wgrad_workspace(cd)
-            ws = workspace(wsb, dev)
-            with _timed("conv_wgrad", ctx.flops, ctx.tag):
-                _native.check(lib.vcg_conv_wgrad(_ptr(xp), _ptr(dt), _ptr(gw), _ptr(gb), cd, _ptr(ws), ws.numel() * 4,
-                                                 _stream()), "vcg_conv_wgrad")
+
+            def run_wgrad():
+                ws = workspace(wsb, dev)
+                with _timed("conv_wgrad", ctx.flops, ctx.tag):
+                    _native.check(lib.vcg_conv_wgrad(_ptr(xp), _ptr(dt), _ptr(gw), _ptr(gb), cd, _ptr(ws), ws.numel() * 4,
+                                                     _stream()), "vcg_conv_wgrad")
+            if _OVERLAP[0]:
+                side = _side_stream(dev)
+                side.wait_stream(torch.cuda.current_stream(dev))      # dt (and, the first time, x) are ready
+                with torch.cuda.stream(side):
+                    run_wgrad()
+                xp.record_stream(side)                                # the allocator must not recycle them under the side stream
+                dt.record_stream(side)
+            else:
+                run_wgrad()
         dx = None
         if ctx.needs_input_grad[0] and id(spec) not in _NO_DGRAD:
             dxp = torch.empty_like(xp)
