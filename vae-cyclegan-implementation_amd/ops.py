@@ -8,6 +8,7 @@ CPU tensors raise.
 """
 import ctypes
 import os
+import weakref
 import math
 
 import torch
@@ -219,6 +220,9 @@ class ConvSpec:
         self.cout_pitch = pitch(cout)
         self._packed = None
         self._packed_key = None
+        self._pack_stream = None
+        self._pack_event = None
+        self._pack_weight = None
 
     def desc(self, n, h, w):
         cd = (ctypes.c_int32 * 16)()
@@ -234,8 +238,11 @@ class ConvSpec:
         return ((hl + 2 * self.pad - self.k) // self.stride + 1, (wl + 2 * self.pad - self.k) // self.stride + 1)
 
     def packed(self, weight):
-        """Wf[K][Cout] for the current parameter values (repacked once per optimizer step)."""
-        key = (PARAM_EPOCH[0], weight._version, weight.data_ptr())
+        """Packed weight buffer (Wf + the transformed copies) for the current parameter values: repacked once per
+        optimizer step.  Parameters owned by a FusedAdam carry that optimizer's step counter (`_vcg_epoch`), so a step
+        of one optimizer does not invalidate the packs of another's parameters."""
+        ep = getattr(weight, "_vcg_epoch", None)
+        key = (ep[0] if ep is not None else PARAM_EPOCH[0], id(ep), weight._version, weight.data_ptr())
         if self._packed is None or self._packed_key != key or self._packed.device != weight.device:
             cd = self.desc(1, max(self.ups * self.k, 2 * self.ups * (self.pad + 1)), max(self.ups * self.k, 2 * self.ups * (self.pad + 1)))
             if self._packed is None or self._packed.device != weight.device:
@@ -248,7 +255,41 @@ class ConvSpec:
                 w = w.contiguous()
             _native.check(_native.lib().vcg_pack_weight(_ptr(w), _ptr(self._packed), cd, _stream()), "vcg_pack_weight")
             self._packed_key = key
+            self._pack_stream = torch.cuda.current_stream(weight.device)
+            self._pack_event = torch.cuda.Event()
+            self._pack_event.record(self._pack_stream)
+            self._pack_weight = weakref.ref(weight)
+            _PACKS[id(self)] = self
+        elif self._pack_stream is not None:
+            cur = torch.cuda.current_stream(weight.device)
+            if cur != self._pack_stream:          # packed ahead of time on the side stream (repack_async): order after it
+                cur.wait_event(self._pack_event)
         return self._packed
+
+
+_PACKS = weakref.WeakValueDictionary()      # specs that have packed something (dropped with their module)
+
+
+def repack_async(params):
+    """After an optimizer step: repack the conv weights that step changed, on the side stream, so that the next
+    forward finds them ready (each consumer waits on its own pack's event) instead of packing layer by layer on its
+    critical path."""
+    if not OVERLAP_ENABLED or not _PACKS:
+        return
+    ids = {id(p) for p in params}
+    todo = []
+    for sp in list(_PACKS.values()):
+        w = sp._pack_weight() if sp._pack_weight is not None else None
+        if w is not None and id(w) in ids and w.is_cuda:
+            todo.append((sp, w))
+    if not todo:
+        return
+    dev = todo[0][1].device
+    side = _side_stream(dev)
+    side.wait_stream(torch.cuda.current_stream(dev))        # after the Adam launch and after every reader of the old packs
+    with torch.cuda.stream(side):
+        for sp, w in todo:
+            sp.packed(w)
 
 
 # Phase control of the alternating GAN update.  `ctx.needs_input_grad` is fixed at forward

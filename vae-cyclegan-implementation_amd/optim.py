@@ -55,6 +55,9 @@ class FusedAdam:
                 p.grad = self.flat_grad[o:o + p.numel()].view(p.shape)
         self.step_count = 0
         self.grad_scale = 1.0
+        self._epoch = [0]                       # bumped by step(); ConvSpec.packed() keys its cache on it
+        for p in plist:
+            p._vcg_epoch = self._epoch
         self.defaults = dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=0, amsgrad=False, maximize=False,
                              foreach=None, capturable=False, differentiable=False, fused=None,
                              decoupled_weight_decay=False)
@@ -78,6 +81,8 @@ class FusedAdam:
         scale = self.grad_scale if grad_scale is None else grad_scale
         ops.adam_step_flat(self.flat_param, self.flat_grad, self.exp_avg, self.exp_avg_sq, self.step_count,
                            g["lr"], g["betas"][0], g["betas"][1], g["eps"], scale)
+        self._epoch[0] += 1
+        ops.repack_async(self.params)
 
     def state_dict(self):
         state = {}
