@@ -11,6 +11,7 @@ dominant kernel family during extra instrumented steps (ops.PROFILE); `cpu_basel
 oracle's CPU restatement of the same step on a bounded sample (rank 0, N=1 only).
 """
 import argparse
+import gc
 import importlib
 import json
 import os
@@ -106,6 +107,11 @@ def main():
 
     for i in range(args.warmup):
         model.training_step(pool[i % len(pool)])
+    # a full collection of Python's cyclic GC walks every long-lived object (modules, parameters, ctypes tables): ~30 ms
+    # on the host, and since each step ends with a metric read-back the GPU idles for all of it.  Collect once now and
+    # move the survivors out of the collector's way; the GC stays on for what the steps allocate.
+    gc.collect()
+    gc.freeze()
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):

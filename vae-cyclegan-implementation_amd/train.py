@@ -13,6 +13,7 @@ TensorBoard, checkpoint resume and the seven other composites.  Asking for them 
 `create_model` and `train_epoch` mirror the reference's functions of the same name (train.py:43-128).
 """
 import argparse
+import gc
 import json
 import os
 import sys
@@ -86,6 +87,8 @@ def train_epoch(model, dataloader, device, args, writer=None, epoch=None):
     total_loss = 0.0
     loss_components = {}
     last_output = last_x = last_y = None
+    gc.collect()
+    gc.freeze()          # keep full collections (~30 ms of host time each, with the GPU idle behind them) off the step loop
     for batch in dataloader:
         batch["x"] = batch["x"].to(device)
         batch["y"] = batch["y"].to(device)
