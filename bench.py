@@ -57,6 +57,9 @@ def main():
     backend = os.environ.get("VCG_DIST_BACKEND", "nccl")
     if os.environ.get("VCG_ONE_DEVICE") == "1":
         local_rank = 0
+        # several ranks on one card: main + side + gloo's pool streams of every process oversubscribe the device's
+        # hardware queues and the rehearsal crawls (4 s/step); it checks the exchange logic, so one stream is enough
+        os.environ.setdefault("VCG_WGRAD_OVERLAP", "0")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:

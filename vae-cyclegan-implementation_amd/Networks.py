@@ -585,14 +585,18 @@ class CycleVAEGAN(nn.Module):
         # generator parameter, so running it before optimizer_G.step() changes nothing.
         self.optimizer_D.zero_grad()
         with ops.no_dgrad([self.DX.model[0]._spec, self.DY.model[0]._spec]):
-            ops.backward_overlapped(t["D_loss"], inputs=d_params)
+            # data parallel: the F+G exchange is in flight here, so this backward stays on the one stream it was
+            # ordered against (no side stream beside a running collective)
+            ops.backward_overlapped(t["D_loss"], overlap=red is None, inputs=d_params)
         if red is not None:
             red.start(self.optimizer_D)
             red.finish(self.optimizer_G)
-        self.optimizer_G.step()
+        self.optimizer_G.step(repack=red is None)
         if red is not None:
             red.finish(self.optimizer_D)
-        self.optimizer_D.step()
+        self.optimizer_D.step(repack=red is None)
+        if red is not None:
+            ops.repack_async(g_params + d_params)        # both exchanges are done: repack on the side stream now
         return self._metrics(t, with_means=True)
 
     def validation_step(self, batch):

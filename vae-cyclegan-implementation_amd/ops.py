@@ -119,9 +119,11 @@ class wgrad_overlap:
         return False
 
 
-def backward_overlapped(loss, **kw):
-    """loss.backward(**kw) with the weight gradients on the side stream (joined before returning)."""
-    if OVERLAP_ENABLED:
+def backward_overlapped(loss, overlap=True, **kw):
+    """loss.backward(**kw) with the weight gradients on the side stream (joined before returning).
+    `overlap=False`: one stream — used while a gradient exchange is in flight (data parallel), so that the
+    collective only ever runs beside the one compute stream it was ordered against."""
+    if OVERLAP_ENABLED and overlap:
         with wgrad_overlap():
             loss.backward(**kw)
     else:

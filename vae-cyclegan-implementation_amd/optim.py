@@ -73,16 +73,18 @@ class FusedAdam:
                 p.grad = self.flat_grad[o:o + p.numel()].view(p.shape)
         ops.fill_(self.flat_grad, 0.0)
 
-    def step(self, grad_scale=None):
+    def step(self, grad_scale=None, repack=True):
         """`grad_scale` multiplies the gradient inside the fused launch (1/world after a summing
-        all-reduce; parallel.GradReducer sets `self.grad_scale`)."""
+        all-reduce; parallel.GradReducer sets `self.grad_scale`).  `repack=False` leaves the side-stream repack of
+        the conv weights to the caller (ops.repack_async), e.g. until no collective is in flight any more."""
         g = self.param_groups[0]
         self.step_count += 1
         scale = self.grad_scale if grad_scale is None else grad_scale
         ops.adam_step_flat(self.flat_param, self.flat_grad, self.exp_avg, self.exp_avg_sq, self.step_count,
                            g["lr"], g["betas"][0], g["betas"][1], g["eps"], scale)
         self._epoch[0] += 1
-        ops.repack_async(self.params)
+        if repack:
+            ops.repack_async(self.params)
 
     def state_dict(self):
         state = {}
