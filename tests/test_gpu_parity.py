@@ -328,6 +328,38 @@ def test_vae_steps_match_reference_golden(pkg, device, steps_golden, steps_meta)
             _check_state(model, key, steps_golden)
 
 
+def test_side_stream_changes_no_bit(pkg, device):
+    """The weight-gradient side stream and the ahead-of-time weight repack only reorder launches across streams: two
+    CycleVAEGAN steps from the same state must give bit-identical metrics, gradients and parameters with the overlap
+    on and off (every reduction in the library has a fixed order; a missing stream dependency would show here)."""
+    ops = pkg.ops
+    results = []
+    prev = ops.OVERLAP_ENABLED
+    try:
+        for overlap in (False, True):
+            ops.OVERLAP_ENABLED = overlap
+            model = pkg.Networks.CycleVAEGAN(latent_dim=64, paired=False)
+            load_synth(pkg, model, "overlap", STEP_BIAS_STD)
+            model = model.to(device).train()
+            model.configure_optimizers(lr=LR)
+            model.configure_loss(**LAMBDAS)
+            ops.manual_seed(77)
+            mets = []
+            for step in range(2):
+                x, y = pkg.synth.batch(2, 256, SEED + 5, step=step)
+                mets.append(model.training_step({"x": torch.from_numpy(x).to(device), "y": torch.from_numpy(y).to(device)}))
+            torch.cuda.synchronize()
+            results.append((mets, model.optimizer_G.flat_grad.clone(), model.optimizer_D.flat_grad.clone(),
+                            model.optimizer_G.flat_param.clone(), model.optimizer_D.flat_param.clone()))
+    finally:
+        ops.OVERLAP_ENABLED = prev
+    (m0, gg0, gd0, pg0, pd0), (m1, gg1, gd1, pg1, pd1) = results
+    assert m0 == m1, (m0, m1)
+    for a, b, what in ((gg0, gg1, "generator gradients"), (gd0, gd1, "discriminator gradients"),
+                       (pg0, pg1, "generator parameters"), (pd0, pd1, "discriminator parameters")):
+        assert torch.equal(a, b), f"{what} differ between one-stream and side-stream runs"
+
+
 @pytest.mark.parametrize("key,paired", [("cvg256_unpaired", False), ("cvg256_paired", True)])
 def test_cyclevaegan_step_matches_reference_golden(key, paired, pkg, device, steps_golden, steps_meta):
     model = pkg.Networks.CycleVAEGAN(latent_dim=64, paired=paired)
