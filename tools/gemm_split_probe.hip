@@ -1,0 +1,70 @@
+// Diagnostic: accuracy (against float64) and speed of the split-operand bf16 GEMM next to the fp32-MFMA GEMM the
+// Winograd layers use.  Build: C=vae-cyclegan-implementation_amd/csrc; hipcc --offload-arch=gfx950 -O3 -std=c++17 \
+//   -o tools/_build/gemm_split_probe tools/gemm_split_probe.hip $C/conv_igemm.hip $C/conv_thin.hip $C/conv_wino.hip $C/gemm_split.hip $C/norm.hip $C/misc.hip
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdint.h>
+#include <vector>
+
+int vcg_gemm_split_batched(const float* A, const float* Bt, float* C, int rows, int K, int N, int batches, hipStream_t st);
+int vcg_gemm_batched(const float* A, const float* B, float* C, int rows, int K, int Ncols, int batches, hipStream_t st);
+extern "C" const char* vcg_last_error();
+
+static void run(int rows, int K, int N, int batches) {
+  const size_t na = (size_t)batches * rows * K, nb = (size_t)batches * N * K, nc = (size_t)batches * rows * N;
+  std::vector<float> ha(na), hbt(nb), hb(nb);
+  uint32_t x = 99;
+  auto rnd = [&]() { x = x * 1664525u + 1013904223u; return ((x >> 8) & 0xFFFFFF) / 16777216.f - 0.5f; };
+  for (auto& v : ha) v = rnd() * 3.f;
+  for (size_t z = 0; z < (size_t)batches; ++z)
+    for (int n = 0; n < N; ++n)
+      for (int k = 0; k < K; ++k) { float v = rnd(); hbt[(z * N + n) * K + k] = v; hb[(z * K + k) * N + n] = v; }
+  float *A, *Bt, *B, *C, *C2;
+  hipMalloc(&A, na * 4); hipMalloc(&Bt, nb * 4); hipMalloc(&B, nb * 4); hipMalloc(&C, nc * 4); hipMalloc(&C2, nc * 4);
+  hipMemcpy(A, ha.data(), na * 4, hipMemcpyHostToDevice);
+  hipMemcpy(Bt, hbt.data(), nb * 4, hipMemcpyHostToDevice);
+  hipMemcpy(B, hb.data(), nb * 4, hipMemcpyHostToDevice);
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  float ms_split = 0, ms_f32 = 0;
+  for (int w = 0; w < 2; ++w) {
+    if (vcg_gemm_split_batched(A, Bt, C, rows, K, N, batches, 0)) { printf("split failed: %s\n", vcg_last_error()); return; }
+    if (vcg_gemm_batched(A, B, C2, rows, K, N, batches, 0)) { printf("f32 failed: %s\n", vcg_last_error()); return; }
+  }
+  hipDeviceSynchronize();
+  const int reps = 5;
+  hipEventRecord(e0, 0);
+  for (int r = 0; r < reps; ++r) vcg_gemm_split_batched(A, Bt, C, rows, K, N, batches, 0);
+  hipEventRecord(e1, 0); hipEventSynchronize(e1); hipEventElapsedTime(&ms_split, e0, e1);
+  hipEventRecord(e0, 0);
+  for (int r = 0; r < reps; ++r) vcg_gemm_batched(A, B, C2, rows, K, N, batches, 0);
+  hipEventRecord(e1, 0); hipEventSynchronize(e1); hipEventElapsedTime(&ms_f32, e0, e1);
+  std::vector<float> hc(nc), hc2(nc);
+  hipMemcpy(hc.data(), C, nc * 4, hipMemcpyDeviceToHost);
+  hipMemcpy(hc2.data(), C2, nc * 4, hipMemcpyDeviceToHost);
+  double e_split = 0, e_f32 = 0, nrm = 0;
+  for (int s = 0; s < 4000; ++s) {
+    x = x * 1664525u + 1013904223u; const size_t z = (x >> 8) % batches;
+    x = x * 1664525u + 1013904223u; const size_t m = (x >> 8) % rows;
+    x = x * 1664525u + 1013904223u; const size_t n = (x >> 8) % N;
+    double ref = 0;
+    for (int k = 0; k < K; ++k) ref += (double)ha[(z * rows + m) * K + k] * hbt[(z * N + n) * K + k];
+    const size_t ci = (z * rows + m) * N + n;
+    e_split += (hc[ci] - ref) * (hc[ci] - ref); e_f32 += (hc2[ci] - ref) * (hc2[ci] - ref); nrm += ref * ref;
+  }
+  const double fl = 2.0 * batches * rows * N * (double)K;
+  printf("rows %6d K %5d N %5d x%2d | split %8.1f us %6.1f TF  rel err %.2e | fp32 MFMA %8.1f us %6.1f TF  rel err %.2e\n", rows, K, N,
+         batches, ms_split * 1e3 / reps, fl / (ms_split * 1e-3 / reps) * 1e-12, sqrt(e_split / nrm), ms_f32 * 1e3 / reps,
+         fl / (ms_f32 * 1e-3 / reps) * 1e-12, sqrt(e_f32 / nrm));
+  hipFree(A); hipFree(Bt); hipFree(B); hipFree(C); hipFree(C2);
+}
+
+int main() {
+  run(8192, 512, 256, 16);     // D2 forward
+  run(8712, 256, 512, 16);     // D2 data gradient
+  run(512, 1024, 1024, 16);    // R forward
+  run(648, 1024, 1024, 16);    // R data gradient
+  run(2048, 1024, 512, 16);    // D3 forward
+  run(32768, 256, 128, 16);    // D1 forward
+  return 0;
+}

@@ -15,7 +15,7 @@
 #include "vcg_common.h"
 #include <stdlib.h>
 
-int vcg_gemm_batched(const float* A, const float* B, float* C, int rows, int K, int Ncols, int batches, hipStream_t st);
+int vcg_gemm_split_batched(const float* A, const float* Bt, float* C, int rows, int K, int N, int batches, hipStream_t st);
 
 struct WinoP {
   const float* x;
@@ -138,7 +138,7 @@ __global__ __launch_bounds__(256) void k_wino_out(WinoP p) {
 // U[xi][k][co] = (G g G^T)[xi], G = [[1, 0, 0], [.5, .5, .5], [.5, -.5, .5], [0, 0, 1]]; k = (phase, c) as in Wf.
 // One thread per (k, co), co fastest: coalesced stores into the 16 planes, 36-byte OIHW reads.
 __global__ __launch_bounds__(256) void k_wino_weight(const float* __restrict__ w, float* __restrict__ u, int Cin, int Cout,
-                                                     int ups, int cin_log, int cout_log) {
+                                                     int ups, int cin_log, int cout_log, int flip) {
   const int U2 = ups * ups, Kc = U2 * Cin;
   const size_t total = (size_t)Kc * Cout;
   for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
@@ -150,7 +150,7 @@ __global__ __launch_bounds__(256) void k_wino_weight(const float* __restrict__ w
 #pragma unroll
     for (int a = 0; a < 3; ++a)
 #pragma unroll
-      for (int b = 0; b < 3; ++b) g[a][b] = ok ? wp[a * 3 + b] : 0.f;
+      for (int b = 0; b < 3; ++b) g[a][b] = ok ? (flip ? wp[(2 - a) * 3 + (2 - b)] : wp[a * 3 + b]) : 0.f;
     float h[4][3];
 #pragma unroll
     for (int b = 0; b < 3; ++b) {
@@ -174,7 +174,7 @@ __global__ __launch_bounds__(256) void k_wino_weight(const float* __restrict__ w
 // scatters the unshuffle phases.  Ud[xi][co][k] = (G g' G^T)[xi] with g'[a][b] = w[co][k][2 - a][2 - b].
 // One thread per (co, k), k fastest: coalesced stores, 36-byte OIHW reads that are contiguous along k for ups == 1.
 __global__ __launch_bounds__(256) void k_wino_weight_dgrad(const float* __restrict__ w, float* __restrict__ u, int Cin, int Cout,
-                                                           int ups, int cin_log, int cout_log) {
+                                                           int ups, int cin_log, int cout_log, int flip) {
   const int U2 = ups * ups, Kc = U2 * Cin;
   const size_t total = (size_t)Kc * Cout;
   for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
@@ -186,7 +186,7 @@ __global__ __launch_bounds__(256) void k_wino_weight_dgrad(const float* __restri
 #pragma unroll
     for (int a = 0; a < 3; ++a)
 #pragma unroll
-      for (int b = 0; b < 3; ++b) g[a][b] = ok ? wp[(2 - a) * 3 + (2 - b)] : 0.f;
+      for (int b = 0; b < 3; ++b) g[a][b] = ok ? (flip ? wp[(2 - a) * 3 + (2 - b)] : wp[a * 3 + b]) : 0.f;
     float h[4][3];
 #pragma unroll
     for (int b = 0; b < 3; ++b) {
@@ -314,7 +314,7 @@ static int wino_blocks(size_t work) {
 // shape class the packed weights carry a transformed copy for (no spatial condition: packing sees no image size)
 bool vcg_wino_weight_ok(const ConvGeom& g) {
   return g.KH == 3 && g.KW == 3 && g.stride == 1 && g.pad == 1 && g.ups * g.ups * g.Cin >= 128 && g.Cout >= 64 &&
-         g.Cin % 4 == 0 && g.Cout % 4 == 0;
+         g.Cin % 4 == 0 && g.Cout % 64 == 0 && (g.ups * g.ups * g.Cin) % 64 == 0;     // N of both GEMMs in 64-column tiles
 }
 bool vcg_wino_fwd_ok(const ConvGeom& g) {
   if (!vcg_wino_weight_ok(g)) return false;
@@ -336,8 +336,9 @@ size_t vcg_wino_fwd_workspace(const ConvGeom& g) {
 }
 int vcg_wino_weight(const ConvGeom& g, const float* w_oihw, float* u, hipStream_t st) {
   const size_t total = (size_t)g.ups * g.ups * g.Cin * g.Cout;
-  hipLaunchKernelGGL(k_wino_weight, dim3(wino_blocks(total)), dim3(256), 0, st, w_oihw, u, g.Cin, g.Cout, g.ups, g.cin_log,
-                     g.cout_log);
+  // Bt operand of the forward GEMM M = V . U: [xi][co][k], k contiguous
+  hipLaunchKernelGGL(k_wino_weight_dgrad, dim3(wino_blocks(total)), dim3(256), 0, st, w_oihw, u, g.Cin, g.Cout, g.ups,
+                     g.cin_log, g.cout_log, 0);
   VCG_LAUNCH_CHECK("vcg_wino_weight");
   return 0;
 }
@@ -395,8 +396,9 @@ size_t vcg_wino_dgrad_workspace(const ConvGeom& g) {
 }
 int vcg_wino_weight_dgrad(const ConvGeom& g, const float* w_oihw, float* ud, hipStream_t st) {
   const size_t total = (size_t)g.ups * g.ups * g.Cin * g.Cout;
-  hipLaunchKernelGGL(k_wino_weight_dgrad, dim3(wino_blocks(total)), dim3(256), 0, st, w_oihw, ud, g.Cin, g.Cout, g.ups,
-                     g.cin_log, g.cout_log);
+  // Bt operand of the data-gradient GEMM dXp = Vdy . Ud: [xi][k][co], co contiguous, kernel flipped
+  hipLaunchKernelGGL(k_wino_weight, dim3(wino_blocks(total)), dim3(256), 0, st, w_oihw, ud, g.Cin, g.Cout, g.ups, g.cin_log,
+                     g.cout_log, 1);
   VCG_LAUNCH_CHECK("vcg_wino_weight_dgrad");
   return 0;
 }
@@ -418,7 +420,7 @@ int vcg_wino_dgrad(const ConvGeom& g, const float* dy, const float* ud, float* d
   p.v = V; p.m = M;
   hipLaunchKernelGGL(k_wino_in, dim3(wino_blocks((size_t)p.T * g.Cout / 4)), dim3(256), 0, st, p);
   VCG_LAUNCH_CHECK("vcg_conv_dgrad(winograd input transform)");
-  if (vcg_gemm_batched(V, ud, M, p.T, g.Cout, kc, 16, st)) return -2;
+  if (vcg_gemm_split_batched(V, ud, M, p.T, g.Cout, kc, 16, st)) return -2;
   WinoP q = p;
   q.Kc = kc;                                      // the output side: k columns
   hipLaunchKernelGGL(k_wino_out_pad, dim3(wino_blocks((size_t)p.T * kc / 4)), dim3(256), 0, st, (const float*)M, dxp, q);
@@ -438,7 +440,7 @@ int vcg_wino_fwd(const ConvGeom& g, const float* x, const float* u, const float*
   p.x = x; p.v = V; p.m = M; p.bias = bias; p.y = y;
   hipLaunchKernelGGL(k_wino_in, dim3(wino_blocks((size_t)p.T * p.Kc / 4)), dim3(256), 0, st, p);
   VCG_LAUNCH_CHECK("vcg_conv_fwd(winograd input transform)");
-  if (vcg_gemm_batched(V, u, M, p.T, p.Kc, g.Cout, 16, st)) return -2;
+  if (vcg_gemm_split_batched(V, u, M, p.T, p.Kc, g.Cout, 16, st)) return -2;
   hipLaunchKernelGGL(k_wino_out, dim3(wino_blocks((size_t)p.T * g.Cout / 4)), dim3(256), 0, st, p);
   VCG_LAUNCH_CHECK("vcg_conv_fwd(winograd output transform)");
   return 0;

@@ -1,0 +1,215 @@
+// Batched dense GEMM for the Winograd layers on the bf16 matrix pipe with fp32-level accuracy ("split-operand" or
+// bf16x3 emulation):   C[z][m][n] = sum_k A[z][m][k] * Bt[z][n][k]      (A, Bt, C fp32 in memory; k contiguous in both)
+//
+// gfx950 runs v_mfma_f32_32x32x16_bf16 at 16x the rate of v_mfma_f32_32x32x2_f32.  Every fp32 operand is split while
+// it is staged into LDS:  x = h + m + l  with  h = bf16(x), m = bf16(x - h), l = bf16(x - h - m)  (3 x 8 mantissa
+// bits = the 24 of fp32), and the six cross products of weight >= 2^-16 relative —  hh, hm, mh, hl, lh, mm  — are
+// accumulated in the MFMA's fp32 accumulator, smallest first.  What is dropped (ml, lm, ll) is below 2^-24 relative
+// to |a||b|: the result rounds like an fp32 GEMM (tools/gemm_split_probe.hip measures it against float64).
+// 6 bf16 MFMAs of 32 cycles replace 8 fp32 MFMAs of 64: 2.7x less matrix-pipe time; the kernel then runs at what its
+// staging (global -> split -> LDS) and its epilogue allow.
+//
+// Tile 128 x BN (BN = 128 or 64), BK = 32, 256 threads = 2 x 2 waves, each wave (64 x BN/2) as 32x32 accumulators.
+// LDS images: per piece [rows][32] bf16, 64-byte rows, the four 16-byte chunks of a row XOR-swizzled by (row >> 2) & 3
+// so that the ds_read_b128 fragment reads (lane = row, 16 consecutive rows per LDS cycle) are conflict-free.
+#include "vcg_common.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4g __attribute__((ext_vector_type(4)));
+
+struct GemmSplitP {
+  const float* a;
+  const float* bt;
+  float* c;
+  int rows, K, N;
+  uint32_t a_bytes, b_bytes;          // per batch (buffer-load bounds)
+  uint32_t a_bstride, b_bstride;      // floats between batches
+  size_t c_bstride;
+};
+
+__device__ __forceinline__ float4 gs_bload4(__amdgpu_buffer_rsrc_t r, uint32_t off) {
+  u32x4g v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0);
+  return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+#define GS_OOB 0x80000000u
+
+// 4 consecutive k of one row -> three 8-byte bf16 quads
+__device__ __forceinline__ void split4(const float4& v, uint2& h, uint2& m, uint2& l) {
+  const float x[4] = {v.x, v.y, v.z, v.w};
+  unsigned short hs[4], ms[4], ls[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const __bf16 hb = (__bf16)x[i];
+    const float r1 = x[i] - (float)hb;
+    const __bf16 mb = (__bf16)r1;
+    const float r2 = r1 - (float)mb;
+    const __bf16 lb = (__bf16)r2;
+    hs[i] = __builtin_bit_cast(unsigned short, hb);
+    ms[i] = __builtin_bit_cast(unsigned short, mb);
+    ls[i] = __builtin_bit_cast(unsigned short, lb);
+  }
+  h = make_uint2((uint32_t)hs[0] | ((uint32_t)hs[1] << 16), (uint32_t)hs[2] | ((uint32_t)hs[3] << 16));
+  m = make_uint2((uint32_t)ms[0] | ((uint32_t)ms[1] << 16), (uint32_t)ms[2] | ((uint32_t)ms[3] << 16));
+  l = make_uint2((uint32_t)ls[0] | ((uint32_t)ls[1] << 16), (uint32_t)ls[2] | ((uint32_t)ls[3] << 16));
+}
+
+template <int BN>
+__global__ __launch_bounds__(256, 2) void k_gemm_split(GemmSplitP p) {
+  constexpr int BM = 128, NI = BN / 64, MI = 2, AR = BM / 32, BR = BN / 32;
+  // [piece][row][32 bf16] as raw bytes: 64 B per row
+  __shared__ __attribute__((aligned(16))) unsigned char As[3][BM * 64];
+  __shared__ __attribute__((aligned(16))) unsigned char Bs[3][BN * 64];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid >> 1, wn = wid & 1, l31 = lane & 31, lh = lane >> 5;
+  // XCD-aware tile order (see k_conv_fwd): the N tiles that share an A tile run back to back on one XCD
+  int mt, nt, zb;
+  {
+    const uint32_t per = gridDim.x * gridDim.y, nwg = per * gridDim.z;
+    const uint32_t gid = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    const uint32_t q = nwg >> 3, r = nwg & 7, xcd = gid & 7;
+    const uint32_t swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (gid >> 3);
+    zb = (int)(swz / per);
+    const uint32_t l = swz - (uint32_t)zb * per;
+    mt = (int)(l / gridDim.y);
+    nt = (int)(l - (uint32_t)mt * gridDim.y);
+  }
+  const int m0 = mt * BM, n0 = nt * BN;
+  const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)(p.a + (size_t)zb * p.a_bstride), 0, (int)p.a_bytes, 0x00020000),
+                               rb = __builtin_amdgcn_make_buffer_rsrc((void*)(p.bt + (size_t)zb * p.b_bstride), 0, (int)p.b_bytes, 0x00020000);
+  const int s_row = tid >> 3, s_u = tid & 7;                    // staging: row (+32 i), k quad
+  uint32_t aoff[AR], boff[BR];
+#pragma unroll
+  for (int i = 0; i < AR; ++i) {
+    const int r = m0 + s_row + 32 * i;
+    aoff[i] = r < p.rows ? (uint32_t)(((size_t)r * p.K + s_u * 4) * 4) : GS_OOB;
+  }
+#pragma unroll
+  for (int i = 0; i < BR; ++i) {
+    const int r = n0 + s_row + 32 * i;
+    boff[i] = r < p.N ? (uint32_t)(((size_t)r * p.K + s_u * 4) * 4) : GS_OOB;
+  }
+  // LDS byte offset of this thread's quad inside a piece image: row r, chunk (u >> 1) swizzled, half (u & 1)
+  uint32_t soff[AR > BR ? AR : BR];
+#pragma unroll
+  for (int i = 0; i < (AR > BR ? AR : BR); ++i) {
+    const int r = s_row + 32 * i;
+    soff[i] = (uint32_t)(r * 64 + (((s_u >> 1) ^ ((r >> 2) & 3)) << 4) + ((s_u & 1) << 3));
+  }
+
+  f32x16 acc[MI][NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  float4 va[AR], vb[BR];
+  const int nkt = (p.K + 31) / 32;
+  auto load_tiles = [&](int kt) {
+    const bool kv = kt * 32 + s_u * 4 < p.K;                    // K is a multiple of 4
+#pragma unroll
+    for (int i = 0; i < AR; ++i) va[i] = gs_bload4(ra, (kv && aoff[i] != GS_OOB) ? aoff[i] + (uint32_t)kt * 128u : GS_OOB);
+#pragma unroll
+    for (int i = 0; i < BR; ++i) vb[i] = gs_bload4(rb, (kv && boff[i] != GS_OOB) ? boff[i] + (uint32_t)kt * 128u : GS_OOB);
+  };
+  auto store_tiles = [&]() {
+#pragma unroll
+    for (int i = 0; i < AR; ++i) {
+      uint2 h, m, l;
+      split4(va[i], h, m, l);
+      *reinterpret_cast<uint2*>(&As[0][soff[i]]) = h;
+      *reinterpret_cast<uint2*>(&As[1][soff[i]]) = m;
+      *reinterpret_cast<uint2*>(&As[2][soff[i]]) = l;
+    }
+#pragma unroll
+    for (int i = 0; i < BR; ++i) {
+      uint2 h, m, l;
+      split4(vb[i], h, m, l);
+      *reinterpret_cast<uint2*>(&Bs[0][soff[i]]) = h;
+      *reinterpret_cast<uint2*>(&Bs[1][soff[i]]) = m;
+      *reinterpret_cast<uint2*>(&Bs[2][soff[i]]) = l;
+    }
+  };
+  // fragment byte offsets (per k slice s: chunk 2s + lh)
+  uint32_t fa[MI], fb[NI];
+  int sa[MI], sb[NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i) { const int r = wm * 64 + i * 32 + l31; fa[i] = (uint32_t)(r * 64); sa[i] = (r >> 2) & 3; }
+#pragma unroll
+  for (int j = 0; j < NI; ++j) { const int r = wn * (BN / 2) + j * 32 + l31; fb[j] = (uint32_t)(r * 64); sb[j] = (r >> 2) & 3; }
+
+  load_tiles(0);
+  store_tiles();
+  __syncthreads();
+  for (int kt = 0; kt < nkt; ++kt) {
+    if (kt + 1 < nkt) load_tiles(kt + 1);
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      bf16x8 a[3][MI], b[3][NI];
+#pragma unroll
+      for (int pc = 0; pc < 3; ++pc) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+          a[pc][i] = *reinterpret_cast<const bf16x8*>(&As[pc][fa[i] + (((2 * s + lh) ^ sa[i]) << 4)]);
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+          b[pc][j] = *reinterpret_cast<const bf16x8*>(&Bs[pc][fb[j] + (((2 * s + lh) ^ sb[j]) << 4)]);
+      }
+      // smallest contributions first: mm, lh, hl, mh, hm, hh
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+          f32x16 c = acc[i][j];
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][i], b[1][j], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2][i], b[0][j], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[2][j], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][i], b[0][j], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[1][j], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[0][j], c, 0, 0, 0);
+          acc[i][j] = c;
+        }
+    }
+    __syncthreads();
+    if (kt + 1 < nkt) {
+      store_tiles();
+      __syncthreads();
+    }
+  }
+  float* const dst = p.c + (size_t)zb * p.c_bstride;
+#pragma unroll
+  for (int j = 0; j < NI; ++j) {
+    const int n = n0 + wn * (BN / 2) + j * 32 + l31;
+    if (n >= p.N) continue;
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = (e & 3) + 8 * (e >> 2) + 4 * lh;
+        const int m = m0 + wm * 64 + i * 32 + row;
+        if (m < p.rows) dst[(size_t)m * p.N + n] = acc[i][j][e];
+      }
+  }
+}
+
+// rows x K times (N x K)^T per batch; K % 4 == 0, N % 64 == 0
+int vcg_gemm_split_batched(const float* A, const float* Bt, float* C, int rows, int K, int N, int batches, hipStream_t st) {
+  VCG_CHECK_ARG(K % 4 == 0 && N % 64 == 0 && rows > 0, "vcg_gemm_split_batched: bad shape rows=%d K=%d N=%d", rows, K, N);
+  VCG_CHECK_ARG((unsigned long long)rows * K * 4 < (1ull << 31) && (unsigned long long)N * K * 4 < (1ull << 31),
+                "vcg_gemm_split_batched: operand extents must stay below 2 GiB per batch");
+  VCG_CHECK_ARG((unsigned long long)rows * K * (unsigned long long)batches < (1ull << 32) &&
+                    (unsigned long long)N * K * (unsigned long long)batches < (1ull << 32),
+                "vcg_gemm_split_batched: batch stride overflow");
+  GemmSplitP p;
+  p.a = A; p.bt = Bt; p.c = C; p.rows = rows; p.K = K; p.N = N;
+  p.a_bytes = (uint32_t)((size_t)rows * K * 4); p.b_bytes = (uint32_t)((size_t)N * K * 4);
+  p.a_bstride = (uint32_t)((size_t)rows * K); p.b_bstride = (uint32_t)((size_t)N * K);
+  p.c_bstride = (size_t)rows * N;
+  const int bn = (N % 128 == 0) ? 128 : 64;
+  dim3 grid((rows + 127) / 128, N / bn, batches);
+  if (bn == 128) hipLaunchKernelGGL(k_gemm_split<128>, grid, dim3(256), 0, st, p);
+  else hipLaunchKernelGGL(k_gemm_split<64>, grid, dim3(256), 0, st, p);
+  VCG_LAUNCH_CHECK("vcg_gemm_split_batched");
+  return 0;
+}
