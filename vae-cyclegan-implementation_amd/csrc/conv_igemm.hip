@@ -402,6 +402,223 @@ __global__ __launch_bounds__(256, TWO ? 2 : 3) void k_conv_fwd(ConvP p) {   // T
   VCG_STAMP_AT(3);
 }
 
+// one K-step (32) of the split-operand product: two 16-wide slices x six bf16 MFMAs per 32x32 accumulator.
+// The dominant h*h products go to `acc`, the five cross terms (<= 2^-7 of them) to `lo`: every add into an fp32
+// accumulator rounds relative to the accumulator's magnitude, so feeding all six into one chain would cost six
+// roundings of the big running sum per slice instead of one (measured: 7.9e-7 -> see tools/conv_accuracy.py).
+template <int MI, int NI, int RA, int RB>
+__device__ __forceinline__ void split_mma_ktile(f32x16 (&acc)[MI][NI], f32x16 (&lo)[MI][NI], const unsigned char (&As)[3][RA],
+                                                const unsigned char (&Bs)[3][RB], const uint32_t (&fa)[MI], const uint32_t (&fb)[NI],
+                                                const int (&sa)[MI], const int (&sb)[NI], int lh) {
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    bf16x8 a[3][MI], b[3][NI];
+#pragma unroll
+    for (int pc = 0; pc < 3; ++pc) {
+#pragma unroll
+      for (int i = 0; i < MI; ++i) a[pc][i] = *reinterpret_cast<const bf16x8*>(&As[pc][fa[i] + (((2 * s + lh) ^ sa[i]) << 4)]);
+#pragma unroll
+      for (int j = 0; j < NI; ++j) b[pc][j] = *reinterpret_cast<const bf16x8*>(&Bs[pc][fb[j] + (((2 * s + lh) ^ sb[j]) << 4)]);
+    }
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        f32x16 c = lo[i][j];
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][i], b[1][j], c, 0, 0, 0);     // smallest contributions first
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2][i], b[0][j], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[2][j], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][i], b[0][j], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[1][j], c, 0, 0, 0);
+        lo[i][j] = c;
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[0][j], acc[i][j], 0, 0, 0);
+      }
+  }
+}
+
+// The forward implicit GEMM on the bf16 matrix pipe with split operands (gemm_split.hip explains the arithmetic: three
+// bf16 pieces per fp32 value, six MFMA products, fp32 accumulation — fp32-level rounding at 2.7x less matrix-pipe
+// time).  Same gather as k_conv_fwd; B comes from the transposed pack WfT[Cout][K] so that both operands are staged as
+// k-contiguous quads, split, and written to the swizzled [row][32 bf16] images that ds_read_b128 feeds to the MFMA.
+template <int BN>
+__global__ __launch_bounds__(256, 2) void k_conv_fwd_split(ConvP p) {
+  VCG_STAMP_AT(0);
+  constexpr int BM = 128, WN = 2, WM = 2;
+  constexpr int MI = BM / (32 * WM), NI = BN / (32 * WN), AR = BM / 32, BE = BN / 32;
+  __shared__ __attribute__((aligned(16))) unsigned char As[3][BM * 64];
+  __shared__ __attribute__((aligned(16))) unsigned char Bs[3][BN * 64];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid / WN, wn = wid % WN, l31 = lane & 31, lh = lane >> 5;
+  // Tile assignment.  Batched GEMMs (XCD-aware, cdna_hip_programming.md T1): workgroup ids round-robin over the 8
+  // XCDs, each with its own L2, so the launch is cut into 8 contiguous runs of the N-fastest tile order — the N
+  // tiles that share an A tile then run back to back on ONE XCD instead of fetching it into eight L2s.
+  int mt = blockIdx.x, nt = blockIdx.y, zb = 0;
+  if (p.nbatch > 1) {
+    const uint32_t per = gridDim.x * gridDim.y, nwg = per * gridDim.z;
+    const uint32_t gid = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    const uint32_t q = nwg >> 3, r = nwg & 7, xcd = gid & 7;
+    const uint32_t swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (gid >> 3);   // bijective
+    zb = (int)(swz / per);
+    const uint32_t l = swz - (uint32_t)zb * per;
+    mt = (int)(l / gridDim.y);
+    nt = (int)(l - (uint32_t)mt * gridDim.y);
+  }
+  const int m0 = mt * BM, n0 = nt * BN;
+  const int a_row = tid >> 3, a_u = tid & 7;
+
+  const __amdgpu_buffer_rsrc_t ra = make_srd(p.a + (size_t)zb * p.a_bstride, p.a_bytes),
+                               rb = make_srd(p.b + (size_t)zb * p.b_bstride, p.b_bytes);
+  int pnH[AR], boh[AR], bow[AR];
+  bool pv[AR];
+#pragma unroll
+  for (int r = 0; r < AR; ++r) {
+    uint32_t m = (uint32_t)(m0 + a_row + 32 * r);
+    pv[r] = m < (uint32_t)p.M;
+    uint32_t n = fd_div(m, p.fd_howo);
+    uint32_t rem = m - n * (uint32_t)(p.Ho * p.Wo);
+    uint32_t oh = fd_div(rem, p.fd_wo);
+    uint32_t ow = rem - oh * (uint32_t)p.Wo;
+    pnH[r] = (int)n * p.H;
+    boh[r] = (int)oh * p.stride - p.pad;
+    bow[r] = (int)ow * p.stride - p.pad;
+  }
+
+  f32x16 acc[MI][NI], lo[MI][NI];               // h*h chain and cross-term chain (split_mma_ktile)
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = lo[i][j][e] = 0.f;
+
+  float4 va[AR], vb[BE];
+  int nkt = (p.K + BK - 1) / BK;
+  int kt0 = 0;
+  if (p.ksplit > 1) {
+    kt0 = (int)blockIdx.z * p.kt_per;
+    int kt1 = kt0 + p.kt_per;
+    nkt = kt1 < nkt ? kt1 : nkt;
+  }
+
+  // byte offsets of this thread's rows for the CURRENT tap; recomputed only when the tap changes (every
+  // Cin/32 K-steps), so a steady-state K-step costs one add per row instead of the reflect arithmetic
+  uint32_t rowoff[AR];
+  int tap_cur = -1;
+  // weight tile from WfT[Cout][K]: row co = n0 + a_row + 32 e, this thread's k quad a_u of the K-step
+  uint32_t boff[BE];
+#pragma unroll
+  for (int e = 0; e < BE; ++e) {
+    const int co = n0 + a_row + 32 * e;
+    boff[e] = co < p.Cout ? (uint32_t)(((size_t)co * p.K + a_u * 4) * 4) : VCG_OOB;
+  }
+  // LDS byte offset of this thread's quad in a piece image (row r, chunk a_u >> 1 swizzled by (r >> 2) & 3, half a_u & 1)
+  uint32_t soff[AR > BE ? AR : BE];
+#pragma unroll
+  for (int i = 0; i < (AR > BE ? AR : BE); ++i) {
+    const int r = a_row + 32 * i;
+    soff[i] = (uint32_t)(r * 64 + (((a_u >> 1) ^ ((r >> 2) & 3)) << 4) + ((a_u & 1) << 3));
+  }
+
+  auto load_tiles = [&](int kt) {
+    const uint32_t g = (uint32_t)(kt * 8 + a_u);
+    const bool kv = (int)(g * 4) < p.K;
+    uint32_t tap = fd_div(g, p.fd_cin4);
+    const int c = (int)(g - tap * (uint32_t)p.cin4) * 4;
+    if ((int)tap != tap_cur) {
+      tap_cur = (int)tap;
+      int ii = 0, jj = 0;
+      if (p.ups == 2) { jj = tap & 1; ii = (tap >> 1) & 1; tap >>= 2; }
+      const uint32_t q = fd_div(tap, p.fd_kw);
+      const int kh = (int)q, kw = (int)(tap - q * (uint32_t)p.KW);
+#pragma unroll
+      for (int r = 0; r < AR; ++r) {
+        int ih = boh[r] + kh, iw = bow[r] + kw;
+        bool ok = pv[r];
+        if (p.reflect) {
+          ih = reflect_idx(ih, p.Hl);
+          iw = reflect_idx(iw, p.Wl);
+        } else {
+          ok = ok && (ih >= 0) && (ih < p.Hl) && (iw >= 0) && (iw < p.Wl);
+        }
+        rowoff[r] = ok ? (uint32_t)(((pnH[r] + ih * p.ups + ii) * p.W + (iw * p.ups + jj)) * p.Cin) * 4u : VCG_OOB;
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < AR; ++r) {
+      const uint32_t off = (kv && rowoff[r] != VCG_OOB) ? rowoff[r] + (uint32_t)c * 4u : VCG_OOB;
+      va[r] = bload4(ra, off);
+    }
+#pragma unroll
+    for (int e = 0; e < BE; ++e) vb[e] = bload4(rb, (kv && boff[e] != VCG_OOB) ? boff[e] + (uint32_t)kt * 128u : VCG_OOB);
+  };
+  auto store_tiles = [&]() {
+#pragma unroll
+    for (int r = 0; r < AR; ++r) {
+      uint2 h, m, l;
+      split4(va[r], h, m, l);
+      *reinterpret_cast<uint2*>(&As[0][soff[r]]) = h;
+      *reinterpret_cast<uint2*>(&As[1][soff[r]]) = m;
+      *reinterpret_cast<uint2*>(&As[2][soff[r]]) = l;
+    }
+#pragma unroll
+    for (int e = 0; e < BE; ++e) {
+      uint2 h, m, l;
+      split4(vb[e], h, m, l);
+      *reinterpret_cast<uint2*>(&Bs[0][soff[e]]) = h;
+      *reinterpret_cast<uint2*>(&Bs[1][soff[e]]) = m;
+      *reinterpret_cast<uint2*>(&Bs[2][soff[e]]) = l;
+    }
+  };
+  uint32_t fa[MI], fb[NI];
+  int sa[MI], sb[NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i) { const int r = wm * (BM / WM) + i * 32 + l31; fa[i] = (uint32_t)(r * 64); sa[i] = (r >> 2) & 3; }
+#pragma unroll
+  for (int j = 0; j < NI; ++j) { const int r = wn * (BN / WN) + j * 32 + l31; fb[j] = (uint32_t)(r * 64); sb[j] = (r >> 2) & 3; }
+
+  if (kt0 < nkt) {
+    load_tiles(kt0);
+    store_tiles();
+  }
+  __syncthreads();
+  VCG_STAMP_AT(1);
+  for (int kt = kt0; kt < nkt; ++kt) {
+    if (kt + 1 < nkt) load_tiles(kt + 1);
+    split_mma_ktile<MI, NI>(acc, lo, As, Bs, fa, fb, sa, sb, lh);
+    __syncthreads();
+    if (kt + 1 < nkt) {
+      store_tiles();
+      __syncthreads();
+    }
+  }
+  VCG_STAMP_AT(2);
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j) acc[i][j] += lo[i][j];
+
+  // epilogue: bias + activation, NHWC store (32 consecutive channels per half-wave);
+  // a K slice stores its raw partial tile instead (bias/activation happen in k_splitk_finish)
+  float* const dst = p.ksplit > 1 ? p.slab + (size_t)blockIdx.z * p.M * p.Cout : p.out + (size_t)zb * p.out_bstride;
+  const int act = p.ksplit > 1 ? VCG_ACT_NONE : p.act;
+#pragma unroll
+  for (int j = 0; j < NI; ++j) {
+    const int co = n0 + wn * (BN / WN) + j * 32 + l31;
+    if (co >= p.Cout) continue;
+    const float bv = (p.ksplit <= 1 && p.bias && co < p.cout_log) ? p.bias[co] : 0.f;
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = (e & 3) + 8 * (e >> 2) + 4 * lh;
+        const int m = m0 + wm * (BM / WM) + i * 32 + row;
+        if (m < p.M) dst[(size_t)m * p.Cout + co] = act_apply(acc[i][j][e] + bv, act);
+      }
+    }
+  }
+  VCG_STAMP_AT(3);
+}
+
 // out[m][c] = act(sum_z slab[z][m][c] + bias[c]) — fixed summation order, float4 per lane
 __global__ __launch_bounds__(256) void k_splitk_finish(const float* __restrict__ slab, const float* __restrict__ bias,
                                                        float* __restrict__ out, size_t rows, int C, int nsplit,
@@ -1021,6 +1238,28 @@ __global__ __launch_bounds__(256) void k_pack_weight_t(const float* __restrict__
     for (int t = 0; t < T; ++t) wf[((size_t)t * p.Cin + c) * p.Cout + co] = tile[(t * 8 + cl_) * 33 + col];
 }
 
+// OIHW -> WfT[Cout][K] (the transpose of Wf; the B^T operand of k_conv_fwd_split): one thread per (co, k), k fastest
+__global__ __launch_bounds__(256) void k_pack_weight_wft(const float* __restrict__ w, float* __restrict__ wft, ConvP p, int cin_log,
+                                                         int cout_log) {
+  const size_t total = (size_t)p.K * p.Cout;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    const int co = (int)(idx / p.K);
+    const uint32_t R = (uint32_t)(idx - (size_t)co * p.K);
+    uint32_t tap = R / (uint32_t)p.Cin;
+    const int c = (int)(R - tap * (uint32_t)p.Cin);
+    float v = 0.f;
+    if (co < cout_log && c < cin_log) {
+      int ii = 0, jj = 0;
+      if (p.ups == 2) { jj = tap & 1; ii = (tap >> 1) & 1; tap >>= 2; }
+      const int kh = (int)tap / p.KW, kw = (int)tap % p.KW;
+      const int cl = (p.ups == 2) ? (c * 4 + ii * 2 + jj) : c;
+      const int cinL = (p.ups == 2) ? cin_log * 4 : cin_log;
+      v = w[(((size_t)co * cinL + cl) * p.KH + kh) * p.KW + kw];
+    }
+    wft[idx] = v;
+  }
+}
+
 // gbias[co] += sum_m dy[m][co]: per-chunk partials then a fixed-order final sum
 // float4 per lane (TC channel quads x TP row lanes per block), 4 independent rows in flight per lane
 __global__ __launch_bounds__(256) void k_colsum_partial(const float* __restrict__ dy, float* __restrict__ part,
@@ -1215,7 +1454,14 @@ int vcg_gemm_batched(const float* A, const float* B, float* C, int rows, int K, 
 // floats of the packed-weight buffer: Wf[K][Cout], then (3x3 stride-1 layers) the Winograd-transformed U[16][Kc][Cout]
 static size_t wf_floats(const ConvGeom& g) { return (((size_t)g.K * g.Cout + 63) / 64) * 64; }
 // offset of Wkd (kw-folded thin data gradient) in the packed buffer: after Wf and, for a 4 -> 4 layer, after Wk
+// the direct forward on the split-operand kernel wants WfT; thin (Cout == 4) layers never take it
+static bool wft_wanted(const ConvGeom& g) { return g.Cout >= 64 && g.Cin % 4 == 0; }
 static size_t wkd_offset(const ConvGeom& g) { return wf_floats(g) + (vcg_thin_fold_ok(g) ? vcg_thin_fold_weight_floats(g) : 0); }
+static size_t wft_offset(const ConvGeom& g) {
+  return wf_floats(g) + (vcg_wino_weight_ok(g) ? 2 * vcg_wino_weight_floats(g) : 0) +
+         (vcg_thin_fold_ok(g) ? vcg_thin_fold_weight_floats(g) : 0) +
+         (vcg_thin_fold_dgrad_ok(g) ? vcg_thin_fold_dgrad_weight_floats(g) : 0);
+}
 // the forward kernel on a caller-built geometry (no bias, no activation, no K slicing): conv_thin.hip's kw-folded path
 int vcg_fwd_launch(const ConvGeom& g, const float* x, const float* wf, float* y, hipStream_t st) {
   ConvP p; fill_params(g, p);
@@ -1236,7 +1482,8 @@ extern "C" size_t vcg_pack_weight_floats(const int32_t* cd) {
   if (vcg_conv_geom(cd, &g, "vcg_pack_weight_floats")) return 0;
   return wf_floats(g) + (vcg_wino_weight_ok(g) ? 2 * vcg_wino_weight_floats(g) : 0)   // + U (forward) + Ud (data gradient)
          + (vcg_thin_fold_ok(g) ? vcg_thin_fold_weight_floats(g) : 0)                   // + Wk (kw-folded thin forward)
-         + (vcg_thin_fold_dgrad_ok(g) ? vcg_thin_fold_dgrad_weight_floats(g) : 0);      // + Wkd (kw-folded thin data gradient)
+         + (vcg_thin_fold_dgrad_ok(g) ? vcg_thin_fold_dgrad_weight_floats(g) : 0)       // + Wkd (kw-folded thin data gradient)
+         + (wft_wanted(g) ? wf_floats(g) : 0);                                          // + WfT (split-operand direct forward)
 }
 
 extern "C" int vcg_pack_weight(const float* w_oihw, float* wf, const int32_t* cd, void* stream) {
@@ -1245,6 +1492,14 @@ extern "C" int vcg_pack_weight(const float* w_oihw, float* wf, const int32_t* cd
   VCG_CHECK_ARG(w_oihw && wf, "vcg_pack_weight: null pointer");
   if (vcg_thin_fold_ok(g) && vcg_thin_fold_pack(g, w_oihw, wf + wf_floats(g), (hipStream_t)stream)) return -2;
   if (vcg_thin_fold_dgrad_ok(g) && vcg_thin_fold_dgrad_pack(g, w_oihw, wf + wkd_offset(g), (hipStream_t)stream)) return -2;
+  if (wft_wanted(g)) {
+    ConvP q; fill_params(g, q);
+    const size_t tot = (size_t)g.K * g.Cout;
+    int blocks = (int)((tot + 255) / 256); if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(k_pack_weight_wft, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w_oihw, wf + wft_offset(g), q,
+                       g.cin_log, g.cout_log);
+    VCG_LAUNCH_CHECK("vcg_pack_weight(WfT)");
+  }
   if (vcg_wino_weight_ok(g)) {
     if (vcg_wino_weight(g, w_oihw, wf + wf_floats(g), (hipStream_t)stream)) return -2;
     if (vcg_wino_weight_dgrad(g, w_oihw, wf + wf_floats(g) + vcg_wino_weight_floats(g), (hipStream_t)stream)) return -2;
@@ -1308,7 +1563,11 @@ extern "C" int vcg_conv_fwd(const float* x, const float* wf, const float* bias, 
   }
   dim3 grid((g.M + bm - 1) / bm, (g.Cout + bn - 1) / bn, nsplit);
   hipStream_t st = (hipStream_t)stream;
-  if (bm == 128 && bn == 128 && g.K <= 2048) hipLaunchKernelGGL((k_conv_fwd<128, 128, 2, false>), grid, dim3(256), 0, st, p);
+  if (bm == 128 && bn >= 64 && wft_wanted(g)) {          // split-operand bf16 kernel, B^T from the WfT region of the pack
+    p.b = wf + wft_offset(g);
+    if (bn == 128) hipLaunchKernelGGL((k_conv_fwd_split<128>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((k_conv_fwd_split<64>), grid, dim3(256), 0, st, p);
+  } else if (bm == 128 && bn == 128 && g.K <= 2048) hipLaunchKernelGGL((k_conv_fwd<128, 128, 2, false>), grid, dim3(256), 0, st, p);
   else DISPATCH_FWD(bm, bn, grid, st, p);
   if (nsplit > 1)
     hipLaunchKernelGGL(k_splitk_finish, dim3(ew_grid((size_t)g.M * g.Cout / 4)), dim3(256), 0, st, (const float*)ws, bias,

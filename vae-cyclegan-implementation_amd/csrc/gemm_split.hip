@@ -4,7 +4,7 @@
 // gfx950 runs v_mfma_f32_32x32x16_bf16 at 16x the rate of v_mfma_f32_32x32x2_f32.  Every fp32 operand is split while
 // it is staged into LDS:  x = h + m + l  with  h = bf16(x), m = bf16(x - h), l = bf16(x - h - m)  (3 x 8 mantissa
 // bits = the 24 of fp32), and the six cross products of weight >= 2^-16 relative —  hh, hm, mh, hl, lh, mm  — are
-// accumulated in the MFMA's fp32 accumulator, smallest first.  What is dropped (ml, lm, ll) is below 2^-24 relative
+// accumulated in fp32 MFMA accumulators (h*h in one chain, the five cross terms in a second one).  What is dropped (ml, lm, ll) is below 2^-24 relative
 // to |a||b|: the result rounds like an fp32 GEMM (tools/gemm_split_probe.hip measures it against float64).
 // 6 bf16 MFMAs of 32 cycles replace 8 fp32 MFMAs of 64: 2.7x less matrix-pipe time; the kernel then runs at what its
 // staging (global -> split -> LDS) and its epilogue allow.
@@ -14,7 +14,6 @@
 // so that the ds_read_b128 fragment reads (lane = row, 16 consecutive rows per LDS cycle) are conflict-free.
 #include "vcg_common.h"
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4g __attribute__((ext_vector_type(4)));
 
 struct GemmSplitP {
@@ -32,26 +31,6 @@ __device__ __forceinline__ float4 gs_bload4(__amdgpu_buffer_rsrc_t r, uint32_t o
   return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
 }
 #define GS_OOB 0x80000000u
-
-// 4 consecutive k of one row -> three 8-byte bf16 quads
-__device__ __forceinline__ void split4(const float4& v, uint2& h, uint2& m, uint2& l) {
-  const float x[4] = {v.x, v.y, v.z, v.w};
-  unsigned short hs[4], ms[4], ls[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const __bf16 hb = (__bf16)x[i];
-    const float r1 = x[i] - (float)hb;
-    const __bf16 mb = (__bf16)r1;
-    const float r2 = r1 - (float)mb;
-    const __bf16 lb = (__bf16)r2;
-    hs[i] = __builtin_bit_cast(unsigned short, hb);
-    ms[i] = __builtin_bit_cast(unsigned short, mb);
-    ls[i] = __builtin_bit_cast(unsigned short, lb);
-  }
-  h = make_uint2((uint32_t)hs[0] | ((uint32_t)hs[1] << 16), (uint32_t)hs[2] | ((uint32_t)hs[3] << 16));
-  m = make_uint2((uint32_t)ms[0] | ((uint32_t)ms[1] << 16), (uint32_t)ms[2] | ((uint32_t)ms[3] << 16));
-  l = make_uint2((uint32_t)ls[0] | ((uint32_t)ls[1] << 16), (uint32_t)ls[2] | ((uint32_t)ls[3] << 16));
-}
 
 template <int BN>
 __global__ __launch_bounds__(256, 2) void k_gemm_split(GemmSplitP p) {
@@ -96,13 +75,15 @@ __global__ __launch_bounds__(256, 2) void k_gemm_split(GemmSplitP p) {
     soff[i] = (uint32_t)(r * 64 + (((s_u >> 1) ^ ((r >> 2) & 3)) << 4) + ((s_u & 1) << 3));
   }
 
-  f32x16 acc[MI][NI];
+  // acc: the h*h chain; lo: the five cross terms (<= 2^-7 of it).  One chain for all six would round the big running
+  // sum six times per slice instead of once.
+  f32x16 acc[MI][NI], lo[MI][NI];
 #pragma unroll
   for (int i = 0; i < MI; ++i)
 #pragma unroll
     for (int j = 0; j < NI; ++j)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = lo[i][j][e] = 0.f;
 
   float4 va[AR], vb[BR];
   const int nkt = (p.K + 31) / 32;
@@ -161,14 +142,14 @@ __global__ __launch_bounds__(256, 2) void k_gemm_split(GemmSplitP p) {
       for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
-          f32x16 c = acc[i][j];
+          f32x16 c = lo[i][j];
           c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][i], b[1][j], c, 0, 0, 0);
           c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2][i], b[0][j], c, 0, 0, 0);
           c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[2][j], c, 0, 0, 0);
           c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][i], b[0][j], c, 0, 0, 0);
           c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[1][j], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[0][j], c, 0, 0, 0);
-          acc[i][j] = c;
+          lo[i][j] = c;
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[0][j], acc[i][j], 0, 0, 0);
         }
     }
     __syncthreads();
@@ -188,7 +169,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_split(GemmSplitP p) {
       for (int e = 0; e < 16; ++e) {
         const int row = (e & 3) + 8 * (e >> 2) + 4 * lh;
         const int m = m0 + wm * 64 + i * 32 + row;
-        if (m < p.rows) dst[(size_t)m * p.N + n] = acc[i][j][e];
+        if (m < p.rows) dst[(size_t)m * p.N + n] = acc[i][j][e] + lo[i][j][e];
       }
   }
 }

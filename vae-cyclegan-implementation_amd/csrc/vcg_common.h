@@ -92,6 +92,27 @@ __device__ static inline double wave_sum_d(double v) {
   return v;
 }
 
+// split-operand bf16 arithmetic (gemm_split.hip): 4 consecutive k of one row -> three 8-byte bf16 quads
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ void split4(const float4& v, uint2& h, uint2& m, uint2& l) {
+  const float x[4] = {v.x, v.y, v.z, v.w};
+  unsigned short hs[4], ms[4], ls[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const __bf16 hb = (__bf16)x[i];
+    const float r1 = x[i] - (float)hb;
+    const __bf16 mb = (__bf16)r1;
+    const float r2 = r1 - (float)mb;
+    const __bf16 lb = (__bf16)r2;
+    hs[i] = __builtin_bit_cast(unsigned short, hb);
+    ms[i] = __builtin_bit_cast(unsigned short, mb);
+    ls[i] = __builtin_bit_cast(unsigned short, lb);
+  }
+  h = make_uint2((uint32_t)hs[0] | ((uint32_t)hs[1] << 16), (uint32_t)hs[2] | ((uint32_t)hs[3] << 16));
+  m = make_uint2((uint32_t)ms[0] | ((uint32_t)ms[1] << 16), (uint32_t)ms[2] | ((uint32_t)ms[3] << 16));
+  l = make_uint2((uint32_t)ls[0] | ((uint32_t)ls[1] << 16), (uint32_t)ls[2] | ((uint32_t)ls[3] << 16));
+}
+
 // geometry derived from the int32[16] conv descriptor
 struct ConvGeom {
   int N, H, W, Cin, Cout, KH, KW, stride, pad, reflect, ups, act, cin_log, cout_log;
