@@ -833,6 +833,217 @@ __global__ __launch_bounds__(256, 2) void k_conv_dgrad(ConvP p) {
   VCG_STAMP_AT(3);
 }
 
+// The data gradient on the split-operand bf16 path (see k_conv_fwd_split / gemm_split.hip).  Same gather as
+// k_conv_dgrad — including the fold of the reflect halo, summed in fp32 BEFORE the split — and the same weight rows
+// (Wf viewed as [tap][J][co] is already k-contiguous per output column J).
+template <int BN, int WN>
+__global__ __launch_bounds__(256, 2) void k_conv_dgrad_split(ConvP p) {
+  VCG_STAMP_AT(0);
+  constexpr int BM = 128, WM = 4 / WN;
+  constexpr int MI = BM / (32 * WM), NI = BN / (32 * WN), AR = BM / 32, BR = BN / 32;
+  __shared__ __attribute__((aligned(16))) unsigned char As[3][BM * 64];
+  __shared__ __attribute__((aligned(16))) unsigned char Bs[3][BN * 64];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid / WN, wn = wid % WN, l31 = lane & 31, lh = lane >> 5;
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  const int a_row = tid >> 3, a_u = tid & 7;
+  const int s = p.stride, sshift = s - 1;
+  const int cls = p.ksplit > 1 ? 0 : (int)blockIdx.z;     // blockIdx.z: parity class (stride 2) OR K slice
+  const int ca = cls / s, cb = cls % s;
+  const int kh0 = (ca + p.pad) % s, kw0 = (cb + p.pad) % s;
+  const int nKH = (p.KH - kh0 + s - 1) / s, nKW = (p.KW - kw0 + s - 1) / s;
+  const int Kc = nKH * nKW * p.Cout;
+
+  int pnHo[AR], ph[AR], pw[AR];
+  bool pv[AR];
+#pragma unroll
+  for (int r = 0; r < AR; ++r) {
+    uint32_t m = (uint32_t)(m0 + a_row + 32 * r);
+    pv[r] = m < (uint32_t)p.Mc;
+    uint32_t n = fd_div(m, p.fd_hcwc);
+    uint32_t rem = m - n * (uint32_t)(p.Hc * p.Wc);
+    uint32_t hq = fd_div(rem, p.fd_wc);
+    uint32_t wq = rem - hq * (uint32_t)p.Wc;
+    pnHo[r] = (int)n * p.Ho;
+    ph[r] = (int)hq * s + ca;
+    pw[r] = (int)wq * s + cb;
+  }
+
+  f32x16 acc[MI][NI], lo[MI][NI];               // h*h chain and cross-term chain (split_mma_ktile)
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = lo[i][j][e] = 0.f;
+
+  float4 va[AR], ve[AR], vb[BR];
+  int nkt = (Kc + BK - 1) / BK;
+  int kt0 = 0;
+  if (p.ksplit > 1) {                      // stride 1 only: blockIdx.z is the K slice, not a parity class
+    kt0 = (int)blockIdx.z * p.kt_per;
+    int kt1 = kt0 + p.kt_per;
+    nkt = kt1 < nkt ? kt1 : nkt;
+  }
+
+  // Bounds-checked buffer loads + per-tap row offsets (see k_conv_fwd).  A pixel within `pad` of a border
+  // (but not on it) also receives the contributions that reflect padding folded onto it: one mirrored row
+  // coordinate eh and/or one mirrored column coordinate ew, i.e. up to three extra sources per tap, whose
+  // offsets are likewise computed once per tap.
+  const __amdgpu_buffer_rsrc_t ra = make_srd(p.a, p.a_bytes), rb = make_srd(p.b, p.b_bytes);
+  const int NONE = -(1 << 20);
+  int eh[AR], ew[AR];
+  bool edge[AR], any_edge = false;
+#pragma unroll
+  for (int r = 0; r < AR; ++r) {
+    const int h = ph[r], w = pw[r];
+    eh[r] = (h >= 1 && h <= p.pad) ? -h : (h >= p.Hl - 1 - p.pad && h <= p.Hl - 2) ? 2 * (p.Hl - 1) - h : NONE;
+    ew[r] = (w >= 1 && w <= p.pad) ? -w : (w >= p.Wl - 1 - p.pad && w <= p.Wl - 2) ? 2 * (p.Wl - 1) - w : NONE;
+    edge[r] = pv[r] && p.reflect && (eh[r] != NONE || ew[r] != NONE);
+    any_edge = any_edge || edge[r];
+    ve[r] = f4zero();
+  }
+  uint32_t rowoff[AR], xoff[AR][3], wbase[BR];
+  int tap_cur = -1;
+
+  auto load_tiles = [&](int kt) {
+    const uint32_t g = (uint32_t)(kt * 8 + a_u);
+    const bool kv = (int)(g * 4) < Kc;
+    const uint32_t tapc = fd_div(g, p.fd_cout4);
+    const int co = (int)(g - tapc * (uint32_t)p.cout4) * 4;
+    if ((int)tapc != tap_cur) {
+      tap_cur = (int)tapc;
+      const int u = (int)tapc / nKW, v_ = (int)tapc % nKW;
+      const int kh = kh0 + u * s, kw = kw0 + v_ * s;
+      auto src = [&](int r, int qh, int qw) -> uint32_t {      // dy offset of the output pixel whose tap hits (qh, qw)
+        const int numh = qh - kh + p.pad, numw = qw - kw + p.pad;
+        const int oh = numh >> sshift, ow = numw >> sshift;
+        const bool ok = pv[r] && qh != NONE && qw != NONE && numh >= 0 && oh < p.Ho && numw >= 0 && ow < p.Wo;
+        return ok ? (uint32_t)(((pnHo[r] + oh) * p.Wo + ow) * p.Cout) * 4u : VCG_OOB;
+      };
+#pragma unroll
+      for (int r = 0; r < AR; ++r) {
+        rowoff[r] = src(r, ph[r], pw[r]);
+        if (any_edge) {
+          xoff[r][0] = edge[r] ? src(r, eh[r], pw[r]) : VCG_OOB;
+          xoff[r][1] = edge[r] ? src(r, ph[r], ew[r]) : VCG_OOB;
+          xoff[r][2] = edge[r] ? src(r, eh[r], ew[r]) : VCG_OOB;
+        }
+      }
+      const int tapfull = kh * p.KW + kw;
+#pragma unroll
+      for (int r = 0; r < BR; ++r) {
+        const int J = n0 + a_row + 32 * r;
+        wbase[r] = J < p.NB ? (uint32_t)((tapfull * p.NB + J) * p.Cout) * 4u : VCG_OOB;
+      }
+    }
+    const uint32_t cb4 = (uint32_t)co * 4u;
+#pragma unroll
+    for (int r = 0; r < AR; ++r) va[r] = bload4(ra, (kv && rowoff[r] != VCG_OOB) ? rowoff[r] + cb4 : VCG_OOB);
+    if (p.dbl_mirror) {                      // tiny maps (e.g. 3x3 with pad 1): general 3x3 candidate search
+      const int u = tap_cur / nKW, v_ = tap_cur % nKW;
+#pragma unroll
+      for (int r = 0; r < AR; ++r)
+        ve[r] = (pv[r] && kv) ? adjoint_extras(p, p.a, pnHo[r], ph[r], pw[r], kh0 + u * s, kw0 + v_ * s, co, sshift) : f4zero();
+    } else if (any_edge) {
+#pragma unroll
+      for (int r = 0; r < AR; ++r) {
+        float4 e = f4zero();
+        if (edge[r] && kv) {
+#pragma unroll
+          for (int k = 0; k < 3; ++k)
+            if (xoff[r][k] != VCG_OOB) f4add(e, bload4(ra, xoff[r][k] + cb4));
+        }
+        ve[r] = e;
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < BR; ++r) vb[r] = bload4(rb, (kv && wbase[r] != VCG_OOB) ? wbase[r] + cb4 : VCG_OOB);
+  };
+  uint32_t soff[AR > BR ? AR : BR];
+#pragma unroll
+  for (int i = 0; i < (AR > BR ? AR : BR); ++i) {
+    const int r = a_row + 32 * i;
+    soff[i] = (uint32_t)(r * 64 + (((a_u >> 1) ^ ((r >> 2) & 3)) << 4) + ((a_u & 1) << 3));
+  }
+  auto store_tiles = [&]() {
+#pragma unroll
+    for (int r = 0; r < AR; ++r) {
+      const float4 v = make_float4(va[r].x + ve[r].x, va[r].y + ve[r].y, va[r].z + ve[r].z, va[r].w + ve[r].w);   // ve == 0 off the edges
+      uint2 h, m, l;
+      split4(v, h, m, l);
+      *reinterpret_cast<uint2*>(&As[0][soff[r]]) = h;
+      *reinterpret_cast<uint2*>(&As[1][soff[r]]) = m;
+      *reinterpret_cast<uint2*>(&As[2][soff[r]]) = l;
+    }
+#pragma unroll
+    for (int r = 0; r < BR; ++r) {
+      uint2 h, m, l;
+      split4(vb[r], h, m, l);
+      *reinterpret_cast<uint2*>(&Bs[0][soff[r]]) = h;
+      *reinterpret_cast<uint2*>(&Bs[1][soff[r]]) = m;
+      *reinterpret_cast<uint2*>(&Bs[2][soff[r]]) = l;
+    }
+  };
+  uint32_t fa[MI], fb[NI];
+  int sa[MI], sb[NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i) { const int r = wm * (BM / WM) + i * 32 + l31; fa[i] = (uint32_t)(r * 64); sa[i] = (r >> 2) & 3; }
+#pragma unroll
+  for (int j = 0; j < NI; ++j) { const int r = wn * (BN / WN) + j * 32 + l31; fb[j] = (uint32_t)(r * 64); sb[j] = (r >> 2) & 3; }
+
+  if (kt0 < nkt) {
+    load_tiles(kt0);
+    store_tiles();
+  }
+  __syncthreads();
+  VCG_STAMP_AT(1);
+  for (int kt = kt0; kt < nkt; ++kt) {
+    if (kt + 1 < nkt) load_tiles(kt + 1);
+    split_mma_ktile<MI, NI>(acc, lo, As, Bs, fa, fb, sa, sb, lh);
+    __syncthreads();
+    if (kt + 1 < nkt) {
+      store_tiles();
+      __syncthreads();
+    }
+  }
+  VCG_STAMP_AT(2);
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j) acc[i][j] += lo[i][j];
+
+  // epilogue: column J = (q, c) -> physical pixel (h*ups + i, w*ups + j), channel c.
+  // A K slice writes its raw partial into slab[z] in the same physical layout; k_splitk_finish sums them.
+  float* const dst = p.ksplit > 1 ? p.slab + (size_t)blockIdx.z * p.N * p.H * p.W * p.Cin : p.out;
+#pragma unroll
+  for (int j = 0; j < NI; ++j) {
+    const int J = n0 + wn * (BN / WN) + j * 32 + l31;
+    if (J >= p.NB) continue;
+    int q = 0, c = J;
+    if (p.ups == 2) { q = (int)fd_div((uint32_t)J, p.fd_cin); c = J - q * p.Cin; }
+    const int qi = q >> 1, qj = q & 1;
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = (e & 3) + 8 * (e >> 2) + 4 * lh;
+        const uint32_t m = (uint32_t)(m0 + wm * (BM / WM) + i * 32 + row);
+        if (m < (uint32_t)p.Mc) {
+          uint32_t n = fd_div(m, p.fd_hcwc);
+          uint32_t rem = m - n * (uint32_t)(p.Hc * p.Wc);
+          uint32_t hq = fd_div(rem, p.fd_wc);
+          uint32_t wq = rem - hq * (uint32_t)p.Wc;
+          int h = (int)hq * s + ca, w = (int)wq * s + cb;
+          size_t off = ((size_t)((int)n * p.H + h * p.ups + qi) * p.W + (w * p.ups + qj)) * p.Cin + c;
+          dst[off] = acc[i][j][e];
+        }
+      }
+    }
+  }
+  VCG_STAMP_AT(3);
+}
+
 // ------------------------------------------------------------------ wgrad
 // NT = 256: four waves, two such workgroups per CU.  NT = 512: eight waves in lockstep on one 256-row tile, one
 // workgroup per CU — the two waves of a SIMD then advance together (the per-K-step barrier), where two independent
@@ -1629,7 +1840,11 @@ extern "C" int vcg_conv_dgrad(const float* dy, const float* wf, float* dx, const
   }
   dim3 grid((p.Mc + bm - 1) / bm, (p.NB + bn - 1) / bn, nsplit > 1 ? nsplit : g.stride * g.stride);
   hipStream_t st = (hipStream_t)stream;
-  DISPATCH_DGRAD(bm, bn, grid, st, p);
+  if (bm == 128 && bn >= 64) {                            // split-operand bf16 kernel
+    if (bn == 128) hipLaunchKernelGGL((k_conv_dgrad_split<128, 2>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((k_conv_dgrad_split<64, 2>), grid, dim3(256), 0, st, p);
+  } else if (bn == 32) hipLaunchKernelGGL((k_conv_dgrad_split<32, 1>), grid, dim3(256), 0, st, p);
+  else DISPATCH_DGRAD(bm, bn, grid, st, p);
   if (nsplit > 1)
     hipLaunchKernelGGL(k_splitk_finish, dim3(ew_grid((size_t)g.N * g.H * g.W * g.Cin / 4)), dim3(256), 0, st,
                        (const float*)ws, (const float*)nullptr, dx, (size_t)g.N * g.H * g.W, g.Cin, nsplit, g.Cin,
