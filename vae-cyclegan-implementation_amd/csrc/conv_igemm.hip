@@ -1227,6 +1227,243 @@ __global__ __launch_bounds__(NT) void k_conv_wgrad(ConvP p) {
   VCG_STAMP_AT(3);
 }
 
+// The weight gradient on the split-operand bf16 path.  Here the reduction index (the pixel) is the SLOW index of both
+// operands — x and dy are [pixel][channel] — while the MFMA wants 8 consecutive reduction indices per lane.  The
+// tiles are therefore staged as they come, [32 pixels][128 channels] bf16 per piece (256-byte rows, 16-byte chunks
+// XOR-swizzled by ((row & 3) << 2) | ((row >> 2) & 3)), and read with gfx950's transposing LDS read
+// ds_read_b64_tr_b16: per 16-lane group it takes a 4-row x 16-column block and hands each lane one column's four
+// rows — two such reads give a lane its 8 reduction indices.  Everything else (stream-K segments, gather, slabs) is
+// k_conv_wgrad's.
+__device__ __forceinline__ uint32_t tr_off(int row, int col) {       // byte offset of element (row, col) in a 256-B-row image
+  const int f = ((row & 3) << 2) | ((row >> 2) & 3);
+  return (uint32_t)(256 * row + 16 * ((col >> 3) ^ f) + (col & 7) * 2);
+}
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ bf16x8 tr_frag(const unsigned char* img, int row0, int col) {   // rows row0 .. row0+7 of column `col`
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(img + tr_off(row0, col)));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(img + tr_off(row0 + 4, col)));
+  typedef short s16x8 __attribute__((ext_vector_type(8)));
+  const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+__global__ __launch_bounds__(256, 2) void k_conv_wgrad_split(ConvP p) {
+  VCG_STAMP_AT(0);
+  constexpr int BM = 128, BN = 128, NT = 256;
+  constexpr int WR = NT / 128;                                 // wave rows (x 2 wave columns)
+  constexpr int MI = BM / (32 * WR), NI = BN / 64;
+  constexpr int RQ = BM / 4, PS = NT / RQ, AP = BK / PS, BE = (BK * BN / 4) / NT;
+  __shared__ __attribute__((aligned(16))) unsigned char Xs[3][BK * BM * 2];   // [piece][32 pixels][128 rows of dW] bf16
+  __shared__ __attribute__((aligned(16))) unsigned char Ds[3][BK * BN * 2];   // [piece][32 pixels][128 columns] bf16
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid >> 1, wn = wid & 1, l31 = lane & 31, lh = lane >> 5;
+  const int rq = tid % RQ, ps = tid / RQ;
+  const uint32_t bstep = (uint32_t)(BK * p.Cout * 4);
+  // When Wo % 32 == 0 the 32 pixels of a K' step lie in one image row: (n, oh) and the row part of the
+  // reflect/address arithmetic are shared by the thread's AP slots.
+  const bool row_aligned = !p.adjoint && (p.Wo % BK) == 0;
+
+  int unit = (int)blockIdx.x * p.sk_len;
+  int unit_end = unit + p.sk_len;
+  if (unit_end > p.sk_units) unit_end = p.sk_units;
+  while (unit < unit_end) {                       // one segment = one tile's K' range [kt_begin, kt_end)
+  const int tile = unit / p.ktiles_total;
+  const int kt_begin = unit - tile * p.ktiles_total;
+  int kt_end = kt_begin + (unit_end - unit);
+  if (kt_end > p.ktiles_total) kt_end = p.ktiles_total;
+  const int tr = tile / p.sk_ntn;
+  const int zb = tr / p.sk_ntr_pb;                 // batch (0 unless this is a batched launch)
+  const int r0 = (tr - zb * p.sk_ntr_pb) * BM, n0 = (tile - tr * p.sk_ntn) * BN;
+  const __amdgpu_buffer_rsrc_t ra = make_srd(p.a + (size_t)zb * p.a_bstride, p.a_bytes),
+                               rb = make_srd(p.b + (size_t)zb * p.b_bstride, p.b_bytes);
+
+  // this thread's K-row quad (fixed for the segment)
+  const int R = r0 + rq * 4;
+  const bool rv = R < p.K;
+  int kh, kw, ii, jj, c;
+  decode_tap(p, (uint32_t)(R >> 2), kh, kw, ii, jj, c);
+
+  f32x16 acc[MI][NI], lo[MI][NI];               // h*h chain and cross-term chain
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = lo[i][j][e] = 0.f;
+
+  float4 va[AP], vb[BE];
+
+  // Pixel coordinates of this thread's K' slots, advanced incrementally (32 pixels per step): the two
+  // divisions per pixel per step of a from-scratch decode were most of this kernel's 8 VALU ops per MFMA.
+  uint32_t sm[AP];
+  int sn[AP], soh[AP], sow[AP];
+#pragma unroll
+  for (int a = 0; a < AP; ++a) {
+    uint32_t m = (uint32_t)(kt_begin * BK + ps + PS * a);
+    uint32_t n = fd_div(m, p.fd_howo);
+    uint32_t rem = m - n * (uint32_t)(p.Ho * p.Wo);
+    uint32_t oh = fd_div(rem, p.fd_wo);
+    sm[a] = m; sn[a] = (int)n; soh[a] = (int)oh; sow[a] = (int)(rem - oh * (uint32_t)p.Wo);
+  }
+  uint32_t boff[BE];
+#pragma unroll
+  for (int e = 0; e < BE; ++e) {
+    int idx = tid + NT * e;
+    int pp = idx / (BN / 4), j4 = idx % (BN / 4);
+    const int co = n0 + j4 * 4;
+    // rows past M fall off the end of the buffer (b_bytes = M * Cout * 4) and read as zeros
+    boff[e] = co < p.Cout ? (uint32_t)(((kt_begin * BK + pp) * p.Cout + co) * 4) : VCG_OOB;
+  }
+
+  auto load_tiles = [&](int /*kt: tiles are visited strictly in order*/) {
+    if (row_aligned) {
+      const int n = sn[0], oh = soh[0];
+      int ih = oh * p.stride - p.pad + kh;
+      bool okr = rv && sm[0] < (uint32_t)p.M;            // M % 32 == 0 here, so all slots agree
+      if (p.reflect) ih = reflect_idx(ih, p.Hl);
+      else okr = okr && ih >= 0 && ih < p.Hl;
+      const uint32_t rowbase = (uint32_t)(((n * p.H + ih * p.ups + ii) * p.W + jj) * p.Cin + c) * 4u;
+      const uint32_t colstep = (uint32_t)(p.ups * p.Cin) * 4u;
+#pragma unroll
+      for (int a = 0; a < AP; ++a) {
+        int iw = sow[a] * p.stride - p.pad + kw;
+        bool ok = okr;
+        if (p.reflect) iw = reflect_idx(iw, p.Wl);
+        else ok = ok && iw >= 0 && iw < p.Wl;
+        va[a] = bload4(ra, ok ? rowbase + (uint32_t)iw * colstep : VCG_OOB);
+        sm[a] += BK;
+        sow[a] += BK;
+        if (sow[a] >= p.Wo) { sow[a] -= p.Wo; ++soh[a]; if (soh[a] >= p.Ho) { soh[a] = 0; ++sn[a]; } }
+      }
+    } else {
+#pragma unroll
+      for (int a = 0; a < AP; ++a) {
+        const int n = sn[a], oh = soh[a], ow = sow[a];
+        if (p.adjoint) {
+          // swapped roles: this K' pixel is an INPUT pixel; its row entries come from the 4-channel dy
+          float4 v = f4zero();
+          if (rv && sm[a] < (uint32_t)p.M) {
+            float4 ex;
+            adjoint_gather(p, p.a, n * p.Ho, oh, ow, kh, kw, 0, 0, v, ex);
+            f4add(v, ex);
+          }
+          va[a] = v;
+        } else {
+          int ih = oh * p.stride - p.pad + kh, iw = ow * p.stride - p.pad + kw;
+          bool ok = rv && sm[a] < (uint32_t)p.M;
+          if (p.reflect) {
+            ih = reflect_idx(ih, p.Hl);
+            iw = reflect_idx(iw, p.Wl);
+          } else {
+            ok = ok && (ih >= 0) && (ih < p.Hl) && (iw >= 0) && (iw < p.Wl);
+          }
+          const uint32_t off = ok ? (uint32_t)(((n * p.H + ih * p.ups + ii) * p.W + (iw * p.ups + jj)) * p.Cin + c) * 4u : VCG_OOB;
+          va[a] = bload4(ra, off);
+        }
+        sm[a] += BK;
+        sow[a] += BK;
+        while (sow[a] >= p.Wo) { sow[a] -= p.Wo; ++soh[a]; }
+        while (soh[a] >= p.Ho) { soh[a] -= p.Ho; ++sn[a]; }
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < BE; ++e) {
+      vb[e] = bload4(rb, boff[e]);
+      if (boff[e] != VCG_OOB) boff[e] += bstep;
+    }
+  };
+  auto store_tiles = [&]() {
+#pragma unroll
+    for (int a = 0; a < AP; ++a) {
+      uint2 h, m, l;
+      split4(va[a], h, m, l);
+      const uint32_t o = tr_off(ps + PS * a, rq * 4);
+      *reinterpret_cast<uint2*>(&Xs[0][o]) = h;
+      *reinterpret_cast<uint2*>(&Xs[1][o]) = m;
+      *reinterpret_cast<uint2*>(&Xs[2][o]) = l;
+    }
+#pragma unroll
+    for (int e = 0; e < BE; ++e) {
+      const int idx = tid + NT * e;
+      const int pp = idx / (BN / 4), j4 = idx % (BN / 4);
+      uint2 h, m, l;
+      split4(vb[e], h, m, l);
+      const uint32_t o = tr_off(pp, j4 * 4);
+      *reinterpret_cast<uint2*>(&Ds[0][o]) = h;
+      *reinterpret_cast<uint2*>(&Ds[1][o]) = m;
+      *reinterpret_cast<uint2*>(&Ds[2][o]) = l;
+    }
+  };
+  // transposing fragment reads: 16-lane group g = lane >> 4 handles columns 16 (g & 1) .. +15 of a 32-wide MFMA tile and
+  // the reduction rows of half lh = g >> 1; inside it lane 4q + p addresses row q, columns 4p .. 4p+3
+  const int tq = (lane & 15) >> 2, tp = lane & 3, tcol = 16 * ((lane >> 4) & 1) + 4 * tp;
+
+  if (kt_begin < kt_end) {
+    load_tiles(kt_begin);
+    store_tiles();
+  }
+  __syncthreads();
+  VCG_STAMP_AT(1);
+  for (int kt = kt_begin; kt < kt_end; ++kt) {
+    if (kt + 1 < kt_end) load_tiles(kt + 1);
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      const int row0 = 16 * s2 + 8 * lh + tq;
+      bf16x8 af[3][MI], bfr[3][NI];
+#pragma unroll
+      for (int pc = 0; pc < 3; ++pc) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i) af[pc][i] = tr_frag(Xs[pc], row0, wm * (BM / WR) + i * 32 + tcol);
+#pragma unroll
+        for (int j = 0; j < NI; ++j) bfr[pc][j] = tr_frag(Ds[pc], row0, wn * (BN / 2) + j * 32 + tcol);
+      }
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+          f32x16 c = lo[i][j];
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][i], bfr[1][j], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2][i], bfr[0][j], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bfr[2][j], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][i], bfr[0][j], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bfr[1][j], c, 0, 0, 0);
+          lo[i][j] = c;
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bfr[0][j], acc[i][j], 0, 0, 0);
+        }
+    }
+    __syncthreads();
+    if (kt + 1 < kt_end) {
+      store_tiles();
+      __syncthreads();
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j) acc[i][j] += lo[i][j];
+  VCG_STAMP_AT(2);
+  const int part = (int)blockIdx.x - (int)fd_div((uint32_t)(tile * p.ktiles_total), p.fd_sklen);
+  float* slab = p.out + ((size_t)part * p.nbatch + zb) * p.K * p.Cout;      // slab[part][batch][K][Cout]
+#pragma unroll
+  for (int j = 0; j < NI; ++j) {
+    const int co = n0 + wn * (BN / 2) + j * 32 + l31;
+    if (co >= p.Cout) continue;
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = (e & 3) + 8 * (e >> 2) + 4 * lh;
+        const int Rr = r0 + wm * (BM / WR) + i * 32 + row;
+        if (Rr < p.K) slab[(size_t)Rr * p.Cout + co] = acc[i][j][e];
+      }
+    }
+  }
+  unit += kt_end - kt_begin;
+  if (unit < unit_end) __syncthreads();           // the next segment's prologue overwrites LDS half 0
+  }
+  VCG_STAMP_AT(3);
+}
+
 // number of partial sums the stream-K split left for the tile that holds element (R, co)
 __device__ __forceinline__ int sk_parts(const ConvP& p, int R, int co) {
   const int tile = (R >> p.sk_bm_shift) * p.sk_ntn + (co >> p.sk_bn_shift);
@@ -1948,7 +2185,7 @@ int vcg_wino_wgrad_core(const ConvGeom& g, const float* V, const float* dM, int 
   p.sk_ntr_pb = wp.ntr / 16;
   p.fd_sklen = make_fastdiv((uint32_t)wp.len);
   dim3 grid(wp.grid);
-  if (wp.bm == 128 && wp.bn == 128) hipLaunchKernelGGL((k_conv_wgrad<128, 128>), grid, dim3(256), 0, st, p);
+  if (wp.bm == 128 && wp.bn == 128) hipLaunchKernelGGL(k_conv_wgrad_split, grid, dim3(256), 0, st, p);        // split-operand bf16
   else if (wp.bm == 128 && wp.bn == 64) hipLaunchKernelGGL((k_conv_wgrad<128, 64>), grid, dim3(256), 0, st, p);
   else if (wp.bm == 64 && wp.bn == 128) hipLaunchKernelGGL((k_conv_wgrad<64, 128>), grid, dim3(256), 0, st, p);
   else hipLaunchKernelGGL((k_conv_wgrad<64, 64>), grid, dim3(256), 0, st, p);
@@ -2034,7 +2271,7 @@ extern "C" int vcg_conv_wgrad(const float* x, const float* dy, float* gw_oihw, f
   dim3 grid(wp.grid);
   hipStream_t st = (hipStream_t)stream;
   if (bm == 256) hipLaunchKernelGGL((k_conv_wgrad<256, 128, 512>), grid, dim3(512), 0, st, p);
-  else if (bm == 128 && bn == 128) hipLaunchKernelGGL((k_conv_wgrad<128, 128>), grid, dim3(256), 0, st, p);
+  else if (bm == 128 && bn == 128) hipLaunchKernelGGL(k_conv_wgrad_split, grid, dim3(256), 0, st, p);     // split-operand bf16
   else if (bm == 128 && bn == 64) hipLaunchKernelGGL((k_conv_wgrad<128, 64>), grid, dim3(256), 0, st, p);
   else if (bm == 64 && bn == 128) hipLaunchKernelGGL((k_conv_wgrad<64, 128>), grid, dim3(256), 0, st, p);
   else hipLaunchKernelGGL((k_conv_wgrad<64, 64>), grid, dim3(256), 0, st, p);
