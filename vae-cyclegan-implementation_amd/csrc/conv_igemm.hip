@@ -1234,22 +1234,25 @@ __global__ __launch_bounds__(NT) void k_conv_wgrad(ConvP p) {
 // ds_read_b64_tr_b16: per 16-lane group it takes a 4-row x 16-column block and hands each lane one column's four
 // rows — two such reads give a lane its 8 reduction indices.  Everything else (stream-K segments, gather, slabs) is
 // k_conv_wgrad's.
-__device__ __forceinline__ uint32_t tr_off(int row, int col) {       // byte offset of element (row, col) in a 256-B-row image
-  const int f = ((row & 3) << 2) | ((row >> 2) & 3);
-  return (uint32_t)(256 * row + 16 * ((col >> 3) ^ f) + (col & 7) * 2);
+template <int COLS>
+__device__ __forceinline__ uint32_t tr_off(int row, int col) {       // byte offset of element (row, col) in a [rows][COLS] bf16 image
+  const int f = (((row & 3) << 2) | ((row >> 2) & 3)) & (COLS / 8 - 1);
+  return (uint32_t)(2 * COLS * row + 16 * ((col >> 3) ^ f) + (col & 7) * 2);
 }
 typedef short s16x4 __attribute__((ext_vector_type(4)));
+template <int COLS>
 __device__ __forceinline__ bf16x8 tr_frag(const unsigned char* img, int row0, int col) {   // rows row0 .. row0+7 of column `col`
-  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(img + tr_off(row0, col)));
-  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(img + tr_off(row0 + 4, col)));
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(img + tr_off<COLS>(row0, col)));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(img + tr_off<COLS>(row0 + 4, col)));
   typedef short s16x8 __attribute__((ext_vector_type(8)));
   const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
   return __builtin_bit_cast(bf16x8, v);
 }
 
+template <int BN>
 __global__ __launch_bounds__(256, 2) void k_conv_wgrad_split(ConvP p) {
   VCG_STAMP_AT(0);
-  constexpr int BM = 128, BN = 128, NT = 256;
+  constexpr int BM = 128, NT = 256;
   constexpr int WR = NT / 128;                                 // wave rows (x 2 wave columns)
   constexpr int MI = BM / (32 * WR), NI = BN / 64;
   constexpr int RQ = BM / 4, PS = NT / RQ, AP = BK / PS, BE = (BK * BN / 4) / NT;
@@ -1377,7 +1380,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_wgrad_split(ConvP p) {
     for (int a = 0; a < AP; ++a) {
       uint2 h, m, l;
       split4(va[a], h, m, l);
-      const uint32_t o = tr_off(ps + PS * a, rq * 4);
+      const uint32_t o = tr_off<BM>(ps + PS * a, rq * 4);
       *reinterpret_cast<uint2*>(&Xs[0][o]) = h;
       *reinterpret_cast<uint2*>(&Xs[1][o]) = m;
       *reinterpret_cast<uint2*>(&Xs[2][o]) = l;
@@ -1388,7 +1391,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_wgrad_split(ConvP p) {
       const int pp = idx / (BN / 4), j4 = idx % (BN / 4);
       uint2 h, m, l;
       split4(vb[e], h, m, l);
-      const uint32_t o = tr_off(pp, j4 * 4);
+      const uint32_t o = tr_off<BN>(pp, j4 * 4);
       *reinterpret_cast<uint2*>(&Ds[0][o]) = h;
       *reinterpret_cast<uint2*>(&Ds[1][o]) = m;
       *reinterpret_cast<uint2*>(&Ds[2][o]) = l;
@@ -1413,9 +1416,9 @@ __global__ __launch_bounds__(256, 2) void k_conv_wgrad_split(ConvP p) {
 #pragma unroll
       for (int pc = 0; pc < 3; ++pc) {
 #pragma unroll
-        for (int i = 0; i < MI; ++i) af[pc][i] = tr_frag(Xs[pc], row0, wm * (BM / WR) + i * 32 + tcol);
+        for (int i = 0; i < MI; ++i) af[pc][i] = tr_frag<BM>(Xs[pc], row0, wm * (BM / WR) + i * 32 + tcol);
 #pragma unroll
-        for (int j = 0; j < NI; ++j) bfr[pc][j] = tr_frag(Ds[pc], row0, wn * (BN / 2) + j * 32 + tcol);
+        for (int j = 0; j < NI; ++j) bfr[pc][j] = tr_frag<BN>(Ds[pc], row0, wn * (BN / 2) + j * 32 + tcol);
       }
 #pragma unroll
       for (int i = 0; i < MI; ++i)
@@ -2185,8 +2188,8 @@ int vcg_wino_wgrad_core(const ConvGeom& g, const float* V, const float* dM, int 
   p.sk_ntr_pb = wp.ntr / 16;
   p.fd_sklen = make_fastdiv((uint32_t)wp.len);
   dim3 grid(wp.grid);
-  if (wp.bm == 128 && wp.bn == 128) hipLaunchKernelGGL(k_conv_wgrad_split, grid, dim3(256), 0, st, p);        // split-operand bf16
-  else if (wp.bm == 128 && wp.bn == 64) hipLaunchKernelGGL((k_conv_wgrad<128, 64>), grid, dim3(256), 0, st, p);
+  if (wp.bm == 128 && wp.bn == 128) hipLaunchKernelGGL(k_conv_wgrad_split<128>, grid, dim3(256), 0, st, p);        // split-operand bf16
+  else if (wp.bm == 128 && wp.bn == 64) hipLaunchKernelGGL(k_conv_wgrad_split<64>, grid, dim3(256), 0, st, p);
   else if (wp.bm == 64 && wp.bn == 128) hipLaunchKernelGGL((k_conv_wgrad<64, 128>), grid, dim3(256), 0, st, p);
   else hipLaunchKernelGGL((k_conv_wgrad<64, 64>), grid, dim3(256), 0, st, p);
   VCG_LAUNCH_CHECK("vcg_conv_wgrad(winograd gemm)");
@@ -2271,8 +2274,8 @@ extern "C" int vcg_conv_wgrad(const float* x, const float* dy, float* gw_oihw, f
   dim3 grid(wp.grid);
   hipStream_t st = (hipStream_t)stream;
   if (bm == 256) hipLaunchKernelGGL((k_conv_wgrad<256, 128, 512>), grid, dim3(512), 0, st, p);
-  else if (bm == 128 && bn == 128) hipLaunchKernelGGL(k_conv_wgrad_split, grid, dim3(256), 0, st, p);     // split-operand bf16
-  else if (bm == 128 && bn == 64) hipLaunchKernelGGL((k_conv_wgrad<128, 64>), grid, dim3(256), 0, st, p);
+  else if (bm == 128 && bn == 128) hipLaunchKernelGGL(k_conv_wgrad_split<128>, grid, dim3(256), 0, st, p);     // split-operand bf16
+  else if (bm == 128 && bn == 64) hipLaunchKernelGGL(k_conv_wgrad_split<64>, grid, dim3(256), 0, st, p);
   else if (bm == 64 && bn == 128) hipLaunchKernelGGL((k_conv_wgrad<64, 128>), grid, dim3(256), 0, st, p);
   else hipLaunchKernelGGL((k_conv_wgrad<64, 64>), grid, dim3(256), 0, st, p);
   VCG_LAUNCH_CHECK("vcg_conv_wgrad");
