@@ -140,8 +140,12 @@ def main():
                    "image_size": S, "latent_dim": latent, "parallelism": f"dp{world}", "init": "random (reference init statistics)"},
     }
 
-    if rank == 0 and not args.no_roofline:
-        out.update(measure_roofline(pkg, model, pool, wl, B, S, latent, ms_per_step))
+    if not args.no_roofline:
+        # every rank runs the two extra (untimed) steps: with N > 1 they contain the gradient exchange, which all
+        # ranks must enter; rank 0 reports its own kernels
+        roof = measure_roofline(pkg, model, pool, wl, B, S, latent, ms_per_step, rank)
+        if rank == 0:
+            out.update(roof)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(pkg, wl, S, latent)
     if world > 1:
@@ -152,7 +156,7 @@ def main():
         dist.destroy_process_group()
 
 
-def measure_roofline(pkg, model, pool, wl, B, S, latent, ms_per_step):
+def measure_roofline(pkg, model, pool, wl, B, S, latent, ms_per_step, rank=0):
     """HIP events around every conv launch of two extra steps; the dominant family's algorithmic
     FLOPs / its summed launch time, against the fp32 MFMA peak."""
     ops = pkg.ops
@@ -175,7 +179,7 @@ def measure_roofline(pkg, model, pool, wl, B, S, latent, ms_per_step):
             s[0] += flops
             s[1] += dt
             s[2] += 1
-    dump = os.environ.get("VCG_BENCH_SHAPES")
+    dump = os.environ.get("VCG_BENCH_SHAPES") if rank == 0 else None
     if dump:                                   # per-shape table for kernel work (not part of the JSON line)
         with open(dump, "w") as fh:
             for (name, tag), (fl, sec, cnt) in sorted(shapes.items(), key=lambda kv: -kv[1][1]):

@@ -179,3 +179,37 @@ def test_data_parallel_gradient_exchange_equals_big_batch_gradient():
         assert err < 1e-5, f"rank {rank}: averaged shard gradients differ from the big-batch gradient by {err:.2e}"
         assert merr < 1e-5
         assert scale == 0.5 and w0 == 1.0
+
+
+def test_bench_extra_steps_are_entered_by_every_rank():
+    """bench.py's roofline pass runs two extra training steps; with N > 1 each contains the gradient all-reduce, so the
+    call must not sit behind a rank test (rank 0 alone in a collective hangs the job: seen on a 2-rank rehearsal)."""
+    import ast
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    tree = ast.parse(src)
+
+    def mentions_rank(node):
+        return any(isinstance(n, ast.Name) and n.id == "rank" for n in ast.walk(node))
+
+    class V(ast.NodeVisitor):
+        def __init__(self):
+            self.guards, self.bad, self.seen = [], [], 0
+
+        def visit_If(self, node):
+            self.guards.append(mentions_rank(node.test))
+            for b in node.body:
+                self.visit(b)
+            self.guards.pop()
+            for b in node.orelse:
+                self.visit(b)
+
+        def visit_Call(self, node):
+            if isinstance(node.func, ast.Name) and node.func.id == "measure_roofline":
+                self.seen += 1
+                if any(self.guards):
+                    self.bad.append(node.lineno)
+            self.generic_visit(node)
+
+    v = V()
+    v.visit(tree)
+    assert v.seen == 1 and not v.bad, f"measure_roofline is called under a rank test at bench.py:{v.bad}"

@@ -1575,62 +1575,69 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ 
 }
 
 // Winograd weight gradient, last stage: slabs[part][xi][k][co] hold dU = sum_t V^T dM per transform point xi.
-// dg (3x3) = G^T dU G is the adjoint of U = G g G^T; the sum over parts runs in fixed order first.  Block layout and
-// the coalesced OIHW read-modify-write are those of k_wgrad_reduce (32 co x 8 c x all taps through LDS).
+// dg (3x3) = G^T dU G is the adjoint of U = G g G^T; the sum over parts runs in fixed order first.  A block owns
+// 64 co x 8 c of ONE unshuffle phase (blockIdx.z); a thread owns two neighbouring co (8-byte loads: a wave row is a
+// 256-byte segment of a slab row) and keeps the 16 transform points of a part as 16 independent loads in flight (one
+// dependent load at a time made the D2 reduce latency-bound: 227 us for 42 MB).  The OIHW read-modify-write goes
+// through LDS as in k_wgrad_reduce (9-float runs per (co, c) when ups == 2).  Cout % 64 == 0 (vcg_wino_weight_ok).
 __global__ __launch_bounds__(256) void k_wino_wgrad_reduce(const float* __restrict__ slabs, float* __restrict__ gw, ConvP p,
                                                            int Cin, int ups, int cin_log, int cout_log) {
-  extern __shared__ __attribute__((aligned(16))) float tile[];
+  __shared__ float tile[9 * 8 * 65];
   const int U2 = ups * ups, KK = 9;
-  const int co0 = blockIdx.x * 32, c0 = blockIdx.y * 8;
-  const int cl_ = threadIdx.x >> 5, col = threadIdx.x & 31;
+  const int co0 = blockIdx.x * 64, c0 = blockIdx.y * 8, ph = blockIdx.z;
+  const int cl_ = threadIdx.x >> 5, col = (threadIdx.x & 31) * 2;
   const size_t plane = (size_t)p.nbatch * p.K * p.Cout;          // one part: [16][Kc][Cout]
   {
     const int c = c0 + cl_, co = co0 + col;
-    const bool ok = c < Cin && co < p.Cout;
-    for (int ph = 0; ph < U2; ++ph) {
-      float s[16];
+    const bool ok = c < Cin;
+    float2 s[16];
+    int nz[16], nzmax = 0;
 #pragma unroll
-      for (int xi = 0; xi < 16; ++xi) {
-        float a = 0.f;
-        if (ok) {
-          const int R = xi * p.K + ph * Cin + c;
-          const int nz = sk_parts(p, R, co);
-          const size_t idx = (size_t)R * p.Cout + co;
-          for (int z = 0; z < nz; ++z) a += slabs[(size_t)z * plane + idx];
-        }
-        s[xi] = a;
-      }
+    for (int xi = 0; xi < 16; ++xi) {
+      nz[xi] = ok ? sk_parts(p, xi * p.K + ph * Cin + c, co) : 0;
+      nzmax = nz[xi] > nzmax ? nz[xi] : nzmax;
+      s[xi] = make_float2(0.f, 0.f);
+    }
+    const float* src = slabs + (size_t)(ph * Cin + (ok ? c : 0)) * p.Cout + co;
+    const size_t xstride = (size_t)p.K * p.Cout;
+    for (int z = 0; z < nzmax; ++z) {                              // parts in fixed order; adding 0 past a tile's count
+      float2 v[16];
+#pragma unroll
+      for (int xi = 0; xi < 16; ++xi)
+        v[xi] = z < nz[xi] ? *reinterpret_cast<const float2*>(src + (size_t)z * plane + (size_t)xi * xstride) : make_float2(0.f, 0.f);
+#pragma unroll
+      for (int xi = 0; xi < 16; ++xi) { s[xi].x += v[xi].x; s[xi].y += v[xi].y; }
+    }
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
       float h[3][4];
 #pragma unroll
       for (int b = 0; b < 4; ++b) {
-        h[0][b] = s[0 + b] + 0.5f * (s[4 + b] + s[8 + b]);
-        h[1][b] = 0.5f * (s[4 + b] - s[8 + b]);
-        h[2][b] = 0.5f * (s[4 + b] + s[8 + b]) + s[12 + b];
+        const float s0 = e ? s[0 + b].y : s[0 + b].x, s1 = e ? s[4 + b].y : s[4 + b].x;
+        const float s2 = e ? s[8 + b].y : s[8 + b].x, s3 = e ? s[12 + b].y : s[12 + b].x;
+        h[0][b] = s0 + 0.5f * (s1 + s2);
+        h[1][b] = 0.5f * (s1 - s2);
+        h[2][b] = 0.5f * (s1 + s2) + s3;
       }
 #pragma unroll
       for (int a = 0; a < 3; ++a) {
-        const float d0 = h[a][0] + 0.5f * (h[a][1] + h[a][2]);
-        const float d1 = 0.5f * (h[a][1] - h[a][2]);
-        const float d2 = 0.5f * (h[a][1] + h[a][2]) + h[a][3];
-        tile[(((a * 3 + 0) * U2 + ph) * 8 + cl_) * 33 + col] = d0;
-        tile[(((a * 3 + 1) * U2 + ph) * 8 + cl_) * 33 + col] = d1;
-        tile[(((a * 3 + 2) * U2 + ph) * 8 + cl_) * 33 + col] = d2;
+        tile[((a * 3 + 0) * 8 + cl_) * 65 + col + e] = h[a][0] + 0.5f * (h[a][1] + h[a][2]);
+        tile[((a * 3 + 1) * 8 + cl_) * 65 + col + e] = 0.5f * (h[a][1] - h[a][2]);
+        tile[((a * 3 + 2) * 8 + cl_) * 65 + col + e] = 0.5f * (h[a][1] + h[a][2]) + h[a][3];
       }
     }
   }
   __syncthreads();
   const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int cinL = cin_log * U2;
-  const int run = 8 * U2 * KK;
-  for (int j = 0; j < 8; ++j) {
-    const int colw = wid * 8 + j, co = co0 + colw;
+  for (int j = 0; j < 16; ++j) {
+    const int colw = wid * 16 + j, co = co0 + colw;
     if (co >= cout_log) continue;
-    for (int q = lane; q < run; q += 64) {
-      const int clq = q / KK, tap9 = q - clq * KK;
-      const int c_local = clq / U2, ph = clq - c_local * U2;
+    for (int q = lane; q < 8 * KK; q += 64) {
+      const int c_local = q / KK, tap9 = q - c_local * KK;
       const int c = c0 + c_local;
       if (c >= cin_log) continue;
-      gw[((size_t)co * cinL + (size_t)c * U2 + ph) * KK + tap9] += tile[((tap9 * U2 + ph) * 8 + c_local) * 33 + colw];
+      gw[((size_t)co * cinL + (size_t)c * U2 + ph) * KK + tap9] += tile[(tap9 * 8 + c_local) * 65 + colw];
     }
   }
 }
@@ -2193,10 +2200,8 @@ int vcg_wino_wgrad_core(const ConvGeom& g, const float* V, const float* dM, int 
   else if (wp.bm == 64 && wp.bn == 128) hipLaunchKernelGGL((k_conv_wgrad<64, 128>), grid, dim3(256), 0, st, p);
   else hipLaunchKernelGGL((k_conv_wgrad<64, 64>), grid, dim3(256), 0, st, p);
   VCG_LAUNCH_CHECK("vcg_conv_wgrad(winograd gemm)");
-  const int U2 = g.ups * g.ups;
-  const size_t lds = (size_t)9 * U2 * 8 * 33 * sizeof(float);
-  hipLaunchKernelGGL(k_wino_wgrad_reduce, dim3((g.Cout + 31) / 32, (g.Cin + 7) / 8), dim3(256), lds, st, (const float*)ws,
-                     gw_oihw, p, g.Cin, g.ups, g.cin_log, g.cout_log);
+  hipLaunchKernelGGL(k_wino_wgrad_reduce, dim3(g.Cout / 64, (g.Cin + 7) / 8, g.ups * g.ups), dim3(256), 0, st,
+                     (const float*)ws, gw_oihw, p, g.Cin, g.ups, g.cin_log, g.cout_log);
   VCG_LAUNCH_CHECK("vcg_conv_wgrad(winograd reduce)");
   return 0;
 }
