@@ -27,6 +27,10 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 FP32_MFMA_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs @ 2.4 GHz
+# The GEMMs run on the bf16 matrix pipe with every fp32 operand split into three bf16 pieces and six cross products
+# accumulated in fp32 (csrc/gemm_split.hip): fp32-level results at 6 bf16 MFMAs per fp32 multiply-add.
+BF16_MFMA_PEAK_TFLOPS = 16 * FP32_MFMA_PEAK_TFLOPS          # same guide: BF16 dense = 16x the F32 MFMA rate (~2.5 PF)
+BF16X3_FP32_EQUIV_PEAK_TFLOPS = BF16_MFMA_PEAK_TFLOPS / 6   # 419.5: what that pipe can deliver in fp32-equivalent FLOPs
 WORKLOADS = {
     "cyclevaegan": "cyclevaegan unpaired, 3x256x256 synthetic summer<->winter, per-GPU batch 8, latent 64 (BASELINE.json configs[3]/[4])",
     "vae": "vae latent 1024, 3x256x256 synthetic, batch 16 (BASELINE.json configs[2])",
@@ -136,6 +140,8 @@ def main():
         "value": round(images_per_s, 3), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
+        "arithmetic": "fp32 in, fp32 out, fp32 accumulate; GEMM products as 3x bf16 split operands (6 bf16 MFMAs per fp32 MFMA), "
+                      "rounding error at or below PyTorch-CPU fp32 (profiles/r01_conv_accuracy.txt)",
         "config": {"workload": WORKLOADS[wl] if (S == 256) else f"{wl} {S}x{S} batch {B}", "per_gpu_batch": B, "global_batch": B * world,
                    "image_size": S, "latent_dim": latent, "parallelism": f"dp{world}", "init": "random (reference init statistics)"},
     }
@@ -203,6 +209,11 @@ def measure_roofline(pkg, model, pool, wl, B, S, latent, ms_per_step, rank=0):
         "roofline": {"bound": "mfma", "kernel": dom, "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
                      "launches": n // 2, "avg_launch_ms": round(secs / n * 1e3, 4),
+                     "peak_is": "fp32 MFMA (v_mfma_f32_32x32x2_f32), the roofline BASELINE.json's north_star names",
+                     "peak_bf16x3": round(BF16X3_FP32_EQUIV_PEAK_TFLOPS, 1),
+                     "frac_bf16x3": round(ach / BF16X3_FP32_EQUIV_PEAK_TFLOPS, 4),
+                     "peak_bf16x3_is": "dense bf16 MFMA peak / 6: the GEMMs execute on the bf16 pipe as 6 bf16 products per fp32 "
+                                       "product (3-way operand split, fp32 accumulate, fp32-level rounding)",
                      "flops_counted": "direct-convolution 2*M*Cout*K per call (the Winograd layers execute 2.25x fewer)",
                      "measured": "HIP events around every call of the family in two extra steps run on ONE stream "
                                  "(the timed steps overlap weight gradients with data gradients on a second stream)",

@@ -1044,6 +1044,16 @@ __global__ __launch_bounds__(256, 2) void k_conv_dgrad_split(ConvP p) {
   VCG_STAMP_AT(3);
 }
 
+// Stream-K workgroup numbering, XCD-aware: hardware workgroup ids go round-robin over the 8 XCDs, so XCD x gets the
+// ids x, x+8, ...; handing it a CONTIGUOUS range of logical workgroups (= consecutive tiles: the column tiles of one
+// row tile, then the next row tile of the same batch) lets its L2 serve the operand re-reads.  With ids dealt
+// round-robin the weight-gradient GEMMs fetched 7x their operands from the fabric (PMC: 464 MB per launch).
+__device__ __forceinline__ int sk_logical_wg() {
+  const uint32_t nwg = gridDim.x, gid = blockIdx.x;
+  const uint32_t q = nwg >> 3, r = nwg & 7, xcd = gid & 7;
+  return (int)((xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (gid >> 3));
+}
+
 // ------------------------------------------------------------------ wgrad
 // NT = 256: four waves, two such workgroups per CU.  NT = 512: eight waves in lockstep on one 256-row tile, one
 // workgroup per CU — the two waves of a SIMD then advance together (the per-K-step barrier), where two independent
@@ -1065,7 +1075,8 @@ __global__ __launch_bounds__(NT) void k_conv_wgrad(ConvP p) {
   // reflect/address arithmetic are shared by the thread's AP slots.
   const bool row_aligned = !p.adjoint && (p.Wo % BK) == 0;
 
-  int unit = (int)blockIdx.x * p.sk_len;
+  const int wg = sk_logical_wg();
+  int unit = wg * p.sk_len;
   int unit_end = unit + p.sk_len;
   if (unit_end > p.sk_units) unit_end = p.sk_units;
   while (unit < unit_end) {                       // one segment = one tile's K' range [kt_begin, kt_end)
@@ -1205,7 +1216,7 @@ __global__ __launch_bounds__(NT) void k_conv_wgrad(ConvP p) {
   }
 
   VCG_STAMP_AT(2);
-  const int part = (int)blockIdx.x - (int)fd_div((uint32_t)(tile * p.ktiles_total), p.fd_sklen);
+  const int part = wg - (int)fd_div((uint32_t)(tile * p.ktiles_total), p.fd_sklen);
   float* slab = p.out + ((size_t)part * p.nbatch + zb) * p.K * p.Cout;      // slab[part][batch][K][Cout]
 #pragma unroll
   for (int j = 0; j < NI; ++j) {
@@ -1266,7 +1277,8 @@ __global__ __launch_bounds__(256, 2) void k_conv_wgrad_split(ConvP p) {
   // reflect/address arithmetic are shared by the thread's AP slots.
   const bool row_aligned = !p.adjoint && (p.Wo % BK) == 0;
 
-  int unit = (int)blockIdx.x * p.sk_len;
+  const int wg = sk_logical_wg();
+  int unit = wg * p.sk_len;
   int unit_end = unit + p.sk_len;
   if (unit_end > p.sk_units) unit_end = p.sk_units;
   while (unit < unit_end) {                       // one segment = one tile's K' range [kt_begin, kt_end)
@@ -1445,7 +1457,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_wgrad_split(ConvP p) {
 #pragma unroll
     for (int j = 0; j < NI; ++j) acc[i][j] += lo[i][j];
   VCG_STAMP_AT(2);
-  const int part = (int)blockIdx.x - (int)fd_div((uint32_t)(tile * p.ktiles_total), p.fd_sklen);
+  const int part = wg - (int)fd_div((uint32_t)(tile * p.ktiles_total), p.fd_sklen);
   float* slab = p.out + ((size_t)part * p.nbatch + zb) * p.K * p.Cout;      // slab[part][batch][K][Cout]
 #pragma unroll
   for (int j = 0; j < NI; ++j) {

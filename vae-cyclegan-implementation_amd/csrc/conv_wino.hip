@@ -1,11 +1,9 @@
 // Winograd F(2x2, 3x3) for the 3x3 / stride-1 / pad-1 convolutions of the D, R and U blocks
-// (Networks.py:87-136): 2.25x fewer multiplications than the direct form.  On gfx950 fp32 MFMA has no
-// faster low-precision sibling that keeps fp32 results, so cutting the multiplication count is the one lever left
-// once the implicit-GEMM kernels sit at ~75 % of what the matrix pipe sustains.
+// (Networks.py:87-136): 2.25x fewer multiplications than the direct form, whichever pipe multiplies.
 //
 //   V[xi][t][k]  = (B^T d B)[xi]       input transform of the 4x4 patch of output tile t (2x2 outputs), k = (i, j, c)
-//   U[xi][k][co] = (G g G^T)[xi]       weight transform, once per optimizer step (vcg_pack_weight)
-//   M[xi][t][co] = sum_k V U           16 independent GEMMs: the forward MFMA kernel run as a batched 1x1 convolution
+//   U[xi][co][k] = (G g G^T)[xi]       weight transform, once per optimizer step (vcg_pack_weight)
+//   M[xi][t][co] = sum_k V U           16 independent GEMMs: one launch of the split-operand bf16 GEMM (gemm_split.hip)
 //   y            = A^T M A + bias, activation
 //
 // Padding (reflect or zero) and the folded PixelUnshuffle of the D blocks live in the input transform's gather, so
