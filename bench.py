@@ -205,9 +205,10 @@ def measure_roofline(pkg, model, pool, wl, B, S, latent, ms_per_step, rank=0):
                               "k_fold_pad", "k_splitk_finish"],
                "conv_wgrad": ["k_conv_wgrad", "k_wino_in", "k_wino_dy", "k_wino_wgrad_reduce", "k_wgrad_reduce", "k_wgrad_scatter",
                               "k_slab_sum", "k_colsum_partial", "k_colsum_final"]}
+    traffic, traffic_src = profiled_traffic(dom, n // 2) if wl == "cyclevaegan" and B == 8 and S == 256 else (None, None)
     return {
         "roofline": {"bound": "mfma", "kernel": dom, "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                     "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                     "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
                      "launches": n // 2, "avg_launch_ms": round(secs / n * 1e3, 4),
                      "peak_is": "fp32 MFMA (v_mfma_f32_32x32x2_f32), the roofline BASELINE.json's north_star names",
                      "peak_bf16x3": round(BF16X3_FP32_EQUIV_PEAK_TFLOPS, 1),
@@ -222,6 +223,22 @@ def measure_roofline(pkg, model, pool, wl, B, S, latent, ms_per_step, rank=0):
         "step_conv_frac_of_peak": round(step_flops / (ms_per_step * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
         "kernels": kernels,
     }
+
+
+def profiled_traffic(family, launches_per_step):
+    """Fabric-side bytes per launch (= per C-ABI call) of a kernel family, from the committed rocprofv3 PMC passes over
+    this command at the headline config (profiles/r01_pmc_step_traffic.json, written by tools/pmc_summary.py; not
+    measured live: counters need the profiler).  None when the file is missing."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_step_traffic.json")
+    try:
+        with open(path) as fh:
+            fam = json.load(fh)["families"][family]
+    except (OSError, KeyError, ValueError):
+        return None, None
+    per_launch = (fam["read"] + fam["write"]) / max(launches_per_step, 1)
+    return round(per_launch), ("profiles/r01_pmc_step_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over "
+                               "bench.py, read = 2 x FETCH_SIZE (gfx950), Infinity-Cache hits included; bytes per C-ABI call, "
+                               "averaged over the family's launches of one step")
 
 
 def cpu_baseline(pkg, wl, S, latent):
