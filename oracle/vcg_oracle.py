@@ -318,3 +318,64 @@ def cyclevaegan_step(P, state, x, y, eps6, lr, paired=False, lambda_cycle=10.0, 
     outs = {"Gx": Gx.detach(), "FGx": FGx.detach(), "Fy": Fy.detach(), "GFy": GFy.detach(),
             "mu_x": mu_x.detach(), "logvar_x": lv_x.detach()}
     return m, outs, g_grads, d_grads
+
+
+# ----------------------------------------------------------------------------- validation (forward only, eval mode)
+def autoencoder_validation(P, x, y):
+    """Autoencoder.validation_step — Networks.py:386-413"""
+    with torch.no_grad():
+        out = autoencoder_forward(x, P)
+        v = l1(out, y).item()
+    return {"G_loss": v, "total_loss": v, "loss_trans": v}, {"Gx": out}
+
+
+def vae_validation(P, x, y, eps, lambda_kl=1e-5):
+    """VariationalAutoencoder.validation_step — Networks.py:955-988 (randn_like is drawn in eval mode too, :225)"""
+    with torch.no_grad():
+        out, mu, logvar = vae_forward(x, P, "", eps)
+        loss_trans = l1(out, y)
+        loss_kl = kl_loss(mu, logvar)
+        G_loss = loss_trans + lambda_kl * loss_kl
+    return {"G_loss": G_loss.item(), "loss_trans": loss_trans.item(), "loss_kl": loss_kl.item()}, {"Gx": out}
+
+
+def cyclevaegan_validation(P, x, y, eps6, paired=False, lambda_cycle=10.0, lambda_gan=1.0, lambda_kl=1e-5,
+                           lambda_identity=5.0):
+    """CycleVAEGAN.validation_step — Networks.py:2080-2150 under model.eval() (train.py:133): the six VAE forwards of
+    :1909-1924 in the reference's order, discriminators with the STORED spectral-norm vectors (no power iteration in
+    eval mode, torch/nn/utils/spectral_norm.py compute_weight(do_power_iteration=False))."""
+    with torch.no_grad():
+        Gx, mu_x, lv_x = vae_forward(x, P, "G.", eps6[0])
+        Gy, _, _ = vae_forward(y, P, "G.", eps6[1])
+        FGx, mu_FGx, lv_FGx = vae_forward(Gx, P, "F.", eps6[2])
+        Fy, mu_y, lv_y = vae_forward(y, P, "F.", eps6[3])
+        Fx, _, _ = vae_forward(x, P, "F.", eps6[4])
+        GFy, mu_GFy, lv_GFy = vae_forward(Fy, P, "G.", eps6[5])
+        DYGx = discriminator(Gx, P, "DY.", False)
+        DXFy = discriminator(Fy, P, "DX.", False)
+        DXx = discriminator(x, P, "DX.", False)
+        DYy = discriminator(y, P, "DY.", False)
+        loss_cycle = cycle_loss(x, y, FGx, GFy)
+        _, g_x_real, g_x_fake = gan_loss_generator(DXx, DXFy)
+        _, g_y_real, g_y_fake = gan_loss_generator(DYy, DYGx)
+        loss_gan_g_fake = g_x_fake + g_y_fake
+        loss_kl = kl_loss(mu_x, lv_x) + kl_loss(mu_FGx, lv_FGx) + kl_loss(mu_y, lv_y) + kl_loss(mu_GFy, lv_GFy)
+        G_loss = lambda_cycle * loss_cycle + lambda_gan * loss_gan_g_fake + lambda_kl * loss_kl
+        if paired:
+            loss_identity = identity_loss(x, y, Fx, Gy)
+            G_loss = G_loss + lambda_identity * loss_identity
+        d_x, d_x_real, d_x_fake = gan_loss_discriminator(DXx, DXFy)
+        d_y, d_y_real, d_y_fake = gan_loss_discriminator(DYy, DYGx)
+        D_loss = d_x + d_y
+    m = {
+        "total_loss": G_loss.item() + D_loss.item(), "G_loss": G_loss.item(), "D_loss": D_loss.item(),
+        "D_loss_x_real": d_x_real.item(), "D_loss_x_fake": d_x_fake.item(),
+        "D_loss_y_real": d_y_real.item(), "D_loss_y_fake": d_y_fake.item(),
+        "loss_cycle": loss_cycle.item(), "loss_gan_g": loss_gan_g_fake.item(),
+        "loss_gan_g_x_real": g_x_real.item(), "loss_gan_g_x_fake": g_x_fake.item(),
+        "loss_gan_g_y_real": g_y_real.item(), "loss_gan_g_y_fake": g_y_fake.item(),
+        "loss_kl": loss_kl.item(),
+    }
+    if paired:
+        m["loss_identity"] = loss_identity.item()
+    return m, {"Gx": Gx, "Fy": Fy}

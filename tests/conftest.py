@@ -39,6 +39,14 @@ def steps_golden():
 
 
 @pytest.fixture(scope="session")
+def validation_golden():
+    """(arrays, metric dicts) of the reference's eval-mode validation_step (tests/golden/make_golden.py validation)."""
+    with open(os.path.join(GOLDEN, "validation_meta.json")) as f:
+        meta = json.load(f)
+    return dict(np.load(os.path.join(GOLDEN, "validation.npz"))), meta
+
+
+@pytest.fixture(scope="session")
 def steps_meta():
     with open(os.path.join(GOLDEN, "steps_meta.json")) as f:
         return json.load(f)

@@ -7,7 +7,7 @@ recipe (seed + names; the tensors are rebuilt by synth) and the reference's OUTP
 tensors for atom-sized cases, metric dicts, strided slices and per-tensor checksums for the
 full-size training steps.
 
-    python tests/golden/make_golden.py            # writes atoms.npz, steps.npz next to this file
+    python tests/golden/make_golden.py [atoms] [steps] [validation]      # writes atoms.npz, steps.npz, validation.npz next to this file
 """
 import importlib
 import json
@@ -262,12 +262,48 @@ def gen_steps(N, out, meta):
         param_checksums(model, out, key)
 
 
+def gen_validation(N, out, meta):
+    """`validation_step` in eval mode, as `train.validate` runs it (reference train.py:131-171: model.eval(), no_grad):
+    forward-only metrics plus the Gx / Fy images.  Eval mode matters for the discriminators: spectral_norm does no
+    power iteration and normalises by sigma = u . (W v) with the STORED u, v (here the synthetic, non-converged ones)."""
+    torch.set_num_threads(8)
+    for key, ctor, S, B in (("ae64", N.Autoencoder, 64, 2), ("vae64", lambda: N.VariationalAutoencoder(latent_dim=64), 64, 2)):
+        model = ctor()
+        load_synth_params(model, SEED, 0.02, prefix=key + ".")
+        model.configure_optimizers(lr=LR)          # VariationalAutoencoder.validation_step insists on one (Networks.py:963)
+        model.configure_loss(**LAMBDAS)
+        model.eval()
+        x, y = synth.batch(B, S, SEED, step=7)
+        eps = synth.eps_list(1, (B, 64, S // 16, S // 16), SEED, step=7)
+        with EpsInjector(eps):
+            m = model.validation_step({"x": torch.from_numpy(x), "y": torch.from_numpy(y)})
+        out[key + "/Gx"] = m.pop("Gx")[:, :, ::4, ::4].numpy()
+        meta[key] = m
+        print(key, m)
+    for key, paired in (("cvg256_unpaired", False), ("cvg256_paired", True)):
+        model = N.CycleVAEGAN(latent_dim=64, paired=paired)
+        load_synth_params(model, SEED, 0.02, prefix=key + ".")
+        model.configure_optimizers(lr=LR)
+        model.configure_loss(**LAMBDAS)
+        model.eval()
+        x, y = synth.batch(1, 256, SEED, step=7)
+        eps = synth.eps_list(6, (1, 64, 16, 16), SEED, step=7)
+        u0 = model.DX.model[4].weight_u.clone()
+        with EpsInjector(eps):
+            m = model.validation_step({"x": torch.from_numpy(x), "y": torch.from_numpy(y)})
+        assert torch.equal(u0, model.DX.model[4].weight_u), "eval mode must leave the spectral-norm vectors alone"
+        out[key + "/Gx"] = m.pop("Gx")[:, :, ::16, ::16].numpy()
+        out[key + "/Fy"] = m.pop("Fy")[:, :, ::16, ::16].numpy()
+        meta[key] = m
+        print(key, m)
+
+
 def main():
     N, _ = import_reference()
     torch.manual_seed(0)
     atoms, steps, meta = {}, {}, {"seed": SEED, "lr": LR, "lambdas": LAMBDAS,
                                   "torch": torch.__version__, "reference": "Baverne/VAE-CYCLEGAN-Implementation"}
-    which = sys.argv[1:] or ["atoms", "steps"]
+    which = sys.argv[1:] or ["atoms", "steps", "validation"]
     if "atoms" in which:
         gen_atoms(N, atoms)
         np.savez_compressed(os.path.join(HERE, "atoms.npz"), **atoms)
@@ -276,7 +312,13 @@ def main():
         np.savez_compressed(os.path.join(HERE, "steps.npz"), **steps)
         with open(os.path.join(HERE, "steps_meta.json"), "w") as f:
             json.dump(meta, f, indent=1)
-    for fn in ("atoms.npz", "steps.npz", "steps_meta.json"):
+    if "validation" in which:
+        val, vmeta = {}, {"seed": SEED, "lambdas": LAMBDAS, "torch": torch.__version__, "batch_step": 7}
+        gen_validation(N, val, vmeta)
+        np.savez_compressed(os.path.join(HERE, "validation.npz"), **val)
+        with open(os.path.join(HERE, "validation_meta.json"), "w") as f:
+            json.dump(vmeta, f, indent=1)
+    for fn in ("atoms.npz", "steps.npz", "steps_meta.json", "validation.npz", "validation_meta.json"):
         p = os.path.join(HERE, fn)
         if os.path.exists(p):
             print(fn, os.path.getsize(p), "bytes")

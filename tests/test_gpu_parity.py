@@ -394,3 +394,50 @@ def test_cyclevaegan_unconfigured_raises_like_the_reference(pkg, device):
         model.training_step({"x": None, "y": None})
     with pytest.raises(ValueError):
         model.save_optimizer_states()
+
+
+# ------------------------------------------------------------------ validation_step under model.eval()
+VAL_STEP = 7
+
+
+def test_ae_and_vae_validation_match_reference_golden(pkg, device, validation_golden):
+    arrays, meta = validation_golden
+    x, y = (torch.from_numpy(a).to(device) for a in pkg.synth.batch(2, 64, SEED, step=VAL_STEP))
+    model = pkg.Networks.Autoencoder()
+    load_synth(pkg, model, "ae64", STEP_BIAS_STD)
+    model = model.to(device).eval()
+    model.configure_loss(**LAMBDAS)
+    m = model.validation_step({"x": x, "y": y})
+    assert_close(nchw(m.pop("Gx"))[:, :, ::4, ::4], arrays["ae64/Gx"], "AE Gx", l2=1e-3)
+    _check_metrics(m, meta["ae64"], "ae64 validation")
+    model = pkg.Networks.VariationalAutoencoder(latent_dim=64)
+    load_synth(pkg, model, "vae64", STEP_BIAS_STD)
+    model = model.to(device).eval()
+    with pytest.raises(ValueError):                 # the reference's VAE wants an optimizer even to validate (Networks.py:963)
+        model.validation_step({"x": x, "y": y})
+    model.configure_optimizers(lr=LR)
+    model.configure_loss(**LAMBDAS)
+    pkg.ops.inject_eps([torch.from_numpy(e) for e in pkg.synth.eps_list(1, (2, 64, 4, 4), SEED, step=VAL_STEP)])
+    m = model.validation_step({"x": x, "y": y})
+    assert_close(nchw(m.pop("Gx"))[:, :, ::4, ::4], arrays["vae64/Gx"], "VAE Gx", l2=1e-3)
+    _check_metrics(m, meta["vae64"], "vae64 validation")
+
+
+@pytest.mark.parametrize("key,paired", [("cvg256_unpaired", False), ("cvg256_paired", True)])
+def test_cyclevaegan_validation_matches_reference_golden(key, paired, pkg, device, validation_golden):
+    """Eval mode: the discriminators normalise by sigma = u . (W v) with the STORED (here: synthetic, non-converged)
+    spectral-norm vectors and leave them untouched; the generators draw eps as in training."""
+    arrays, meta = validation_golden
+    model = pkg.Networks.CycleVAEGAN(latent_dim=64, paired=paired)
+    load_synth(pkg, model, key, STEP_BIAS_STD)
+    model = model.to(device).eval()
+    model.configure_loss(**LAMBDAS)
+    x, y = (torch.from_numpy(a).to(device) for a in pkg.synth.batch(1, 256, SEED, step=VAL_STEP))
+    pkg.ops.inject_eps([torch.from_numpy(e) for e in pkg.synth.eps_list(6, (1, 64, 16, 16), SEED, step=VAL_STEP)])
+    sd0 = {k: v.clone() for k, v in model.state_dict().items() if k.endswith(("weight_u", "weight_v"))}
+    m = model.validation_step({"x": x, "y": y})
+    for k, v in sd0.items():
+        assert torch.equal(v, model.state_dict()[k]), f"{k} changed in eval mode"
+    assert_close(nchw(m.pop("Gx"))[:, :, ::16, ::16], arrays[key + "/Gx"], "Gx", l2=1e-3)
+    assert_close(nchw(m.pop("Fy"))[:, :, ::16, ::16], arrays[key + "/Fy"], "Fy", l2=1e-3)
+    _check_metrics(m, meta[key], f"{key} validation")

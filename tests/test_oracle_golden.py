@@ -226,3 +226,38 @@ def test_oracle_cyclevaegan_steps_match_reference(key, paired, nsteps, pkg, orac
         _check_metrics(m, steps_meta[key][step], f"{key} step {step}", tol=1e-3 if step == 0 else 2e-2)
         if step == 0:
             check_step_state(P, {**g_grads, **d_grads}, key, steps_golden, LR, snap="@step1", tol=1e-3)
+
+
+# ------------------------------------------------------------------ validation_step in eval mode
+VAL_STEP = 7          # synth batch / eps stream index the validation fixtures were made with
+
+
+def test_oracle_ae_and_vae_validation_match_reference(pkg, oracle, validation_golden):
+    arrays, meta = validation_golden
+    x, y = (torch.from_numpy(a) for a in pkg.synth.batch(2, 64, SEED, step=VAL_STEP))
+    P = _params(pkg, _model_shapes(pkg, "ae64", pkg.Networks.Autoencoder), STEP_BIAS_STD)
+    m, o = oracle.autoencoder_validation({k[5:]: v for k, v in P.items()}, x, y)
+    _check_metrics(m, meta["ae64"], "ae64 validation", tol=1e-4)
+    assert_close(o["Gx"][:, :, ::4, ::4], arrays["ae64/Gx"], "AE Gx", l2=1e-4, mx=1e-3)
+    P = _params(pkg, _model_shapes(pkg, "vae64", lambda: pkg.Networks.VariationalAutoencoder(64)), STEP_BIAS_STD)
+    eps = torch.from_numpy(pkg.synth.eps_list(1, (2, 64, 4, 4), SEED, step=VAL_STEP)[0])
+    m, o = oracle.vae_validation({k[6:]: v for k, v in P.items()}, x, y, eps, LAMBDAS["lambda_kl"])
+    _check_metrics(m, meta["vae64"], "vae64 validation", tol=1e-4)
+    assert_close(o["Gx"][:, :, ::4, ::4], arrays["vae64/Gx"], "VAE Gx", l2=1e-4, mx=1e-3)
+
+
+@pytest.mark.parametrize("key,paired", [("cvg256_unpaired", False), ("cvg256_paired", True)])
+def test_oracle_cyclevaegan_validation_matches_reference(key, paired, pkg, oracle, validation_golden):
+    arrays, meta = validation_golden
+    torch.set_num_threads(max(1, min(8, os.cpu_count() or 1)))
+    P = _params(pkg, _model_shapes(pkg, key, lambda: pkg.Networks.CycleVAEGAN(64, paired)), STEP_BIAS_STD)
+    P = {k[len(key) + 1:]: v for k, v in P.items()}
+    x, y = (torch.from_numpy(a) for a in pkg.synth.batch(1, 256, SEED, step=VAL_STEP))
+    eps = [torch.from_numpy(e) for e in pkg.synth.eps_list(6, (1, 64, 16, 16), SEED, step=VAL_STEP)]
+    u0 = P["DX.model.4.weight_u"].clone()
+    m, o = oracle.cyclevaegan_validation(P, x, y, eps, paired, LAMBDAS["lambda_cycle"], LAMBDAS["lambda_gan"],
+                                         LAMBDAS["lambda_kl"], LAMBDAS["lambda_identity"])
+    assert torch.equal(u0, P["DX.model.4.weight_u"])
+    _check_metrics(m, meta[key], f"{key} validation", tol=1e-3)
+    assert_close(o["Gx"][:, :, ::16, ::16], arrays[key + "/Gx"], "Gx", l2=1e-4, mx=1e-3)
+    assert_close(o["Fy"][:, :, ::16, ::16], arrays[key + "/Fy"], "Fy", l2=1e-4, mx=1e-3)

@@ -109,6 +109,29 @@ def train_epoch(model, dataloader, device, args, writer=None, epoch=None):
     return float("nan"), {k: float("nan") for k in loss_components}, last_output, last_x, last_y
 
 
+def validate(model, dataloader, device, args):
+    """reference train.py:131-171: model.eval(), forward-only `validation_step` per batch, metrics averaged over
+    len(dataloader) with G_loss as the headline; returns (avg_loss, avg_components, last Gx, last Fy, last x, last y).
+    Eval mode changes one thing on this path: the discriminators' spectral norm uses the stored u, v as they are."""
+    model.eval()
+    total_loss = 0.0
+    loss_components = {}
+    last_Gx = last_Fy = last_x = last_y = None
+    with torch.no_grad():
+        for batch in dataloader:
+            batch["x"] = batch["x"].to(device)
+            batch["y"] = batch["y"].to(device)
+            metrics = model.validation_step(batch)
+            Gx = metrics.pop("Gx")
+            Fy = metrics.pop("Fy", None)            # only the Cycle models return it
+            total_loss += metrics["G_loss"]
+            for key, value in metrics.items():
+                loss_components[key] = loss_components.get(key, 0.0) + value
+            last_Gx, last_Fy, last_x, last_y = Gx, Fy, batch["x"], batch["y"]
+    n = len(dataloader)
+    return total_loss / n, {k: v / n for k, v in loss_components.items()}, last_Gx, last_Fy, last_x, last_y
+
+
 def build_parser():
     p = argparse.ArgumentParser(description="Train VAE-CycleGAN models (MI355X-native path)")
     p.add_argument("--architecture", type=str, default="autoencoder", choices=REFERENCE_ARCHS + list(ALIASES))
@@ -197,6 +220,16 @@ def main(args):
             print(f"\nEpoch {epoch + 1}/{args.epochs}\nTrain Loss: {train_loss:.4f}   ({ips:.1f} images/s)")
             for k, v in comps.items():
                 print(f"  {k}: {v:.6f}")
+        # on the test set (reference train.py:533-537: every log_image_freq epochs); here a held-out synthetic stream.
+        # validation_step has no exchange in it: every rank validates its own shard, rank 0 prints its numbers
+        if args.log_image_freq > 0 and epoch % args.log_image_freq == 0:
+            test_loader = SyntheticLoader(args.batch_size, args.image_size, max(1, args.steps_per_epoch // 10), device,
+                                          args.seed + 1, rank, same_xy, epoch)
+            test_loss, test_comps, *_ = validate(model, test_loader, device, args)
+            if rank == 0:
+                print(f"Test Loss: {test_loss:.4f}")
+                for k, v in test_comps.items():
+                    print(f"  {k}: {v:.6f}")
     if world > 1:
         dist.destroy_process_group()
     if rank == 0:
