@@ -7,7 +7,7 @@ recipe (seed + names; the tensors are rebuilt by synth) and the reference's OUTP
 tensors for atom-sized cases, metric dicts, strided slices and per-tensor checksums for the
 full-size training steps.
 
-    python tests/golden/make_golden.py [atoms] [steps] [validation]      # writes atoms.npz, steps.npz, validation.npz next to this file
+    python tests/golden/make_golden.py [atoms] [steps] [validation] [checkpoint]      # writes atoms.npz, steps.npz, validation.npz next to this file
 """
 import importlib
 import json
@@ -298,12 +298,50 @@ def gen_validation(N, out, meta):
         print(key, m)
 
 
+def gen_checkpoint_skeleton(N):
+    """Structure of the checkpoints the REFERENCE writes (utils.py:17-28: torch.save of {epoch, model_state_dict,
+    optimizer_states, loss, args}) after one training step: key names, shapes and dtypes of every tensor, the optimizer
+    state layout.  Values are pinned elsewhere (steps.npz); files of 0.3-1.7 GB cannot be committed, their skeleton can."""
+    import argparse
+    import tempfile
+    utils = importlib.import_module("utils")          # /root/reference/utils.py
+    torch.set_num_threads(8)
+
+    def describe(v):
+        if isinstance(v, torch.Tensor):
+            return {"tensor": list(v.shape), "dtype": str(v.dtype)}
+        if isinstance(v, dict):
+            return {str(k): describe(x) for k, x in v.items()}
+        if isinstance(v, (list, tuple)):
+            return [describe(x) for x in v]
+        return {"py": type(v).__name__, "value": v if isinstance(v, (int, float, str, bool, type(None))) else repr(v)}
+
+    skel = {}
+    for key, ctor, S in (("autoencoder", N.Autoencoder, 64), ("vae", lambda: N.VariationalAutoencoder(latent_dim=64), 64),
+                         ("cyclevaegan", lambda: N.CycleVAEGAN(latent_dim=64, paired=False), 256)):
+        model = ctor()
+        model.configure_optimizers(lr=LR)
+        model.configure_loss(**LAMBDAS)
+        model.train()
+        x, y = synth.batch(1, S, SEED, step=0)
+        m = model.training_step({"x": torch.from_numpy(x), "y": torch.from_numpy(y if key == "cyclevaegan" else x)})
+        args = argparse.Namespace(architecture=key, lr=LR, batch_size=1)
+        with tempfile.TemporaryDirectory() as d:
+            fn = os.path.join(d, "ck.pth")
+            utils.save_checkpoint(model, 3, m["G_loss"], args, fn)
+            ck = torch.load(fn, map_location="cpu", weights_only=False)
+        skel[key] = describe(ck)
+        skel[key]["loss"]["value"] = None           # a run-dependent number
+        print(key, "checkpoint keys:", list(ck), "state_dict tensors:", len(ck["model_state_dict"]))
+    return skel
+
+
 def main():
     N, _ = import_reference()
     torch.manual_seed(0)
     atoms, steps, meta = {}, {}, {"seed": SEED, "lr": LR, "lambdas": LAMBDAS,
                                   "torch": torch.__version__, "reference": "Baverne/VAE-CYCLEGAN-Implementation"}
-    which = sys.argv[1:] or ["atoms", "steps", "validation"]
+    which = sys.argv[1:] or ["atoms", "steps", "validation", "checkpoint"]
     if "atoms" in which:
         gen_atoms(N, atoms)
         np.savez_compressed(os.path.join(HERE, "atoms.npz"), **atoms)
@@ -318,7 +356,10 @@ def main():
         np.savez_compressed(os.path.join(HERE, "validation.npz"), **val)
         with open(os.path.join(HERE, "validation_meta.json"), "w") as f:
             json.dump(vmeta, f, indent=1)
-    for fn in ("atoms.npz", "steps.npz", "steps_meta.json", "validation.npz", "validation_meta.json"):
+    if "checkpoint" in which:
+        with open(os.path.join(HERE, "checkpoint_skeleton.json"), "w") as f:
+            json.dump(gen_checkpoint_skeleton(N), f, indent=0)
+    for fn in ("atoms.npz", "steps.npz", "steps_meta.json", "validation.npz", "validation_meta.json", "checkpoint_skeleton.json"):
         p = os.path.join(HERE, fn)
         if os.path.exists(p):
             print(fn, os.path.getsize(p), "bytes")

@@ -441,3 +441,70 @@ def test_cyclevaegan_validation_matches_reference_golden(key, paired, pkg, devic
     assert_close(nchw(m.pop("Gx"))[:, :, ::16, ::16], arrays[key + "/Gx"], "Gx", l2=1e-3)
     assert_close(nchw(m.pop("Fy"))[:, :, ::16, ::16], arrays[key + "/Fy"], "Fy", l2=1e-3)
     _check_metrics(m, meta[key], f"{key} validation")
+
+
+# ------------------------------------------------------------------ checkpoint wire format
+def _describe(v):
+    if isinstance(v, torch.Tensor):
+        return {"tensor": list(v.shape), "dtype": str(v.dtype)}
+    if isinstance(v, dict):
+        return {str(k): _describe(x) for k, x in v.items()}
+    if isinstance(v, (list, tuple)):
+        return [_describe(x) for x in v]
+    return {"py": type(v).__name__, "value": v if isinstance(v, (int, float, str, bool, type(None))) else repr(v)}
+
+
+@pytest.mark.parametrize("arch", ["autoencoder", "vae", "cyclevaegan"])
+def test_checkpoint_has_the_reference_format_and_resumes_bit_identically(arch, pkg, device, tmp_path):
+    """A checkpoint written here has the structure of one written by the reference (tests/golden/checkpoint_skeleton.json:
+    top-level keys, every state_dict name / shape / dtype, Adam state layout and param-group fields), and a fresh model
+    restored from it continues exactly like the uninterrupted run (same metrics and parameters, bit for bit)."""
+    import argparse
+    import json
+    with open(os.path.join(os.path.dirname(__file__), "golden", "checkpoint_skeleton.json")) as fh:
+        skel = json.load(fh)[arch]
+    S = 256 if arch == "cyclevaegan" else 64
+
+    def make():
+        torch.manual_seed(5)
+        m = {"autoencoder": pkg.Networks.Autoencoder, "vae": lambda: pkg.Networks.VariationalAutoencoder(latent_dim=64),
+             "cyclevaegan": lambda: pkg.Networks.CycleVAEGAN(latent_dim=64, paired=False)}[arch]()
+        m = m.to(device).train()
+        m.configure_optimizers(lr=LR)
+        m.configure_loss(**LAMBDAS)
+        return m
+
+    def batch(step):
+        x, y = pkg.synth.batch(1, S, SEED, step=step)
+        xb = torch.from_numpy(x).to(device)
+        return {"x": xb, "y": torch.from_numpy(y).to(device) if arch == "cyclevaegan" else xb}
+
+    a = make()
+    pkg.ops.manual_seed(99)
+    m0 = a.training_step(batch(0))
+    fn = str(tmp_path / "ck.pth")
+    pkg.utils.save_checkpoint(a, 3, m0["G_loss"], argparse.Namespace(architecture=arch, lr=LR, batch_size=1), fn)
+    ck = torch.load(fn, map_location="cpu", weights_only=False)
+    got = _describe(ck)
+    got["loss"]["value"] = None
+    assert list(got) == list(skel)
+    assert got["model_state_dict"] == skel["model_state_dict"]
+    assert got["optimizer_states"] == skel["optimizer_states"]
+    assert got["epoch"] == skel["epoch"] and got["args"] == skel["args"] and got["loss"]["py"] == skel["loss"]["py"]
+
+    pkg.ops.manual_seed(123)                       # same eps stream for both continuations
+    m1 = a.training_step(batch(1))
+    b = make()
+    with torch.no_grad():                          # different values until the checkpoint is loaded
+        for p in b.parameters():
+            p.mul_(0.5)
+    epoch, loss = pkg.utils.load_checkpoint(b, fn, device)
+    assert epoch == 3 and loss == m0["G_loss"]
+    pkg.ops.manual_seed(123)
+    m1b = b.training_step(batch(1))
+    assert m1b == m1, f"resumed step differs: {m1b} vs {m1}"
+    sa, sb = a.state_dict(), b.state_dict()
+    for k in sa:
+        assert torch.equal(sa[k], sb[k]), f"{k} differs after the resumed step"
+    with pytest.raises(FileNotFoundError):
+        pkg.utils.load_checkpoint(b, str(tmp_path / "missing.pth"), device)

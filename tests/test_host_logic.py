@@ -123,6 +123,23 @@ def test_validate_averages_like_the_reference():
     assert gx.item() == 4.0 and fy is not None and lx is batches[-1]["x"] and ly is batches[-1]["y"]
 
 
+def test_checkpoint_skeleton_fixture_matches_our_state_dict_surface(pkg):
+    """tests/golden/checkpoint_skeleton.json (structure of checkpoints written by the reference's utils.save_checkpoint):
+    the model_state_dict section names exactly our modules' state_dict entries, with the same shapes."""
+    import json
+    with open(os.path.join(ROOT, "tests", "golden", "checkpoint_skeleton.json")) as fh:
+        skel = json.load(fh)
+    for arch, ctor in (("autoencoder", pkg.Networks.Autoencoder), ("vae", lambda: pkg.Networks.VariationalAutoencoder(64)),
+                       ("cyclevaegan", lambda: pkg.Networks.CycleVAEGAN(64, False))):
+        assert list(skel[arch]) == ["epoch", "model_state_dict", "optimizer_states", "loss", "args"]
+        ours = {k: list(v.shape) for k, v in ctor().state_dict().items()}
+        ref = {k: v["tensor"] for k, v in skel[arch]["model_state_dict"].items()}
+        assert list(ours) == list(ref) and ours == ref
+        for name, opt in skel[arch]["optimizer_states"].items():
+            assert name in ("optimizer", "optimizer_G", "optimizer_D")
+            assert set(opt) == {"state", "param_groups"} and len(opt["param_groups"]) == 1
+
+
 # ------------------------------------------------------------------ data parallel over gloo, world_size 2
 def _free_port():
     s = socket.socket()

@@ -320,7 +320,7 @@ class Autoencoder(_OptimizerStatesMixin, nn.Module):
         x, y = ops.to_nhwc(batch["x"]), ops.to_nhwc(batch["y"])
         output = self(x)
         loss_trans = self.loss_fn(output, y)
-        value = float(loss_trans)                      # the reference's isnan/isinf guard syncs here too (:357)
+        value = float(loss_trans.detach())             # the reference's isnan/isinf guard syncs here too (:357)
         if math.isnan(value) or math.isinf(value):
             print("NaN or Inf detected in loss during training step; skipping the update.")
             self.optimizer.zero_grad()

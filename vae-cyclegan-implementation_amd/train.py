@@ -29,9 +29,9 @@ if __package__ in (None, ""):
     import importlib
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     _pkg = importlib.import_module("vae-cyclegan-implementation_amd")
-    Networks, ops, parallel = _pkg.Networks, _pkg.ops, _pkg.parallel
+    Networks, ops, parallel, utils = _pkg.Networks, _pkg.ops, _pkg.parallel, _pkg.utils
 else:
-    from . import Networks, ops, parallel
+    from . import Networks, ops, parallel, utils
 
 ALIASES = {"ae": "autoencoder", "vae_cyclegan": "cyclevaegan"}
 BUILT = ("autoencoder", "vae", "cyclevaegan")
@@ -172,8 +172,8 @@ def main(args):
     if args.dataset != "synthetic":
         raise NotImplementedError("only --dataset synthetic is built: the image pipelines of Data_Manager.py "
                                   "(PIL + torchvision) are outside the accelerated path (SURVEY.md §2)")
-    if args.resume or args.pretrained_doubleae or args.pretrained_doublevae:
-        raise NotImplementedError("--resume/--pretrained_* (checkpoint wire format) is a next-step row (SURVEY.md §8f)")
+    if args.pretrained_doubleae or args.pretrained_doublevae:
+        raise NotImplementedError("--pretrained_double* remap checkpoints of composites that are not built (SURVEY.md §8f.3)")
     if args.no_cuda or not torch.cuda.is_available():
         raise RuntimeError("this path has no CPU implementation: an MI355X is required (the reference's own "
                            "train.py is the CPU path)")
@@ -207,7 +207,14 @@ def main(args):
         parallel.attach(model)
         parallel.broadcast_parameters(model)
     same_xy = args.architecture in ("autoencoder", "vae")
-    for epoch in range(args.epochs):
+    start_epoch = 0
+    if args.resume:                                  # reference train.py:471-477
+        if rank == 0:
+            print(f"Resuming from checkpoint: {args.resume}")
+        start_epoch, _ = utils.load_checkpoint(model, Path(args.resume), device)
+        start_epoch += 1
+    best_test_loss = float("inf")
+    for epoch in range(start_epoch, args.epochs):
         loader = SyntheticLoader(args.batch_size, args.image_size, args.steps_per_epoch, device, args.seed, rank,
                                  same_xy, epoch)
         torch.cuda.synchronize()
@@ -230,6 +237,12 @@ def main(args):
                 print(f"Test Loss: {test_loss:.4f}")
                 for k, v in test_comps.items():
                     print(f"  {k}: {v:.6f}")
+                if test_loss < best_test_loss:       # reference train.py:565-570
+                    best_test_loss = test_loss
+                    utils.save_checkpoint(model, epoch, test_loss, args, output_dir / "best_model.pth")
+                    print(f"New best model saved (test_loss: {test_loss:.4f})")
+        if rank == 0 and (epoch + 1) % args.save_freq == 0:      # reference train.py:573-575 (replicas are identical)
+            utils.save_checkpoint(model, epoch, train_loss, args, output_dir / f"checkpoint_epoch_{epoch + 1}.pth")
     if world > 1:
         dist.destroy_process_group()
     if rank == 0:
