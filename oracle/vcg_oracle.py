@@ -379,3 +379,80 @@ def cyclevaegan_validation(P, x, y, eps6, paired=False, lambda_cycle=10.0, lambd
     if paired:
         m["loss_identity"] = loss_identity.item()
     return m, {"Gx": Gx, "Fy": Fy}
+
+
+# ----------------------------------------------------------------------------- CycleAEGAN
+def _cycleaegan_losses(Q, x, y, paired, lambda_cycle, lambda_gan, lambda_identity, run_d):
+    """Shared by the training and validation steps: forward :1654-1665 and the generator objective :1733-1753 — the
+    WHOLE LSGAN generator loss (real + fake terms) enters G_loss, unlike CycleVAEGAN's fake-only sum."""
+    Gx = autoencoder_forward(x, Q, "G.")
+    Gy = autoencoder_forward(y, Q, "G.")
+    FGx = autoencoder_forward(Gx, Q, "F.")
+    Fy = autoencoder_forward(y, Q, "F.")
+    Fx = autoencoder_forward(x, Q, "F.")
+    GFy = autoencoder_forward(Fy, Q, "G.")
+    DYGx, DXFy, DXx, DYy = run_d(Gx, "DY."), run_d(Fy, "DX."), run_d(x, "DX."), run_d(y, "DY.")
+    loss_cycle = cycle_loss(x, y, FGx, GFy)
+    g_x, g_x_real, g_x_fake = gan_loss_generator(DXx, DXFy)
+    g_y, g_y_real, g_y_fake = gan_loss_generator(DYy, DYGx)
+    loss_gan_g = g_x + g_y
+    G_loss = lambda_cycle * loss_cycle + lambda_gan * loss_gan_g
+    loss_identity = None
+    if paired:
+        loss_identity = identity_loss(x, y, Fx, Gy)
+        G_loss = G_loss + lambda_identity * loss_identity
+    m = {"loss_cycle": loss_cycle, "loss_gan_g": loss_gan_g, "loss_gan_g_x_real": g_x_real, "loss_gan_g_x_fake": g_x_fake,
+         "loss_gan_g_y_real": g_y_real, "loss_gan_g_y_fake": g_y_fake}
+    if paired:
+        m["loss_identity"] = loss_identity
+    return G_loss, m, (Gx, FGx, Fy, GFy), (DYGx, DXFy, DXx, DYy)
+
+
+def cycleaegan_step(P, state, x, y, lr, paired=False, lambda_cycle=10.0, lambda_gan=1.0, lambda_identity=5.0):
+    """CycleAEGAN.training_step — Networks.py:1711-1812 (generator update, then discriminators re-run on detached
+    generator outputs :1763-1771).  Spectral-norm u/v in P are updated in place."""
+    g_names = trainable_names(P, ("F.", "G."))
+    d_names = trainable_names(P, ("DX.", "DY."))
+    Q = _leaf_params(P, g_names + d_names)
+    sn = {}
+
+    def run_d(inp, pre):
+        out = discriminator(inp, Q, pre, True, sn)
+        Q[pre + "model.4.weight_u"], Q[pre + "model.4.weight_v"] = sn[pre + "model.4.weight_u"], sn[pre + "model.4.weight_v"]
+        return out
+
+    G_loss, m, (Gx, FGx, Fy, GFy), _ = _cycleaegan_losses(Q, x, y, paired, lambda_cycle, lambda_gan, lambda_identity, run_d)
+    g_grads = _grads(G_loss, Q, g_names)
+    adam_update(P, g_grads, state.setdefault("G", {}), g_names, lr)
+    DYGx_d, DXFy_d, DXx_d, DYy_d = run_d(Gx.detach(), "DY."), run_d(Fy.detach(), "DX."), run_d(x, "DX."), run_d(y, "DY.")
+    d_x, d_x_real, d_x_fake = gan_loss_discriminator(DXx_d, DXFy_d)
+    d_y, d_y_real, d_y_fake = gan_loss_discriminator(DYy_d, DYGx_d)
+    D_loss = d_x + d_y
+    d_grads = _grads(D_loss, Q, d_names)
+    adam_update(P, d_grads, state.setdefault("D", {}), d_names, lr)
+    for k, v in sn.items():
+        P[k] = v
+    out = {"total_loss": G_loss.item() + D_loss.item(), "G_loss": G_loss.item(), "D_loss": D_loss.item(),
+           "D_loss_x_real": d_x_real.item(), "D_loss_x_fake": d_x_fake.item(),
+           "D_loss_y_real": d_y_real.item(), "D_loss_y_fake": d_y_fake.item()}
+    out.update({k: v.item() for k, v in m.items()})
+    out.update({"d_x_real_mean": DXx_d.mean().item(), "d_x_fake_mean": DXFy_d.mean().item(),
+                "d_y_real_mean": DYy_d.mean().item(), "d_y_fake_mean": DYGx_d.mean().item()})
+    outs = {"Gx": Gx.detach(), "FGx": FGx.detach(), "Fy": Fy.detach(), "GFy": GFy.detach()}
+    return out, outs, g_grads, d_grads
+
+
+def cycleaegan_validation(P, x, y, paired=False, lambda_cycle=10.0, lambda_gan=1.0, lambda_identity=5.0):
+    """CycleAEGAN.validation_step — Networks.py:1814-1869 under model.eval(): stored spectral-norm vectors."""
+    with torch.no_grad():
+        G_loss, m, (Gx, _, Fy, _), (DYGx, DXFy, DXx, DYy) = _cycleaegan_losses(
+            P, x, y, paired, lambda_cycle, lambda_gan, lambda_identity, lambda inp, pre: discriminator(inp, P, pre, False))
+        d_x, d_x_real, d_x_fake = gan_loss_discriminator(DXx, DXFy)
+        d_y, d_y_real, d_y_fake = gan_loss_discriminator(DYy, DYGx)
+        D_loss = d_x + d_y
+    out = {"total_loss": G_loss.item() + D_loss.item(), "G_loss": G_loss.item(), "D_loss": D_loss.item(),
+           "D_loss_x_real": d_x_real.item(), "D_loss_x_fake": d_x_fake.item(),
+           "D_loss_y_real": d_y_real.item(), "D_loss_y_fake": d_y_fake.item()}
+    out.update({k: v.item() for k, v in m.items()})
+    return out, {"Gx": Gx, "Fy": Fy}
+

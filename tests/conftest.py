@@ -47,6 +47,14 @@ def validation_golden():
 
 
 @pytest.fixture(scope="session")
+def cycleaegan_golden():
+    """(arrays, metric dicts) of the reference's CycleAEGAN step and eval-mode validation (make_golden.py cycleaegan)."""
+    with open(os.path.join(GOLDEN, "cycleaegan_meta.json")) as f:
+        meta = json.load(f)
+    return dict(np.load(os.path.join(GOLDEN, "cycleaegan.npz"))), meta
+
+
+@pytest.fixture(scope="session")
 def steps_meta():
     with open(os.path.join(GOLDEN, "steps_meta.json")) as f:
         return json.load(f)

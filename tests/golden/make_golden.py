@@ -298,6 +298,36 @@ def gen_validation(N, out, meta):
         print(key, m)
 
 
+def gen_cycleaegan(N, out, meta):
+    """CycleAEGAN (Networks.py:1618-1869) at 256x256, batch 1: one training step (unpaired and paired)
+    from synthetic parameters, and `validation_step` in eval mode on another batch."""
+    torch.set_num_threads(8)
+    for key, paired in (("cag256_unpaired", False), ("cag256_paired", True)):
+        model = N.CycleAEGAN(paired=paired)
+        load_synth_params(model, SEED, 0.02, prefix=key + ".")
+        model.configure_optimizers(lr=LR)
+        model.configure_loss(**LAMBDAS)
+        model.eval()
+        x, y = synth.batch(1, 256, SEED, step=7)
+        m = model.validation_step({"x": torch.from_numpy(x), "y": torch.from_numpy(y)})
+        out[key + "/val_Gx"] = m.pop("Gx")[:, :, ::16, ::16].numpy()
+        out[key + "/val_Fy"] = m.pop("Fy")[:, :, ::16, ::16].numpy()
+        meta[key + "/validation"] = m
+        model.train()
+        x, y = synth.batch(1, 256, SEED, step=0)
+        xb, yb = torch.from_numpy(x), torch.from_numpy(y)
+        with torch.no_grad():
+            fw = model(xb, yb)
+            assert len(fw) == 10
+            for nm, t in zip(("Gx", "FGx", "Fy", "GFy"), fw[:4]):
+                out[f"{key}/{nm}0"] = t[:, :, ::16, ::16].numpy()
+            out[key + "/D0"] = torch.stack([fw[4], fw[5], fw[6], fw[7]]).numpy()
+        meta[key] = [model.training_step({"x": xb, "y": yb})]
+        param_checksums(model, out, key + "@step1")
+        fp64_truth(lambda: N.CycleAEGAN(paired=paired), key, {"x": xb, "y": yb}, [], out)
+        print(key, meta[key], meta[key + "/validation"])
+
+
 def gen_checkpoint_skeleton(N):
     """Structure of the checkpoints the REFERENCE writes (utils.py:17-28: torch.save of {epoch, model_state_dict,
     optimizer_states, loss, args}) after one training step: key names, shapes and dtypes of every tensor, the optimizer
@@ -341,7 +371,7 @@ def main():
     torch.manual_seed(0)
     atoms, steps, meta = {}, {}, {"seed": SEED, "lr": LR, "lambdas": LAMBDAS,
                                   "torch": torch.__version__, "reference": "Baverne/VAE-CYCLEGAN-Implementation"}
-    which = sys.argv[1:] or ["atoms", "steps", "validation", "checkpoint"]
+    which = sys.argv[1:] or ["atoms", "steps", "validation", "cycleaegan", "checkpoint"]
     if "atoms" in which:
         gen_atoms(N, atoms)
         np.savez_compressed(os.path.join(HERE, "atoms.npz"), **atoms)
@@ -356,10 +386,17 @@ def main():
         np.savez_compressed(os.path.join(HERE, "validation.npz"), **val)
         with open(os.path.join(HERE, "validation_meta.json"), "w") as f:
             json.dump(vmeta, f, indent=1)
+    if "cycleaegan" in which:
+        arr, cmeta = {}, {"seed": SEED, "lr": LR, "lambdas": LAMBDAS, "torch": torch.__version__}
+        gen_cycleaegan(N, arr, cmeta)
+        np.savez_compressed(os.path.join(HERE, "cycleaegan.npz"), **arr)
+        with open(os.path.join(HERE, "cycleaegan_meta.json"), "w") as f:
+            json.dump(cmeta, f, indent=1)
     if "checkpoint" in which:
         with open(os.path.join(HERE, "checkpoint_skeleton.json"), "w") as f:
             json.dump(gen_checkpoint_skeleton(N), f, indent=0)
-    for fn in ("atoms.npz", "steps.npz", "steps_meta.json", "validation.npz", "validation_meta.json", "checkpoint_skeleton.json"):
+    for fn in ("atoms.npz", "steps.npz", "steps_meta.json", "validation.npz", "validation_meta.json", "cycleaegan.npz",
+               "cycleaegan_meta.json", "checkpoint_skeleton.json"):
         p = os.path.join(HERE, fn)
         if os.path.exists(p):
             print(fn, os.path.getsize(p), "bytes")

@@ -508,3 +508,31 @@ def test_checkpoint_has_the_reference_format_and_resumes_bit_identically(arch, p
         assert torch.equal(sa[k], sb[k]), f"{k} differs after the resumed step"
     with pytest.raises(FileNotFoundError):
         pkg.utils.load_checkpoint(b, str(tmp_path / "missing.pth"), device)
+
+
+# ------------------------------------------------------------------ CycleAEGAN
+@pytest.mark.parametrize("key,paired", [("cag256_unpaired", False), ("cag256_paired", True)])
+def test_cycleaegan_step_and_validation_match_reference_golden(key, paired, pkg, device, cycleaegan_golden):
+    arrays, meta = cycleaegan_golden
+    model = pkg.Networks.CycleAEGAN(paired=paired)
+    load_synth(pkg, model, key, STEP_BIAS_STD)
+    model = model.to(device)
+    model.configure_optimizers(lr=LR)
+    model.configure_loss(**LAMBDAS)
+    model.eval()
+    x, y = (torch.from_numpy(a).to(device) for a in pkg.synth.batch(1, 256, SEED, step=VAL_STEP))
+    m = model.validation_step({"x": x, "y": y})
+    assert_close(nchw(m.pop("Gx"))[:, :, ::16, ::16], arrays[key + "/val_Gx"], "val Gx", l2=1e-3)
+    assert_close(nchw(m.pop("Fy"))[:, :, ::16, ::16], arrays[key + "/val_Fy"], "val Fy", l2=1e-3)
+    _check_metrics(m, meta[key + "/validation"], f"{key} validation")
+    model.train()
+    x, y = (torch.from_numpy(a).to(device) for a in pkg.synth.batch(1, 256, SEED, step=0))
+    with torch.no_grad():
+        fw = model(x, y)
+    assert len(fw) == 10
+    for nm, t in zip(("Gx", "FGx", "Fy", "GFy"), fw[:4]):
+        assert_close(nchw(t)[:, :, ::16, ::16], arrays[f"{key}/{nm}0"], nm, l2=1e-3)
+    assert_close(torch.stack([fw[4], fw[5], fw[6], fw[7]]), arrays[key + "/D0"], "D outputs", l2=1e-3)
+    m = model.training_step({"x": x, "y": y})
+    _check_metrics(m, meta[key][0], f"{key} step 0")
+    _check_state(model, key, arrays, flip=GAN_FLIP_BUDGET)

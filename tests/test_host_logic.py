@@ -62,6 +62,15 @@ def test_state_dict_surface_matches_the_reference(pkg):
     for name in ("forward", "configure_optimizers", "save_optimizer_states", "load_optimizer_states",
                  "configure_loss", "training_step", "validation_step"):
         assert callable(getattr(pkg.Networks.CycleVAEGAN, name))
+        assert callable(getattr(pkg.Networks.CycleAEGAN, name))
+    # CycleAEGAN (reference Networks.py:1618-1636): two plain autoencoders + two discriminators, no VAE block.  The
+    # golden arrays of the reference's own step name every state_dict entry (ck.<name>)
+    a = pkg.Networks.CycleAEGAN(paired=False)
+    names = {k.split("/ck.", 1)[1] for k in np.load(os.path.join(ROOT, "tests", "golden", "cycleaegan.npz")).files
+             if k.startswith("cag256_unpaired@step1/ck.")}
+    assert set(a.state_dict()) == names
+    assert not any("variational" in k for k in a.state_dict())
+    assert sum(p.numel() for p in a.parameters()) == 2 * (43955328 + 20453507) + 2 * 2887617
 
 
 def test_cli_keeps_the_reference_flags_and_defaults():

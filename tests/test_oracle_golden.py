@@ -261,3 +261,26 @@ def test_oracle_cyclevaegan_validation_matches_reference(key, paired, pkg, oracl
     _check_metrics(m, meta[key], f"{key} validation", tol=1e-3)
     assert_close(o["Gx"][:, :, ::16, ::16], arrays[key + "/Gx"], "Gx", l2=1e-4, mx=1e-3)
     assert_close(o["Fy"][:, :, ::16, ::16], arrays[key + "/Fy"], "Fy", l2=1e-4, mx=1e-3)
+
+
+# ------------------------------------------------------------------ CycleAEGAN
+@pytest.mark.parametrize("key,paired", [("cag256_paired", True)])
+def test_oracle_cycleaegan_step_and_validation_match_reference(key, paired, pkg, oracle, cycleaegan_golden):
+    """Paired mode exercises every term (identity loss included); the unpaired fixtures are held by the GPU suite — the
+    CPU suite has to stay within a few minutes and each 256x256 CycleAEGAN step costs the oracle about a minute."""
+    arrays, meta = cycleaegan_golden
+    torch.set_num_threads(max(1, min(8, os.cpu_count() or 1)))
+    P = _params(pkg, _model_shapes(pkg, key, lambda: pkg.Networks.CycleAEGAN(paired)), STEP_BIAS_STD)
+    P = {k[len(key) + 1:]: v for k, v in P.items()}
+    x, y = (torch.from_numpy(a) for a in pkg.synth.batch(1, 256, SEED, step=VAL_STEP))
+    m, o = oracle.cycleaegan_validation(P, x, y, paired, LAMBDAS["lambda_cycle"], LAMBDAS["lambda_gan"], LAMBDAS["lambda_identity"])
+    _check_metrics(m, meta[key + "/validation"], f"{key} validation", tol=1e-3)
+    assert_close(o["Gx"][:, :, ::16, ::16], arrays[key + "/val_Gx"], "val Gx", l2=1e-4, mx=1e-3)
+    assert_close(o["Fy"][:, :, ::16, ::16], arrays[key + "/val_Fy"], "val Fy", l2=1e-4, mx=1e-3)
+    x, y = (torch.from_numpy(a) for a in pkg.synth.batch(1, 256, SEED, step=0))
+    m, outs, g_grads, d_grads = oracle.cycleaegan_step(P, {}, x, y, LR, paired, LAMBDAS["lambda_cycle"], LAMBDAS["lambda_gan"],
+                                                       LAMBDAS["lambda_identity"])
+    for nm in ("Gx", "FGx", "Fy", "GFy"):
+        assert_close(outs[nm][:, :, ::16, ::16], arrays[f"{key}/{nm}0"], nm, l2=1e-4, mx=1e-3)
+    _check_metrics(m, meta[key][0], f"{key} step 0", tol=1e-3)
+    check_step_state(P, {**g_grads, **d_grads}, key, arrays, LR, snap="@step1", tol=1e-3)

@@ -610,3 +610,93 @@ class CycleVAEGAN(nn.Module):
             m["Fy"] = Fy.detach()
             assert paired == self.paired
             return m
+
+
+class CycleAEGAN(CycleVAEGAN):
+    """Two plain autoencoders (G: X->Y, F: Y->X) + two discriminators; cycle + LSGAN (+identity if paired), alternating
+    G then D update  (reference Networks.py:1618-1869).  CycleVAEGAN's wiring minus the VAE block: no KL term and no
+    eps draws, `forward` returns 10 tensors, and the generator objective carries the WHOLE LSGAN generator loss
+    (`loss_gan_g = loss_gan_g_x + loss_gan_g_y`, real + fake terms, :1745-1748) where CycleVAEGAN takes only the fake
+    terms — the real terms have no gradient into F and G, but they are part of `G_loss` and of the `loss_gan_g` metric.
+    The step itself (one discriminator pass serving both phases, exchange hooks, side stream) is CycleVAEGAN's."""
+
+    def __init__(self, paired=True):
+        nn.Module.__init__(self)
+        self.F = Autoencoder()
+        self.G = Autoencoder()
+        self.DX = Discriminator()
+        self.DY = Discriminator()
+        self.paired = paired
+        self.apply(self._init_weights)
+        self.debug_mode = False
+        self.debug_info = {}
+        self.optimizer_G = None
+        self.optimizer_D = None
+        self.loss_cycle = None
+        self.loss_gan_gen = None
+        self.loss_gan_disc = None
+        self.loss_identity = None
+        self.grad_reducer = None
+
+    def forward(self, x, y):
+        x, y = ops.to_nhwc(x), ops.to_nhwc(y)
+        Gx = self.G(x)
+        Gy = self.G(y)
+        FGx = self.F(Gx)
+        Fy = self.F(y)
+        Fx = self.F(x)
+        GFy = self.G(Fy)
+        return Gx, FGx, Fy, GFy, self.DY(Gx), self.DX(Fy), self.DX(x), self.DY(y), Gy, Fx
+
+    def configure_loss(self, **kwargs):
+        self.loss_cycle = CycleConsistencyLoss()
+        self.loss_gan_gen = GANLossGenerator()
+        self.loss_gan_disc = GANLossDiscriminator()
+        if self.paired:
+            self.loss_identity = IdentityLoss()
+        self.lambda_gan = kwargs.get("lambda_gan", 1.0)
+        self.lambda_identity = kwargs.get("lambda_identity", 5.0)
+        self.lambda_cycle = kwargs.get("lambda_cycle", 10.0)
+
+    def _check_configured(self, need_opt=True):
+        if self.loss_cycle is None or self.loss_gan_gen is None or self.loss_gan_disc is None:
+            raise ValueError("Loss functions have not been configured yet.")
+        if self.paired and self.loss_identity is None:
+            raise ValueError("Identity loss not configured for paired mode.")
+        if need_opt and (self.optimizer_G is None or self.optimizer_D is None):
+            raise ValueError("Optimizers have not been configured yet.")
+
+    def _generator_losses(self, x, y):
+        """reference :1733-1753; G(y), F(x) feed only the identity loss and are skipped when unpaired."""
+        Gx = self.G(x)
+        FGx = self.F(Gx)
+        Fy = self.F(y)
+        GFy = self.G(Fy)
+        DYGx = self.DY(Gx)
+        DXFy = self.DX(Fy)
+        DXx = self.DX(x)
+        DYy = self.DY(y)
+        t = {}
+        t["loss_cycle"] = self.loss_cycle(x, y, FGx, GFy)
+        t["loss_gan_g_x_fake"], t["d_x_fake_mean"] = ops.mse_const(DXFy, 1.0)
+        t["loss_gan_g_y_fake"], t["d_y_fake_mean"] = ops.mse_const(DYGx, 1.0)
+        t["loss_gan_g_x_real"], t["d_x_real_mean"] = ops.mse_const(DXx, 0.0)
+        t["loss_gan_g_y_real"], t["d_y_real_mean"] = ops.mse_const(DYy, 0.0)
+        t["loss_gan_g"] = ops.weighted_sum([t["loss_gan_g_x_real"], t["loss_gan_g_x_fake"], t["loss_gan_g_y_real"],
+                                            t["loss_gan_g_y_fake"]], [1.0] * 4)
+        terms, weights = [t["loss_cycle"], t["loss_gan_g"]], [self.lambda_cycle, self.lambda_gan]
+        if self.paired:
+            t["loss_identity"] = self.loss_identity(x, y, self.F(x), self.G(y))
+            terms.append(t["loss_identity"])
+            weights.append(self.lambda_identity)
+        t["G_loss"] = ops.weighted_sum(terms, weights)
+        t["D_loss_x_real"], _ = ops.mse_const(DXx, 1.0)
+        t["D_loss_x_fake"], _ = ops.mse_const(DXFy, 0.0)
+        t["D_loss_y_real"], _ = ops.mse_const(DYy, 1.0)
+        t["D_loss_y_fake"], _ = ops.mse_const(DYGx, 0.0)
+        t["D_loss"] = ops.weighted_sum([t["D_loss_x_real"], t["D_loss_x_fake"], t["D_loss_y_real"], t["D_loss_y_fake"]],
+                                       [1.0] * 4)
+        return t, Gx, Fy
+
+    _METRIC_KEYS = tuple(k for k in CycleVAEGAN._METRIC_KEYS if k != "loss_kl")
+
