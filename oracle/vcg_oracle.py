@@ -456,3 +456,49 @@ def cycleaegan_validation(P, x, y, paired=False, lambda_cycle=10.0, lambda_gan=1
     out.update({k: v.item() for k, v in m.items()})
     return out, {"Gx": Gx, "Fy": Fy}
 
+
+# ----------------------------------------------------------------------------- CycleAE / CycleVAE
+def _cycle_nogan_losses(Q, x, y, eps4, paired, lambda_cycle, lambda_kl):
+    """CycleAE.forward + losses (Networks.py:1363-1368, :1413-1427) when eps4 is None, else CycleVAE's (:1489-1494,
+    :1541-1559): total = lambda_cycle * cycle (+ lambda_kl * sum of four KLs) (+ L1(G(x), y) + L1(F(y), x) when paired)."""
+    m = {}
+    if eps4 is None:
+        Gx = autoencoder_forward(x, Q, "G.")
+        FGx = autoencoder_forward(Gx, Q, "F.")
+        Fy = autoencoder_forward(y, Q, "F.")
+        GFy = autoencoder_forward(Fy, Q, "G.")
+        total = lambda_cycle * cycle_loss(x, y, FGx, GFy)
+    else:
+        Gx, mu_x, lv_x = vae_forward(x, Q, "G.", eps4[0])
+        FGx, mu_FGx, lv_FGx = vae_forward(Gx, Q, "F.", eps4[1])
+        Fy, mu_y, lv_y = vae_forward(y, Q, "F.", eps4[2])
+        GFy, mu_GFy, lv_GFy = vae_forward(Fy, Q, "G.", eps4[3])
+        m["loss_kl"] = kl_loss(mu_x, lv_x) + kl_loss(mu_FGx, lv_FGx) + kl_loss(mu_y, lv_y) + kl_loss(mu_GFy, lv_GFy)
+        total = lambda_cycle * cycle_loss(x, y, FGx, GFy) + lambda_kl * m["loss_kl"]
+    m["loss_cycle"] = cycle_loss(x, y, FGx, GFy)
+    if paired:
+        m["loss_trans"] = l1(Gx, y) + l1(Fy, x)
+        total = total + m["loss_trans"]
+    return total, m, Gx, Fy
+
+
+def cycle_nogan_step(P, state, x, y, eps4, lr, paired=False, lambda_cycle=10.0, lambda_kl=1e-5):
+    """CycleAE.training_step (Networks.py:1397-1439; eps4 None) / CycleVAE.training_step (:1525-1572)."""
+    names = trainable_names(P)
+    Q = _leaf_params(P, names)
+    total, m, Gx, Fy = _cycle_nogan_losses(Q, x, y, eps4, paired, lambda_cycle, lambda_kl)
+    grads = _grads(total, Q, names)
+    adam_update(P, grads, state, names, lr)
+    out = {k: v.item() for k, v in m.items()}
+    out["total_loss"] = out["G_loss"] = total.item()
+    return out, {"Gx": Gx.detach(), "Fy": Fy.detach()}, grads
+
+
+def cycle_nogan_validation(P, x, y, eps4, paired=False, lambda_cycle=10.0, lambda_kl=1e-5):
+    """CycleAE.validation_step (Networks.py:1441-1480) / CycleVAE.validation_step (:1574-1616)."""
+    with torch.no_grad():
+        total, m, Gx, Fy = _cycle_nogan_losses(P, x, y, eps4, paired, lambda_cycle, lambda_kl)
+    out = {k: v.item() for k, v in m.items()}
+    out["total_loss"] = out["G_loss"] = total.item()
+    return out, {"Gx": Gx, "Fy": Fy}
+

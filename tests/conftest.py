@@ -55,6 +55,14 @@ def cycleaegan_golden():
 
 
 @pytest.fixture(scope="session")
+def cycle_nogan_golden():
+    """(arrays, metric dicts) of the reference's CycleAE / CycleVAE step and validation (make_golden.py cycle_nogan)."""
+    with open(os.path.join(GOLDEN, "cycle_nogan_meta.json")) as f:
+        meta = json.load(f)
+    return dict(np.load(os.path.join(GOLDEN, "cycle_nogan.npz"))), meta
+
+
+@pytest.fixture(scope="session")
 def steps_meta():
     with open(os.path.join(GOLDEN, "steps_meta.json")) as f:
         return json.load(f)

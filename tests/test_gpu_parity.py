@@ -536,3 +536,33 @@ def test_cycleaegan_step_and_validation_match_reference_golden(key, paired, pkg,
     m = model.training_step({"x": x, "y": y})
     _check_metrics(m, meta[key][0], f"{key} step 0")
     _check_state(model, key, arrays, flip=GAN_FLIP_BUDGET)
+
+
+# ------------------------------------------------------------------ CycleAE / CycleVAE
+@pytest.mark.parametrize("name,variational,paired", [("cae64", False, False), ("cae64", False, True), ("cve64", True, False),
+                                                      ("cve64", True, True)])
+def test_cycle_nogan_step_and_validation_match_reference_golden(name, variational, paired, pkg, device, cycle_nogan_golden):
+    arrays, meta = cycle_nogan_golden
+    key = f"{name}_{'paired' if paired else 'unpaired'}"
+    model = pkg.Networks.CycleVAE(latent_dim=64, paired=paired) if variational else pkg.Networks.CycleAE(paired=paired)
+    load_synth(pkg, model, key, STEP_BIAS_STD)
+    model = model.to(device)
+    model.configure_optimizers(lr=LR)
+    model.configure_loss(**LAMBDAS)
+
+    def inject(step):
+        if variational:
+            pkg.ops.inject_eps([torch.from_numpy(e) for e in pkg.synth.eps_list(4, (2, 64, 4, 4), SEED, step=step)])
+    model.eval()
+    x, y = (torch.from_numpy(a).to(device) for a in pkg.synth.batch(2, 64, SEED, step=VAL_STEP))
+    inject(VAL_STEP)
+    m = model.validation_step({"x": x, "y": y})
+    assert_close(nchw(m.pop("Gx"))[:, :, ::4, ::4], arrays[key + "/val_Gx"], "val Gx", l2=1e-3)
+    assert_close(nchw(m.pop("Fy"))[:, :, ::4, ::4], arrays[key + "/val_Fy"], "val Fy", l2=1e-3)
+    _check_metrics(m, meta[key + "/validation"], f"{key} validation")
+    model.train()
+    x, y = (torch.from_numpy(a).to(device) for a in pkg.synth.batch(2, 64, SEED, step=0))
+    inject(0)
+    m = model.training_step({"x": x, "y": y})
+    _check_metrics(m, meta[key][0], f"{key} step 0")
+    _check_state(model, key, arrays)

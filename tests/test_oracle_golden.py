@@ -284,3 +284,33 @@ def test_oracle_cycleaegan_step_and_validation_match_reference(key, paired, pkg,
         assert_close(outs[nm][:, :, ::16, ::16], arrays[f"{key}/{nm}0"], nm, l2=1e-4, mx=1e-3)
     _check_metrics(m, meta[key][0], f"{key} step 0", tol=1e-3)
     check_step_state(P, {**g_grads, **d_grads}, key, arrays, LR, snap="@step1", tol=1e-3)
+
+
+# ------------------------------------------------------------------ CycleAE / CycleVAE
+# the CPU suite has to stay within a few minutes and each of these full-width networks costs the oracle about a minute:
+# it holds the case with every term (CycleVAE, paired: cycle + KL + translation); the GPU suite holds all four
+CYCLE_NOGAN = [("cve64", True, True)]
+
+
+def _cycle_nogan_ctor(pkg, variational, paired):
+    return (lambda: pkg.Networks.CycleVAE(64, paired)) if variational else (lambda: pkg.Networks.CycleAE(paired))
+
+
+@pytest.mark.parametrize("name,variational,paired", CYCLE_NOGAN)
+def test_oracle_cycle_nogan_step_and_validation_match_reference(name, variational, paired, pkg, oracle, cycle_nogan_golden):
+    arrays, meta = cycle_nogan_golden
+    key = f"{name}_{'paired' if paired else 'unpaired'}"
+    P = _params(pkg, _model_shapes(pkg, key, _cycle_nogan_ctor(pkg, variational, paired)), STEP_BIAS_STD)
+    P = {k[len(key) + 1:]: v for k, v in P.items()}
+
+    def eps(step):
+        return [torch.from_numpy(e) for e in pkg.synth.eps_list(4, (2, 64, 4, 4), SEED, step=step)] if variational else None
+    x, y = (torch.from_numpy(a) for a in pkg.synth.batch(2, 64, SEED, step=VAL_STEP))
+    m, o = oracle.cycle_nogan_validation(P, x, y, eps(VAL_STEP), paired, LAMBDAS["lambda_cycle"], LAMBDAS["lambda_kl"])
+    _check_metrics(m, meta[key + "/validation"], f"{key} validation", tol=1e-4)
+    assert_close(o["Gx"][:, :, ::4, ::4], arrays[key + "/val_Gx"], "val Gx", l2=1e-4, mx=1e-3)
+    assert_close(o["Fy"][:, :, ::4, ::4], arrays[key + "/val_Fy"], "val Fy", l2=1e-4, mx=1e-3)
+    x, y = (torch.from_numpy(a) for a in pkg.synth.batch(2, 64, SEED, step=0))
+    m, _, grads = oracle.cycle_nogan_step(P, {}, x, y, eps(0), LR, paired, LAMBDAS["lambda_cycle"], LAMBDAS["lambda_kl"])
+    _check_metrics(m, meta[key][0], f"{key} step 0", tol=1e-4)
+    check_step_state(P, grads, key, arrays, LR, snap="@step1", tol=1e-3)

@@ -700,3 +700,118 @@ class CycleAEGAN(CycleVAEGAN):
 
     _METRIC_KEYS = tuple(k for k in CycleVAEGAN._METRIC_KEYS if k != "loss_kl")
 
+
+class _CycleNoGAN(_OptimizerStatesMixin, nn.Module):
+    """Two generators G: X->Y, F: Y->X trained on the cycle loss alone (+ KL for VAEs, + translation loss when paired),
+    one Adam over both — the shared body of CycleAE and CycleVAE (reference Networks.py:1350-1616)."""
+
+    def _init_common(self, paired):
+        self.paired = paired
+        self.optimizer = None        # (CycleVAE.__init__ in the reference leaves this attribute unset until configured)
+        self.grad_reducer = None
+        self.loss_cycle = None
+        self.loss_trans = None
+        self.loss_kl = None
+        self.lambda_cycle = 0
+        self.lambda_kl = 0
+
+    def configure_optimizers(self, lr=1e-4, betas=(0.5, 0.999)):
+        self.optimizer = FusedAdam(self.parameters(), lr=lr, betas=betas)
+        return self.optimizer
+
+    def _check_configured(self, need_opt=True):
+        if self.loss_cycle is None or (self._variational and self.loss_kl is None):
+            raise ValueError("Loss functions have not been configured yet.")
+        if self.paired and self.loss_trans is None:
+            raise ValueError("Translation loss not configured for paired mode.")
+        if need_opt and self.optimizer is None:
+            raise ValueError("Optimizer has not been configured yet.")
+
+    def _losses(self, batch):
+        x, y = ops.to_nhwc(batch["x"]), ops.to_nhwc(batch["y"])
+        fw = self(x, y)
+        Gx, FGx, Fy, GFy = fw[:4]
+        t = {"loss_cycle": self.loss_cycle(x, y, FGx, GFy)}
+        terms, weights = [t["loss_cycle"]], [self.lambda_cycle]
+        if self._variational:
+            t["loss_kl"] = ops.weighted_sum([self.loss_kl(fw[4 + 2 * i], fw[5 + 2 * i]) for i in range(4)], [1.0] * 4)
+            terms.append(t["loss_kl"])
+            weights.append(self.lambda_kl)
+        if self.paired:
+            t["loss_trans"] = ops.weighted_sum([self.loss_trans(Gx, y), self.loss_trans(Fy, x)], [1.0, 1.0])
+            terms.append(t["loss_trans"])
+            weights.append(1.0)
+        t["G_loss"] = ops.weighted_sum(terms, weights)
+        return t, Gx, Fy
+
+    def training_step(self, batch):
+        self._check_configured()
+        t, _, _ = self._losses(batch)
+        self.optimizer.zero_grad()
+        ops.backward_overlapped(t["G_loss"])
+        _reduced_step(self.optimizer, self.grad_reducer)
+        m = _metrics_to_host(t, self.grad_reducer)
+        m["total_loss"] = m["G_loss"]
+        return m
+
+    def validation_step(self, batch):
+        self._check_configured(need_opt=False)
+        with torch.no_grad():
+            t, Gx, Fy = self._losses(batch)
+            m = _metrics_to_host(t)
+            m["total_loss"] = m["G_loss"]
+            m["Gx"], m["Fy"] = Gx.detach(), Fy.detach()
+            return m
+
+
+class CycleAE(_CycleNoGAN):
+    """reference Networks.py:1350-1480: cycle loss over two plain autoencoders (+ L1(G(x), y) + L1(F(y), x) when paired)."""
+    _variational = False
+
+    def __init__(self, paired=True):
+        super().__init__()
+        self.F = Autoencoder()
+        self.G = Autoencoder()
+        self._init_common(paired)
+
+    def forward(self, x, y):
+        x, y = ops.to_nhwc(x), ops.to_nhwc(y)
+        Gx = self.G(x)
+        FGx = self.F(Gx)
+        Fy = self.F(y)
+        return Gx, FGx, Fy, self.G(Fy)
+
+    def configure_loss(self, **kwargs):
+        self.loss_cycle = CycleConsistencyLoss()
+        if self.paired:
+            self.loss_trans = TranslationLoss()
+        self.lambda_cycle = kwargs.get("lambda_cycle", 10.0)
+
+
+class CycleVAE(_CycleNoGAN):
+    """reference Networks.py:1482-1616: the same over two VAEs, plus the four KL terms; eps is drawn in the order
+    G(x), F(G(x)), F(y), G(F(y)) (:1489-1494)."""
+    _variational = True
+
+    def __init__(self, latent_dim=64, paired=True):
+        super().__init__()
+        self.F = VariationalAutoencoder(latent_dim)
+        self.G = VariationalAutoencoder(latent_dim)
+        self._init_common(paired)
+
+    def forward(self, x, y):
+        x, y = ops.to_nhwc(x), ops.to_nhwc(y)
+        Gx, mu_x, logvar_x = self.G(x)
+        FGx, mu_FGx, logvar_FGx = self.F(Gx)
+        Fy, mu_y, logvar_y = self.F(y)
+        GFy, mu_GFy, logvar_GFy = self.G(Fy)
+        return Gx, FGx, Fy, GFy, mu_x, logvar_x, mu_FGx, logvar_FGx, mu_y, logvar_y, mu_GFy, logvar_GFy
+
+    def configure_loss(self, **kwargs):
+        self.loss_cycle = CycleConsistencyLoss()
+        if self.paired:
+            self.loss_trans = TranslationLoss()
+        self.loss_kl = KLDivergenceLoss()
+        self.lambda_kl = kwargs.get("lambda_kl", 1e-5)
+        self.lambda_cycle = kwargs.get("lambda_cycle", 10.0)
+

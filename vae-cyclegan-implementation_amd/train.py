@@ -34,7 +34,7 @@ else:
     from . import Networks, ops, parallel, utils
 
 ALIASES = {"ae": "autoencoder", "vae_cyclegan": "cyclevaegan"}
-BUILT = ("autoencoder", "vae", "cycleaegan", "cyclevaegan")
+BUILT = ("autoencoder", "vae", "cycleae", "cyclevae", "cycleaegan", "cyclevaegan")
 REFERENCE_ARCHS = ["autoencoder", "doubleae", "doublevae", "vae", "aegan", "vaegan", "cycleae", "cyclevae",
                    "cycleaegan", "cyclevaegan"]
 
@@ -48,6 +48,12 @@ def create_model(architecture, paired=True, latent_dim=64):
     elif architecture == "vae":
         model = Networks.VariationalAutoencoder(latent_dim=latent_dim)
         print("Created Variational Autoencoder")
+    elif architecture == "cycleae":
+        model = Networks.CycleAE(paired=paired)
+        print(f"Created Cycle Autoencoder ({'paired' if paired else 'unpaired'} mode)")
+    elif architecture == "cyclevae":
+        model = Networks.CycleVAE(latent_dim=latent_dim, paired=paired)
+        print(f"Created Cycle VAE ({'paired' if paired else 'unpaired'} mode)")
     elif architecture == "cycleaegan":
         model = Networks.CycleAEGAN(paired=paired)
         print(f"Created Cycle AE-GAN ({'paired' if paired else 'unpaired'} mode)")
