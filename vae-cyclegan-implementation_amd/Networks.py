@@ -750,17 +750,29 @@ class _CycleNoGAN(_OptimizerStatesMixin, nn.Module):
         self.optimizer.zero_grad()
         ops.backward_overlapped(t["G_loss"])
         _reduced_step(self.optimizer, self.grad_reducer)
-        m = _metrics_to_host(t, self.grad_reducer)
-        m["total_loss"] = m["G_loss"]
+        host = _metrics_to_host(t, self.grad_reducer)
+        m = self._ordered(host)
+        if self.paired:
+            m["loss_trans"] = host["loss_trans"]
+        return m
+
+    def _ordered(self, host):
+        """the reference's key order (:1421-1433, :1547-1561): total_loss, loss_cycle, [loss_kl], G_loss, [loss_trans]"""
+        m = {"total_loss": host["G_loss"], "loss_cycle": host["loss_cycle"]}
+        if self._variational:
+            m["loss_kl"] = host["loss_kl"]
+        m["G_loss"] = host["G_loss"]
         return m
 
     def validation_step(self, batch):
         self._check_configured(need_opt=False)
         with torch.no_grad():
             t, Gx, Fy = self._losses(batch)
-            m = _metrics_to_host(t)
-            m["total_loss"] = m["G_loss"]
+            host = _metrics_to_host(t)
+            m = self._ordered(host)
             m["Gx"], m["Fy"] = Gx.detach(), Fy.detach()
+            if self.paired:
+                m["loss_trans"] = host["loss_trans"]
             return m
 
 
