@@ -502,3 +502,58 @@ def cycle_nogan_validation(P, x, y, eps4, paired=False, lambda_cycle=10.0, lambd
     out["total_loss"] = out["G_loss"] = total.item()
     return out, {"Gx": Gx, "Fy": Fy}
 
+
+# ----------------------------------------------------------------------------- DoubleAutoencoder / DoubleVAE
+def _double_forward(Q, x, y, eps):
+    """DoubleAutoencoder.forward (Networks.py:446-462) when eps is None, else DoubleVariationalAutoencoder.forward
+    (:663-690; eps[0] for block A on enc(x), eps[1] for block B on enc(y))."""
+    ex, ey = encoder(x, Q, "encoder."), encoder(y, Q, "encoder.")
+    if eps is None:
+        return decoder(ex, Q, "decoder_A."), decoder(ey, Q, "decoder_B."), None
+    zx, mu_x, lv_x = variational_encoder_block(ex, Q, "vae_encoder_block_A.", eps[0])
+    zy, mu_y, lv_y = variational_encoder_block(ey, Q, "vae_encoder_block_B.", eps[1])
+    Gx = decoder(s_conv(zx, Q, "vae_decoder_block_A.conv."), Q, "decoder_A.")
+    Gy = decoder(s_conv(zy, Q, "vae_decoder_block_B.conv."), Q, "decoder_B.")
+    return Gx, Gy, (mu_x, lv_x, mu_y, lv_y)
+
+
+def _double_losses(Q, x, y, eps, lambda_kl):
+    Gx, Gy, lat = _double_forward(Q, x, y, eps)
+    m = {"loss_recon_A": l1(Gx, x), "loss_recon_B": l1(Gy, y)}
+    total = m["loss_recon_A"] + m["loss_recon_B"]
+    if lat is not None:
+        m["loss_kl_A"], m["loss_kl_B"] = kl_loss(lat[0], lat[1]), kl_loss(lat[2], lat[3])
+        m["loss_kl"] = m["loss_kl_A"] + m["loss_kl_B"]
+        total = total + lambda_kl * m["loss_kl"]
+    return total, m
+
+
+def double_step(P, state, x, y, eps, lr, lambda_kl=1e-5):
+    """DoubleAutoencoder.training_step (Networks.py:502-541; eps None) / DoubleVariationalAutoencoder.training_step (:764-808)."""
+    names = trainable_names(P)
+    Q = _leaf_params(P, names)
+    total, m = _double_losses(Q, x, y, eps, lambda_kl)
+    grads = _grads(total, Q, names)
+    adam_update(P, grads, state, names, lr)
+    out = {k: v.item() for k, v in m.items()}
+    out["G_loss"] = out["total_loss"] = total.item()
+    return out, grads
+
+
+def double_validation(P, x, y, eps, lambda_kl=1e-5):
+    """validation_step (:543-578 / :810-852): the losses of the two reconstructions, and as images the TRANSLATIONS
+    A->B = decoder_B(enc(x)) and B->A = decoder_A(enc(y)); the VAE draws eps[2], eps[3] for them."""
+    with torch.no_grad():
+        total, m = _double_losses(P, x, y, eps, lambda_kl)
+        ex, ey = encoder(x, P, "encoder."), encoder(y, P, "encoder.")
+        if eps is None:
+            Gx, Fy = decoder(ex, P, "decoder_B."), decoder(ey, P, "decoder_A.")
+        else:
+            zx, _, _ = variational_encoder_block(ex, P, "vae_encoder_block_B.", eps[2])
+            Gx = decoder(s_conv(zx, P, "vae_decoder_block_B.conv."), P, "decoder_B.")
+            zy, _, _ = variational_encoder_block(ey, P, "vae_encoder_block_A.", eps[3])
+            Fy = decoder(s_conv(zy, P, "vae_decoder_block_A.conv."), P, "decoder_A.")
+    out = {k: v.item() for k, v in m.items()}
+    out["G_loss"] = out["total_loss"] = total.item()
+    return out, {"Gx": Gx, "Fy": Fy}
+

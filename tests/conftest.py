@@ -63,6 +63,14 @@ def cycle_nogan_golden():
 
 
 @pytest.fixture(scope="session")
+def double_golden():
+    """(arrays, metric dicts) of the reference's DoubleAutoencoder / DoubleVAE step and validation (make_golden.py double)."""
+    with open(os.path.join(GOLDEN, "double_meta.json")) as f:
+        meta = json.load(f)
+    return dict(np.load(os.path.join(GOLDEN, "double.npz"))), meta
+
+
+@pytest.fixture(scope="session")
 def steps_meta():
     with open(os.path.join(GOLDEN, "steps_meta.json")) as f:
         return json.load(f)

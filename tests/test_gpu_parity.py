@@ -568,3 +568,40 @@ def test_cycle_nogan_step_and_validation_match_reference_golden(name, variationa
     # two chained generators lie between the cycle loss and G's parameters, as in CycleVAEGAN: same ReLU-flip allowance
     # (conftest.GAN_FLIP_BUDGET; seen: one near-cancelling U-block bias gradient at 7e-2 where the reference's own fp32 is 1.6e-2)
     _check_state(model, key, arrays, flip=GAN_FLIP_BUDGET)
+
+
+# ------------------------------------------------------------------ DoubleAutoencoder / DoubleVAE
+@pytest.mark.parametrize("key,variational", [("dae64", False), ("dve64", True)])
+def test_double_step_and_validation_match_reference_golden(key, variational, pkg, device, double_golden):
+    arrays, meta = double_golden
+    model = pkg.Networks.DoubleVariationalAutoencoder(latent_dim=64) if variational else pkg.Networks.DoubleAutoencoder()
+    load_synth(pkg, model, key, STEP_BIAS_STD)
+    model = model.to(device)
+    model.configure_optimizers(lr=LR)
+    model.configure_loss(**LAMBDAS)
+
+    def inject(n, step):
+        if variational:
+            pkg.ops.inject_eps([torch.from_numpy(e) for e in pkg.synth.eps_list(n, (2, 64, 4, 4), SEED, step=step)])
+    model.eval()
+    x, y = (torch.from_numpy(a).to(device) for a in pkg.synth.batch(2, 64, SEED, step=VAL_STEP))
+    inject(4, VAL_STEP)
+    m = model.validation_step({"x": x, "y": y})
+    assert_close(nchw(m.pop("Gx"))[:, :, ::4, ::4], arrays[key + "/val_Gx"], "val Gx (A->B)", l2=1e-3)
+    assert_close(nchw(m.pop("Fy"))[:, :, ::4, ::4], arrays[key + "/val_Fy"], "val Fy (B->A)", l2=1e-3)
+    _check_metrics(m, meta[key + "/validation"], f"{key} validation")
+    model.train()
+    x, y = (torch.from_numpy(a).to(device) for a in pkg.synth.batch(2, 64, SEED, step=0))
+    inject(2, 0)
+    m = model.training_step({"x": x, "y": y})
+    _check_metrics(m, meta[key][0], f"{key} step 0")
+    _check_state(model, key, arrays)
+    # the pretraining hand-over (reference :580-606, :701-736): G = encoder + B side, F = encoder + A side
+    cyc = model.create_cycle_vae() if variational else model.create_cycle_ae()
+    sd, cs = model.state_dict(), cyc.state_dict()
+    assert torch.equal(cs["G.decoder.model.5.conv.weight"], sd["decoder_B.model.5.conv.weight"])
+    assert torch.equal(cs["F.decoder.model.5.conv.weight"], sd["decoder_A.model.5.conv.weight"])
+    assert torch.equal(cs["G.encoder.model.0.conv.weight"], sd["encoder.model.0.conv.weight"])
+    if variational:
+        assert torch.equal(cs["G.variational_encoder_block.muConv.conv.weight"], sd["vae_encoder_block_B.muConv.conv.weight"])
+        assert torch.equal(cs["F.variational_decoder_block.conv.conv.weight"], sd["vae_decoder_block_A.conv.conv.weight"])

@@ -89,8 +89,12 @@ def test_cli_keeps_the_reference_flags_and_defaults():
     assert isinstance(train.create_model("ae"), importlib.import_module("vae-cyclegan-implementation_amd").Networks.Autoencoder)
     with pytest.raises(ValueError):
         train.create_model("nonsense")
-    with pytest.raises(NotImplementedError):
-        train.create_model("cycleae")
+    with pytest.raises(NotImplementedError):          # a reference architecture that is not on the accelerated path yet
+        train.create_model("aegan")
+    N = importlib.import_module("vae-cyclegan-implementation_amd").Networks
+    assert type(train.create_model("doubleae")) is N.DoubleAutoencoder and type(train.create_model("doublevae")) is N.DoubleVariationalAutoencoder
+    for arch, cls in (("cycleae", N.CycleAE), ("cyclevae", N.CycleVAE), ("cycleaegan", N.CycleAEGAN), ("cyclevaegan", N.CycleVAEGAN)):
+        assert type(train.create_model(arch, paired=False)) is cls
 
 
 def test_train_epoch_averages_like_the_reference():
@@ -147,6 +151,44 @@ def test_checkpoint_skeleton_fixture_matches_our_state_dict_surface(pkg):
         for name, opt in skel[arch]["optimizer_states"].items():
             assert name in ("optimizer", "optimizer_G", "optimizer_D")
             assert set(opt) == {"state", "param_groups"} and len(opt["param_groups"]) == 1
+
+
+def test_pretrained_double_checkpoints_map_onto_cycle_models(pkg, tmp_path):
+    """reference utils.py:57-239: a DoubleAE / DoubleVAE checkpoint initialises the generators of a Cycle model —
+    G (A->B) from the encoder and the B side, F (B->A) from the encoder and the A side.  Pure state_dict work (no GPU)."""
+    N, utils = pkg.Networks, pkg.utils
+    torch.manual_seed(3)
+    d = N.DoubleVariationalAutoencoder(latent_dim=64)
+    with torch.no_grad():
+        for i, p in enumerate(d.parameters()):          # distinguishable values everywhere (biases are zero at init)
+            p.add_(0.001 * (i + 1))
+    fn = str(tmp_path / "dvae.pth")
+    torch.save({"epoch": 0, "model_state_dict": d.state_dict(), "loss": 0.0, "args": {}}, fn)
+    for cyc in (N.CycleVAE(latent_dim=64, paired=False), N.CycleVAEGAN(latent_dim=64, paired=False)):
+        utils.load_pretrained_doublevae_to_cyclevae(cyc, fn, "cpu")
+        sd, cs = d.state_dict(), cyc.state_dict()
+        for k, v in sd.items():
+            head, rest = k.split(".", 1)
+            targets = {"encoder": ("G.encoder.", "F.encoder."), "decoder_A": ("F.decoder.",), "decoder_B": ("G.decoder.",),
+                       "vae_encoder_block_A": ("F.variational_encoder_block.",), "vae_encoder_block_B": ("G.variational_encoder_block.",),
+                       "vae_decoder_block_A": ("F.variational_decoder_block.",), "vae_decoder_block_B": ("G.variational_decoder_block.",)}[head]
+            for t in targets:
+                assert torch.equal(cs[t + rest], v), (k, t)
+    a = N.DoubleAutoencoder()
+    with torch.no_grad():
+        for i, p in enumerate(a.parameters()):
+            p.add_(0.001 * (i + 1))
+    fn = str(tmp_path / "dae.pth")
+    torch.save({"epoch": 0, "model_state_dict": a.state_dict(), "loss": 0.0, "args": {}}, fn)
+    for cyc in (N.CycleAE(paired=False), N.CycleAEGAN(paired=False)):
+        utils.load_pretrained_doubleae_to_cycleae(cyc, fn, "cpu")
+        sd, cs = a.state_dict(), cyc.state_dict()
+        assert torch.equal(cs["G.decoder.model.5.conv.bias"], sd["decoder_B.model.5.conv.bias"])
+        assert torch.equal(cs["F.decoder.model.5.conv.bias"], sd["decoder_A.model.5.conv.bias"])
+        assert torch.equal(cs["G.encoder.model.2.conv.weight"], sd["encoder.model.2.conv.weight"])
+        assert torch.equal(cs["F.encoder.model.2.conv.weight"], sd["encoder.model.2.conv.weight"])
+    with pytest.raises(FileNotFoundError):
+        utils.load_pretrained_doubleae_to_cycleae(N.CycleAE(), str(tmp_path / "none.pth"), "cpu")
 
 
 # ------------------------------------------------------------------ data parallel over gloo, world_size 2

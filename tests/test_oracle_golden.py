@@ -314,3 +314,24 @@ def test_oracle_cycle_nogan_step_and_validation_match_reference(name, variationa
     m, _, grads = oracle.cycle_nogan_step(P, {}, x, y, eps(0), LR, paired, LAMBDAS["lambda_cycle"], LAMBDAS["lambda_kl"])
     _check_metrics(m, meta[key][0], f"{key} step 0", tol=1e-4)
     check_step_state(P, grads, key, arrays, LR, snap="@step1", tol=1e-3)
+
+
+# ------------------------------------------------------------------ DoubleAutoencoder / DoubleVAE
+def test_oracle_double_vae_step_and_validation_match_reference(pkg, oracle, double_golden):
+    """The variational one holds every term (two reconstructions + two KLs, shared encoder used twice, four eps draws in
+    validation); the plain DoubleAutoencoder fixtures are held by the GPU suite (CPU suite time)."""
+    arrays, meta = double_golden
+    key = "dve64"
+    P = _params(pkg, _model_shapes(pkg, key, lambda: pkg.Networks.DoubleVariationalAutoencoder(64)), STEP_BIAS_STD)
+    P = {k[len(key) + 1:]: v for k, v in P.items()}
+    x, y = (torch.from_numpy(a) for a in pkg.synth.batch(2, 64, SEED, step=VAL_STEP))
+    eps = [torch.from_numpy(e) for e in pkg.synth.eps_list(4, (2, 64, 4, 4), SEED, step=VAL_STEP)]
+    m, o = oracle.double_validation(P, x, y, eps, LAMBDAS["lambda_kl"])
+    _check_metrics(m, meta[key + "/validation"], f"{key} validation", tol=1e-4)
+    assert_close(o["Gx"][:, :, ::4, ::4], arrays[key + "/val_Gx"], "val Gx (A->B)", l2=1e-4, mx=1e-3)
+    assert_close(o["Fy"][:, :, ::4, ::4], arrays[key + "/val_Fy"], "val Fy (B->A)", l2=1e-4, mx=1e-3)
+    x, y = (torch.from_numpy(a) for a in pkg.synth.batch(2, 64, SEED, step=0))
+    eps = [torch.from_numpy(e) for e in pkg.synth.eps_list(2, (2, 64, 4, 4), SEED, step=0)]
+    m, grads = oracle.double_step(P, {}, x, y, eps, LR, LAMBDAS["lambda_kl"])
+    _check_metrics(m, meta[key][0], f"{key} step 0", tol=1e-4)
+    check_step_state(P, grads, key, arrays, LR, snap="@step1", tol=1e-3)

@@ -827,3 +827,166 @@ class CycleVAE(_CycleNoGAN):
         self.lambda_kl = kwargs.get("lambda_kl", 1e-5)
         self.lambda_cycle = kwargs.get("lambda_cycle", 10.0)
 
+
+class DoubleAutoencoder(_OptimizerStatesMixin, nn.Module):
+    """One shared encoder, decoder_A reconstructs the source and decoder_B the target modality — the pretraining model
+    for CycleAE (reference Networks.py:415-606).  The encoder runs twice per step, so its weight gradients accumulate
+    from both uses (the backward kernels add into the flat gradient buffer)."""
+
+    def __init__(self):
+        super().__init__()
+        self.encoder = Encoder()
+        self.decoder_A = Decoder()
+        self.decoder_B = Decoder()
+        self.optimizer = None
+        self.grad_reducer = None
+        self.loss_fn = None
+
+    def forward(self, x, y):
+        x, y = ops.to_nhwc(x), ops.to_nhwc(y)
+        return self.decoder_A(self.encoder(x)), self.decoder_B(self.encoder(y))
+
+    def translate_A_to_B(self, x):
+        return self.decoder_B(self.encoder(ops.to_nhwc(x)))
+
+    def translate_B_to_A(self, y):
+        return self.decoder_A(self.encoder(ops.to_nhwc(y)))
+
+    def create_cycle_ae(self):
+        """reference :580-606: G (A->B) = encoder + decoder_B, F (B->A) = encoder + decoder_A."""
+        cycle_ae = CycleAE().to(next(self.parameters()).device)
+        cycle_ae.G.encoder.load_state_dict(self.encoder.state_dict())
+        cycle_ae.G.decoder.load_state_dict(self.decoder_B.state_dict())
+        cycle_ae.F.encoder.load_state_dict(self.encoder.state_dict())
+        cycle_ae.F.decoder.load_state_dict(self.decoder_A.state_dict())
+        return cycle_ae
+
+    def configure_optimizers(self, lr=1e-4, betas=(0.5, 0.999)):
+        self.optimizer = FusedAdam(self.parameters(), lr=lr, betas=betas)
+        return self.optimizer
+
+    def configure_loss(self, **kwargs):
+        self.loss_fn = TranslationLoss()
+
+    def _losses(self, batch):
+        x, y = ops.to_nhwc(batch["x"]), ops.to_nhwc(batch["y"])
+        Gx, Gy = self(x, y)
+        t = {"loss_recon_A": self.loss_fn(Gx, x), "loss_recon_B": self.loss_fn(Gy, y)}
+        t["G_loss"] = ops.weighted_sum([t["loss_recon_A"], t["loss_recon_B"]], [1.0, 1.0])
+        return t, x, y
+
+    def training_step(self, batch):
+        if self.loss_fn is None:
+            raise ValueError("Loss function has not been configured yet.")
+        if self.optimizer is None:
+            raise ValueError("Optimizer has not been configured yet.")
+        t, _, _ = self._losses(batch)
+        self.optimizer.zero_grad()
+        ops.backward_overlapped(t["G_loss"])
+        _reduced_step(self.optimizer, self.grad_reducer)
+        h = _metrics_to_host(t, self.grad_reducer)
+        return {"G_loss": h["G_loss"], "loss_recon_A": h["loss_recon_A"], "loss_recon_B": h["loss_recon_B"], "total_loss": h["G_loss"]}
+
+    def validation_step(self, batch):
+        if self.loss_fn is None:
+            raise ValueError("Loss function has not been configured yet.")
+        with torch.no_grad():
+            t, x, y = self._losses(batch)
+            h = _metrics_to_host(t)
+            return {"G_loss": h["G_loss"], "total_loss": h["G_loss"], "loss_recon_A": h["loss_recon_A"],
+                    "loss_recon_B": h["loss_recon_B"], "Gx": self.translate_A_to_B(x), "Fy": self.translate_B_to_A(y)}
+
+
+class DoubleVariationalAutoencoder(_OptimizerStatesMixin, nn.Module):
+    """Shared encoder, one VAE bottleneck and one decoder per modality — the pretraining model for CycleVAE / CycleVAEGAN
+    (reference Networks.py:608-852).  eps draws per forward: block A on enc(x), then block B on enc(y); validation adds one
+    per translation."""
+
+    def __init__(self, latent_dim=64):
+        super().__init__()
+        self.encoder = Encoder()
+        self.vae_encoder_block_A = VariationalEncoderBlock(in_channels=1024, latent_dim=latent_dim)
+        self.vae_encoder_block_B = VariationalEncoderBlock(in_channels=1024, latent_dim=latent_dim)
+        self.vae_decoder_block_A = VariationalDecoderBlock(latent_dim=latent_dim, out_channels=1024)
+        self.vae_decoder_block_B = VariationalDecoderBlock(latent_dim=latent_dim, out_channels=1024)
+        self.decoder_A = Decoder()
+        self.decoder_B = Decoder()
+        self.optimizer = None
+        self.grad_reducer = None
+        self.loss_trans_fn = None
+        self.loss_kl_fn = None
+        self.lambda_kl = 0
+        self.apply(self._init_weights)
+
+    def _init_weights(self, module):
+        _kaiming_relu_init(module)
+
+    def forward(self, x, y):
+        x, y = ops.to_nhwc(x), ops.to_nhwc(y)
+        encoded_x = self.encoder(x)
+        encoded_y = self.encoder(y)
+        z_x, mu_x, logvar_x = self.vae_encoder_block_A(encoded_x)
+        z_y, mu_y, logvar_y = self.vae_encoder_block_B(encoded_y)
+        Gx = self.decoder_A(self.vae_decoder_block_A(z_x))
+        Gy = self.decoder_B(self.vae_decoder_block_B(z_y))
+        return Gx, Gy, mu_x, logvar_x, mu_y, logvar_y
+
+    def translate_A_to_B(self, x):
+        z, _, _ = self.vae_encoder_block_B(self.encoder(ops.to_nhwc(x)))
+        return self.decoder_B(self.vae_decoder_block_B(z))
+
+    def translate_B_to_A(self, y):
+        z, _, _ = self.vae_encoder_block_A(self.encoder(ops.to_nhwc(y)))
+        return self.decoder_A(self.vae_decoder_block_A(z))
+
+    def create_cycle_vae(self):
+        """reference :701-736: G = encoder + VAE blocks B + decoder_B, F = encoder + VAE blocks A + decoder_A."""
+        cycle_vae = CycleVAE(latent_dim=self.vae_encoder_block_A.latent_dim).to(next(self.parameters()).device)
+        for gen, sfx in ((cycle_vae.G, "B"), (cycle_vae.F, "A")):
+            gen.encoder.load_state_dict(self.encoder.state_dict())
+            gen.variational_encoder_block.load_state_dict(getattr(self, "vae_encoder_block_" + sfx).state_dict())
+            gen.variational_decoder_block.load_state_dict(getattr(self, "vae_decoder_block_" + sfx).state_dict())
+            gen.decoder.load_state_dict(getattr(self, "decoder_" + sfx).state_dict())
+        return cycle_vae
+
+    def configure_optimizers(self, lr=1e-4, betas=(0.5, 0.999)):
+        self.optimizer = FusedAdam(self.parameters(), lr=lr, betas=betas)
+        return self.optimizer
+
+    def configure_loss(self, **kwargs):
+        self.loss_trans_fn = TranslationLoss()
+        self.loss_kl_fn = KLDivergenceLoss()
+        self.lambda_kl = kwargs.get("lambda_kl", 1e-5)
+
+    def _losses(self, batch):
+        x, y = ops.to_nhwc(batch["x"]), ops.to_nhwc(batch["y"])
+        Gx, Gy, mu_x, logvar_x, mu_y, logvar_y = self(x, y)
+        t = {"loss_recon_A": self.loss_trans_fn(Gx, x), "loss_recon_B": self.loss_trans_fn(Gy, y),
+             "loss_kl_A": self.loss_kl_fn(mu_x, logvar_x), "loss_kl_B": self.loss_kl_fn(mu_y, logvar_y)}
+        t["loss_kl"] = ops.weighted_sum([t["loss_kl_A"], t["loss_kl_B"]], [1.0, 1.0])
+        t["G_loss"] = ops.weighted_sum([t["loss_recon_A"], t["loss_recon_B"], t["loss_kl"]], [1.0, 1.0, self.lambda_kl])
+        return t, x, y
+
+    def training_step(self, batch):
+        if self.loss_trans_fn is None or self.loss_kl_fn is None:
+            raise ValueError("Loss functions have not been configured yet.")
+        if self.optimizer is None:
+            raise ValueError("Optimizer has not been configured yet.")
+        t, _, _ = self._losses(batch)
+        self.optimizer.zero_grad()
+        ops.backward_overlapped(t["G_loss"])
+        _reduced_step(self.optimizer, self.grad_reducer)
+        h = _metrics_to_host(t, self.grad_reducer)
+        return {"G_loss": h["G_loss"], "loss_recon_A": h["loss_recon_A"], "loss_recon_B": h["loss_recon_B"], "loss_kl": h["loss_kl"],
+                "loss_kl_A": h["loss_kl_A"], "loss_kl_B": h["loss_kl_B"], "total_loss": h["G_loss"]}
+
+    def validation_step(self, batch):
+        if self.loss_trans_fn is None or self.loss_kl_fn is None:
+            raise ValueError("Loss functions have not been configured yet.")
+        with torch.no_grad():
+            t, x, y = self._losses(batch)
+            h = _metrics_to_host(t)
+            return {"G_loss": h["G_loss"], "total_loss": h["G_loss"], "loss_recon_A": h["loss_recon_A"],
+                    "loss_recon_B": h["loss_recon_B"], "loss_kl": h["loss_kl"], "loss_kl_A": h["loss_kl_A"],
+                    "loss_kl_B": h["loss_kl_B"], "Gx": self.translate_A_to_B(x), "Fy": self.translate_B_to_A(y)}
+

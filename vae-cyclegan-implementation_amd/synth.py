@@ -5,7 +5,9 @@ batches keyed by ("x"|"y", step, rank), eps keyed by call index.  The golden fix
 tests/golden were produced by feeding exactly these tensors to the reference, so the same
 inputs can be rebuilt on any machine without shipping them.
 """
+import os
 import zlib
+from concurrent.futures import ThreadPoolExecutor
 
 import numpy as np
 
@@ -51,21 +53,24 @@ def state_dict_like(shapes, seed, bias_std=0.0):
     """{name: ndarray} reproducing the reference's init statistics (Networks.py:168-178, 1893-1903):
     conv weights Kaiming-normal fan_out (std = sqrt(2 / (Cout*kh*kw))), biases zero (or N(0, bias_std^2) to
     exercise the bias paths in parity tests), spectral-norm u/v unit vectors."""
-    out = {}
-    for name, shape in shapes.items():
-        shape = tuple(shape)
+    def one(item):
+        name, shape = item[0], tuple(item[1])
         if name.endswith("weight_u") or name.endswith("weight_v"):
             v = normal(shape, seed, name).astype(np.float64)
             v = v / max(np.sqrt((v * v).sum()), 1e-12)
-            out[name] = v.astype(np.float32)
-        elif name.endswith("weight") or name.endswith("weight_orig"):
+            return v.astype(np.float32)
+        if name.endswith("weight") or name.endswith("weight_orig"):
             fan_out = shape[0] * int(np.prod(shape[2:]))
-            out[name] = normal(shape, seed, name, std=float(np.sqrt(2.0 / fan_out)))
-        elif name.endswith("bias"):
-            out[name] = normal(shape, seed, name, std=bias_std) if bias_std > 0 else np.zeros(shape, np.float32)
-        else:
-            raise KeyError(f"don't know how to synthesise {name}")
-    return out
+            return normal(shape, seed, name, std=float(np.sqrt(2.0 / fan_out)))
+        if name.endswith("bias"):
+            return normal(shape, seed, name, std=bias_std) if bias_std > 0 else np.zeros(shape, np.float32)
+        raise KeyError(f"don't know how to synthesise {name}")
+
+    # every tensor is a pure function of (seed, name): build them on a few threads (numpy releases the GIL); a full
+    # CycleVAEGAN (138 M values) takes ~50 s on one core, and every full-model test pays it
+    items = list(shapes.items())
+    with ThreadPoolExecutor(max_workers=max(1, min(6, os.cpu_count() or 1))) as pool:
+        return dict(zip((k for k, _ in items), pool.map(one, items)))
 
 
 def batch(n, size, seed, step=0, rank=0):

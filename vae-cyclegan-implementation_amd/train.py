@@ -34,7 +34,7 @@ else:
     from . import Networks, ops, parallel, utils
 
 ALIASES = {"ae": "autoencoder", "vae_cyclegan": "cyclevaegan"}
-BUILT = ("autoencoder", "vae", "cycleae", "cyclevae", "cycleaegan", "cyclevaegan")
+BUILT = ("autoencoder", "doubleae", "doublevae", "vae", "cycleae", "cyclevae", "cycleaegan", "cyclevaegan")
 REFERENCE_ARCHS = ["autoencoder", "doubleae", "doublevae", "vae", "aegan", "vaegan", "cycleae", "cyclevae",
                    "cycleaegan", "cyclevaegan"]
 
@@ -48,6 +48,12 @@ def create_model(architecture, paired=True, latent_dim=64):
     elif architecture == "vae":
         model = Networks.VariationalAutoencoder(latent_dim=latent_dim)
         print("Created Variational Autoencoder")
+    elif architecture == "doubleae":
+        model = Networks.DoubleAutoencoder()
+        print("Created Double Autoencoder (shared encoder + 2 decoders)")
+    elif architecture == "doublevae":
+        model = Networks.DoubleVariationalAutoencoder(latent_dim=latent_dim)
+        print("Created Double VAE (shared encoder + 2 VAE blocks + 2 decoders)")
     elif architecture == "cycleae":
         model = Networks.CycleAE(paired=paired)
         print(f"Created Cycle Autoencoder ({'paired' if paired else 'unpaired'} mode)")
@@ -181,8 +187,6 @@ def main(args):
     if args.dataset != "synthetic":
         raise NotImplementedError("only --dataset synthetic is built: the image pipelines of Data_Manager.py "
                                   "(PIL + torchvision) are outside the accelerated path (SURVEY.md §2)")
-    if args.pretrained_doubleae or args.pretrained_doublevae:
-        raise NotImplementedError("--pretrained_double* remap checkpoints of composites that are not built (SURVEY.md §8f.3)")
     if args.no_cuda or not torch.cuda.is_available():
         raise RuntimeError("this path has no CPU implementation: an MI355X is required (the reference's own "
                            "train.py is the CPU path)")
@@ -216,6 +220,18 @@ def main(args):
         parallel.attach(model)
         parallel.broadcast_parameters(model)
     same_xy = args.architecture in ("autoencoder", "vae")
+    # reference train.py:448-463: a pretraining checkpoint initialises the generators of a Cycle model
+    if args.pretrained_doubleae is not None and args.pretrained_doublevae is not None:
+        raise ValueError("Cannot specify both --pretrained_doubleae and --pretrained_doublevae")
+    if args.pretrained_doubleae is not None:
+        if args.architecture not in ("cycleae", "cyclevae", "cycleaegan", "cyclevaegan"):
+            raise ValueError(f"--pretrained_doubleae can only be used with Cycle architectures, not {args.architecture}")
+        utils.load_pretrained_doubleae_to_cycleae(model, args.pretrained_doubleae, device)
+    if args.pretrained_doublevae is not None:
+        if args.architecture not in ("cyclevae", "cyclevaegan"):
+            raise ValueError("--pretrained_doublevae can only be used with CycleVAE or CycleVAEGAN architectures, "
+                             f"not {args.architecture}")
+        utils.load_pretrained_doublevae_to_cyclevae(model, args.pretrained_doublevae, device)
     start_epoch = 0
     if args.resume:                                  # reference train.py:471-477
         if rank == 0:

@@ -6,8 +6,8 @@ with the reference's state_dict keys and OIHW shapes (spectral-norm `weight_orig
 `optimizer_states = model.save_optimizer_states()` in torch.optim.Adam's state_dict format (optim.FusedAdam speaks it:
 per-parameter `step`, `exp_avg`, `exp_avg_sq`, one param group).  tests/golden/checkpoint_skeleton.json holds the
 structure of files written by the reference itself; tests/test_gpu_parity.py compares ours against it and checks that a
-resumed run continues bit-identically.  The DoubleAE/DoubleVAE -> Cycle remaps (reference utils.py:57-239) belong to
-composites that are not built."""
+resumed run continues bit-identically.  `load_pretrained_double*_to_cycle*` are the reference's remaps of a pretraining
+checkpoint onto a Cycle model (utils.py:57-239)."""
 import os
 
 import torch
@@ -54,3 +54,49 @@ def _to_cpu(obj):
     if isinstance(obj, (list, tuple)):
         return type(obj)(_to_cpu(v) for v in obj)
     return obj
+
+
+def _split_by_prefix(state_dict, prefixes):
+    parts = {p: {} for p in prefixes}
+    for key, value in state_dict.items():
+        for p in prefixes:
+            if key.startswith(p + "."):
+                parts[p][key[len(p) + 1:]] = value
+                break
+    return parts
+
+
+def load_pretrained_doubleae_to_cycleae(cycleae_model, doubleae_checkpoint_path, device):
+    """reference utils.py:57-121: G (A->B) <- encoder + decoder_B, F (B->A) <- encoder + decoder_A (for CycleAE and
+    CycleAEGAN, whose generators are plain autoencoders)."""
+    if not os.path.exists(doubleae_checkpoint_path):
+        raise FileNotFoundError(f"No DoubleAutoencoder checkpoint found at {doubleae_checkpoint_path}")
+    print(f"Loading DoubleAutoencoder weights from {doubleae_checkpoint_path}")
+    sd = torch.load(doubleae_checkpoint_path, map_location=device, weights_only=False)["model_state_dict"]
+    parts = _split_by_prefix(sd, ("encoder", "decoder_A", "decoder_B"))
+    cycleae_model.G.encoder.load_state_dict(parts["encoder"])
+    cycleae_model.G.decoder.load_state_dict(parts["decoder_B"])
+    cycleae_model.F.encoder.load_state_dict(parts["encoder"])
+    cycleae_model.F.decoder.load_state_dict(parts["decoder_A"])
+    print("Successfully loaded DoubleAutoencoder weights into CycleAE")
+
+
+def load_pretrained_doublevae_to_cyclevae(cycle_model, doublevae_checkpoint_path, device):
+    """reference utils.py:124-239: G <- encoder + VAE blocks B + decoder_B, F <- encoder + VAE blocks A + decoder_A (for
+    CycleVAE and CycleVAEGAN), with the reference's check that G and F did not end up swapped."""
+    if not os.path.exists(doublevae_checkpoint_path):
+        raise FileNotFoundError(f"No DoubleVariationalAutoencoder checkpoint found at {doublevae_checkpoint_path}")
+    print(f"Loading DoubleVariationalAutoencoder weights from {doublevae_checkpoint_path}")
+    sd = torch.load(doublevae_checkpoint_path, map_location=device, weights_only=False)["model_state_dict"]
+    parts = _split_by_prefix(sd, ("encoder", "vae_encoder_block_A", "vae_encoder_block_B", "vae_decoder_block_A",
+                                  "vae_decoder_block_B", "decoder_A", "decoder_B"))
+    for gen, sfx in ((cycle_model.G, "B"), (cycle_model.F, "A")):
+        gen.encoder.load_state_dict(parts["encoder"])
+        gen.variational_encoder_block.load_state_dict(parts["vae_encoder_block_" + sfx])
+        gen.variational_decoder_block.load_state_dict(parts["vae_decoder_block_" + sfx])
+        gen.decoder.load_state_dict(parts["decoder_" + sfx])
+        for name, value in gen.decoder.state_dict().items():
+            assert torch.equal(value.cpu(), parts["decoder_" + sfx][name].cpu()), \
+                f"decoder mismatch at {name} - G and F may be swapped!"
+    print("Successfully loaded DoubleVariationalAutoencoder weights into the Cycle model")
+
