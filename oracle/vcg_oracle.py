@@ -557,3 +557,81 @@ def double_validation(P, x, y, eps, lambda_kl=1e-5):
     out["G_loss"] = out["total_loss"] = total.item()
     return out, {"Gx": Gx, "Fy": Fy}
 
+
+# ----------------------------------------------------------------------------- AEGAN / VAEGAN
+def _single_gan_losses(Q, x, y, eps, run_d, lambda_gan, lambda_identity, lambda_kl, lambda_recon):
+    """AEGAN (Networks.py:1023-1028, :1090-1096; eps None, lambda_recon is 1 there) / VAEGAN (:1203-1208, :1266-1275;
+    eps[0] for G(x), eps[1] for G(y), KL of the x branch only)."""
+    m = {}
+    if eps is None:
+        Gx, Gy = autoencoder_forward(x, Q, "G."), autoencoder_forward(y, Q, "G.")
+    else:
+        Gx, mu, logvar = vae_forward(x, Q, "G.", eps[0])
+        Gy, _, _ = vae_forward(y, Q, "G.", eps[1])
+        m["loss_kl"] = kl_loss(mu, logvar)
+    DGx, Dy = run_d(Gx), run_d(y)
+    m["loss_trans"], m["loss_identity"] = l1(Gx, y), l1(Gy, y)
+    m["gan_g"], m["gan_g_real"], m["gan_g_fake"] = gan_loss_generator(Dy, DGx)
+    G_loss = (1.0 if eps is None else lambda_recon) * m["loss_trans"] + lambda_gan * m["gan_g"] + lambda_identity * m["loss_identity"]
+    if eps is not None:
+        G_loss = G_loss + lambda_kl * m["loss_kl"]
+    return G_loss, m, Gx, DGx, Dy
+
+
+def _single_gan_metrics(variational, training, G_loss, D_loss, d_real, d_fake, m, extra=None):
+    """the reference's metric names: AEGAN :1120-1130 / :1166-1178, VAEGAN :1289-1299 / :1334-1344"""
+    v = {k: t.item() for k, t in m.items()}
+    if not variational:
+        out = {"G_loss": G_loss.item(), "D_loss": D_loss.item(), "D_loss_real": d_real.item(), "D_loss_fake": d_fake.item(),
+               "loss_trans": v["loss_trans"], "loss_gan_g": v["gan_g"]}
+        if training:
+            out.update({"loss_identity": v["loss_identity"], **extra})
+        else:
+            out = {"total_loss": G_loss.item() + D_loss.item(), **out, "loss_gan_g_real": v["gan_g_real"],
+                   "loss_gan_g_fake": v["gan_g_fake"], "loss_identity": v["loss_identity"]}
+        return out
+    if training:
+        return {"G_loss": G_loss.item(), "D_loss": D_loss.item(), "loss_gan_disc_real": d_real.item(), "loss_gan_disc_fake": d_fake.item(),
+                "loss_trans": v["loss_trans"], "loss_gan_real": v["gan_g_real"], "loss_gan_fake": v["gan_g_fake"],
+                "loss_identity": v["loss_identity"], "loss_kl": v["loss_kl"]}
+    return {"total_loss": G_loss.item() + D_loss.item(), "G_loss": G_loss.item(), "D_loss": D_loss.item(),
+            "loss_trans": v["loss_trans"], "loss_gan_real": v["gan_g_real"], "loss_gan_fake": v["gan_g_fake"],
+            "loss_identity": v["loss_identity"], "loss_kl": v["loss_kl"]}
+
+
+def single_gan_step(P, state, x, y, eps, lr, lambda_gan=1.0, lambda_identity=5.0, lambda_kl=1e-5, lambda_recon=1.0):
+    """AEGAN.training_step (Networks.py:1068-1136: D re-run on the detached G(x) after the generator update) /
+    VAEGAN.training_step (:1254-1308: D loss on the same pass with DGx detached).  Both give the D gradients of the
+    pre-update discriminator on the pre-update G(x), which is what is computed here."""
+    g_names, d_names = trainable_names(P, ("G.",)), trainable_names(P, ("D.",))
+    Q = _leaf_params(P, g_names + d_names)
+    sn = {}
+
+    def run_d(inp):
+        out = discriminator(inp, Q, "D.", True, sn)
+        Q["D.model.4.weight_u"], Q["D.model.4.weight_v"] = sn["D.model.4.weight_u"], sn["D.model.4.weight_v"]
+        return out
+
+    G_loss, m, Gx, _, _ = _single_gan_losses(Q, x, y, eps, run_d, lambda_gan, lambda_identity, lambda_kl, lambda_recon)
+    g_grads = _grads(G_loss, Q, g_names)
+    adam_update(P, g_grads, state.setdefault("G", {}), g_names, lr)
+    DGx_d, Dy_d = run_d(Gx.detach()), run_d(y)
+    D_loss, d_real, d_fake = gan_loss_discriminator(Dy_d, DGx_d)
+    # VAEGAN detaches the discriminator OUTPUT of the fake branch (`DGx.detach()`, :1277), not its input: the fake term
+    # is a constant there and only (1 - D(y))^2 reaches the discriminator's parameters.  Reproduced as written.
+    d_grads = _grads(d_real if eps is not None else D_loss, Q, d_names)
+    adam_update(P, d_grads, state.setdefault("D", {}), d_names, lr)
+    for k, v in sn.items():
+        P[k] = v
+    extra = {"d_y_mean": Dy_d.mean().item(), "d_gx_mean": DGx_d.mean().item()}
+    return _single_gan_metrics(eps is not None, True, G_loss, D_loss, d_real, d_fake, m, extra), g_grads, d_grads
+
+
+def single_gan_validation(P, x, y, eps, lambda_gan=1.0, lambda_identity=5.0, lambda_kl=1e-5, lambda_recon=1.0):
+    """AEGAN.validation_step (Networks.py:1138-1188) / VAEGAN.validation_step (:1310-1348) under model.eval()."""
+    with torch.no_grad():
+        G_loss, m, Gx, DGx, Dy = _single_gan_losses(P, x, y, eps, lambda inp: discriminator(inp, P, "D.", False),
+                                                     lambda_gan, lambda_identity, lambda_kl, lambda_recon)
+        D_loss, d_real, d_fake = gan_loss_discriminator(Dy, DGx)
+    return _single_gan_metrics(eps is not None, False, G_loss, D_loss, d_real, d_fake, m), {"Gx": Gx}
+

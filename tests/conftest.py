@@ -71,6 +71,14 @@ def double_golden():
 
 
 @pytest.fixture(scope="session")
+def single_gan_golden():
+    """(arrays, metric dicts) of the reference's AEGAN / VAEGAN step and validation (make_golden.py single_gan)."""
+    with open(os.path.join(GOLDEN, "single_gan_meta.json")) as f:
+        meta = json.load(f)
+    return dict(np.load(os.path.join(GOLDEN, "single_gan.npz"))), meta
+
+
+@pytest.fixture(scope="session")
 def steps_meta():
     with open(os.path.join(GOLDEN, "steps_meta.json")) as f:
         return json.load(f)
@@ -217,6 +225,6 @@ def in_cancelled_bias(name):
     if name.endswith("conv2.bias"):
         return True
     for i in (1, 2, 3):
-        if (name.startswith("DX.") or name.startswith("DY.") or name.startswith("disc.")) and f"model.{i}.conv.bias" in name:
+        if name.startswith(("DX.", "DY.", "D.", "disc.")) and f"model.{i}.conv.bias" in name:
             return True
     return False

@@ -384,6 +384,31 @@ def gen_double(N, out, meta):
         print(key, meta[key], meta[key + "/validation"])
 
 
+def gen_single_gan(N, out, meta):
+    """AEGAN (Networks.py:991-1188) and VAEGAN (:1190-1348), SURVEY.md §8f.3: one generator, one discriminator; 256x256,
+    batch 1.  One training step and the eval-mode validation step.  VAEGAN draws eps for G(x) then G(y) (:1203-1208)."""
+    torch.set_num_threads(8)
+    for key, ctor, ne in (("aeg256", N.AEGAN, 0), ("vag256", lambda: N.VAEGAN(latent_dim=64), 2)):
+        model = ctor()
+        load_synth_params(model, SEED, 0.02, prefix=key + ".")
+        model.configure_optimizers(lr=LR)
+        model.configure_loss(**LAMBDAS)
+        model.eval()
+        x, y = (torch.from_numpy(a) for a in synth.batch(1, 256, SEED, step=7))
+        with EpsInjector(synth.eps_list(ne, (1, 64, 16, 16), SEED, step=7)):
+            m = model.validation_step({"x": x, "y": y})
+        out[key + "/val_Gx"] = m.pop("Gx")[:, :, ::16, ::16].numpy()
+        meta[key + "/validation"] = m
+        model.train()
+        x, y = (torch.from_numpy(a) for a in synth.batch(1, 256, SEED, step=0))
+        eps = synth.eps_list(ne, (1, 64, 16, 16), SEED, step=0)
+        with EpsInjector(eps):
+            meta[key] = [model.training_step({"x": x, "y": y})]
+        param_checksums(model, out, key + "@step1")
+        fp64_truth(ctor, key, {"x": x, "y": y}, eps, out)
+        print(key, meta[key], meta[key + "/validation"])
+
+
 def gen_checkpoint_skeleton(N):
     """Structure of the checkpoints the REFERENCE writes (utils.py:17-28: torch.save of {epoch, model_state_dict,
     optimizer_states, loss, args}) after one training step: key names, shapes and dtypes of every tensor, the optimizer
@@ -427,7 +452,7 @@ def main():
     torch.manual_seed(0)
     atoms, steps, meta = {}, {}, {"seed": SEED, "lr": LR, "lambdas": LAMBDAS,
                                   "torch": torch.__version__, "reference": "Baverne/VAE-CYCLEGAN-Implementation"}
-    which = sys.argv[1:] or ["atoms", "steps", "validation", "cycleaegan", "cycle_nogan", "double", "checkpoint"]
+    which = sys.argv[1:] or ["atoms", "steps", "validation", "cycleaegan", "cycle_nogan", "double", "single_gan", "checkpoint"]
     if "atoms" in which:
         gen_atoms(N, atoms)
         np.savez_compressed(os.path.join(HERE, "atoms.npz"), **atoms)
@@ -460,12 +485,18 @@ def main():
         np.savez_compressed(os.path.join(HERE, "double.npz"), **arr)
         with open(os.path.join(HERE, "double_meta.json"), "w") as f:
             json.dump(cmeta, f, indent=1)
+    if "single_gan" in which:
+        arr, cmeta = {}, {"seed": SEED, "lr": LR, "lambdas": LAMBDAS, "torch": torch.__version__}
+        gen_single_gan(N, arr, cmeta)
+        np.savez_compressed(os.path.join(HERE, "single_gan.npz"), **arr)
+        with open(os.path.join(HERE, "single_gan_meta.json"), "w") as f:
+            json.dump(cmeta, f, indent=1)
     if "checkpoint" in which:
         with open(os.path.join(HERE, "checkpoint_skeleton.json"), "w") as f:
             json.dump(gen_checkpoint_skeleton(N), f, indent=0)
     for fn in ("atoms.npz", "steps.npz", "steps_meta.json", "validation.npz", "validation_meta.json", "cycleaegan.npz",
                "cycleaegan_meta.json", "cycle_nogan.npz", "cycle_nogan_meta.json", "double.npz",
-               "double_meta.json", "checkpoint_skeleton.json"):
+               "double_meta.json", "single_gan.npz", "single_gan_meta.json", "checkpoint_skeleton.json"):
         p = os.path.join(HERE, fn)
         if os.path.exists(p):
             print(fn, os.path.getsize(p), "bytes")

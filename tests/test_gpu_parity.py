@@ -605,3 +605,30 @@ def test_double_step_and_validation_match_reference_golden(key, variational, pkg
     if variational:
         assert torch.equal(cs["G.variational_encoder_block.muConv.conv.weight"], sd["vae_encoder_block_B.muConv.conv.weight"])
         assert torch.equal(cs["F.variational_decoder_block.conv.conv.weight"], sd["vae_decoder_block_A.conv.conv.weight"])
+
+
+# ------------------------------------------------------------------ AEGAN / VAEGAN
+@pytest.mark.parametrize("key,variational", [("aeg256", False), ("vag256", True)])
+def test_single_gan_step_and_validation_match_reference_golden(key, variational, pkg, device, single_gan_golden):
+    arrays, meta = single_gan_golden
+    model = pkg.Networks.VAEGAN(latent_dim=64) if variational else pkg.Networks.AEGAN()
+    load_synth(pkg, model, key, STEP_BIAS_STD)
+    model = model.to(device)
+    model.configure_optimizers(lr=LR)
+    model.configure_loss(**LAMBDAS)
+
+    def inject(step):
+        if variational:
+            pkg.ops.inject_eps([torch.from_numpy(e) for e in pkg.synth.eps_list(2, (1, 64, 16, 16), SEED, step=step)])
+    model.eval()
+    x, y = (torch.from_numpy(a).to(device) for a in pkg.synth.batch(1, 256, SEED, step=VAL_STEP))
+    inject(VAL_STEP)
+    m = model.validation_step({"x": x, "y": y})
+    assert_close(nchw(m.pop("Gx"))[:, :, ::16, ::16], arrays[key + "/val_Gx"], "val Gx", l2=1e-3)
+    _check_metrics(m, meta[key + "/validation"], f"{key} validation")
+    model.train()
+    x, y = (torch.from_numpy(a).to(device) for a in pkg.synth.batch(1, 256, SEED, step=0))
+    inject(0)
+    m = model.training_step({"x": x, "y": y})
+    _check_metrics(m, meta[key][0], f"{key} step 0")
+    _check_state(model, key, arrays, flip=GAN_FLIP_BUDGET)

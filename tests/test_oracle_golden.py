@@ -335,3 +335,24 @@ def test_oracle_double_vae_step_and_validation_match_reference(pkg, oracle, doub
     m, grads = oracle.double_step(P, {}, x, y, eps, LR, LAMBDAS["lambda_kl"])
     _check_metrics(m, meta[key][0], f"{key} step 0", tol=1e-4)
     check_step_state(P, grads, key, arrays, LR, snap="@step1", tol=1e-3)
+
+
+# ------------------------------------------------------------------ AEGAN / VAEGAN
+def test_oracle_vaegan_step_and_validation_match_reference(pkg, oracle, single_gan_golden):
+    """VAEGAN holds every term of the pair (reconstruction, LSGAN, identity, KL); AEGAN's fixtures are held by the GPU suite."""
+    arrays, meta = single_gan_golden
+    torch.set_num_threads(max(1, min(8, os.cpu_count() or 1)))
+    key = "vag256"
+    P = _params(pkg, _model_shapes(pkg, key, lambda: pkg.Networks.VAEGAN(64)), STEP_BIAS_STD)
+    P = {k[len(key) + 1:]: v for k, v in P.items()}
+    lam = (LAMBDAS["lambda_gan"], LAMBDAS["lambda_identity"], LAMBDAS["lambda_kl"], LAMBDAS["lambda_recon"])
+    x, y = (torch.from_numpy(a) for a in pkg.synth.batch(1, 256, SEED, step=VAL_STEP))
+    eps = [torch.from_numpy(e) for e in pkg.synth.eps_list(2, (1, 64, 16, 16), SEED, step=VAL_STEP)]
+    m, o = oracle.single_gan_validation(P, x, y, eps, *lam)
+    _check_metrics(m, meta[key + "/validation"], f"{key} validation", tol=1e-3)
+    assert_close(o["Gx"][:, :, ::16, ::16], arrays[key + "/val_Gx"], "val Gx", l2=1e-4, mx=1e-3)
+    x, y = (torch.from_numpy(a) for a in pkg.synth.batch(1, 256, SEED, step=0))
+    eps = [torch.from_numpy(e) for e in pkg.synth.eps_list(2, (1, 64, 16, 16), SEED, step=0)]
+    m, g_grads, d_grads = oracle.single_gan_step(P, {}, x, y, eps, LR, *lam)
+    _check_metrics(m, meta[key][0], f"{key} step 0", tol=1e-3)
+    check_step_state(P, {**g_grads, **d_grads}, key, arrays, LR, snap="@step1", tol=1e-3)

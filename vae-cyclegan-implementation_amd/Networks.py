@@ -990,3 +990,208 @@ class DoubleVariationalAutoencoder(_OptimizerStatesMixin, nn.Module):
                     "loss_recon_B": h["loss_recon_B"], "loss_kl": h["loss_kl"], "loss_kl_A": h["loss_kl_A"],
                     "loss_kl_B": h["loss_kl_B"], "Gx": self.translate_A_to_B(x), "Fy": self.translate_B_to_A(y)}
 
+
+class _SingleGAN(nn.Module):
+    """One generator G: X->Y and one discriminator D on Y, alternating G / D updates — the shared step of AEGAN and VAEGAN
+    (reference Networks.py:991-1348).  As in CycleVAEGAN the discriminator runs once per step: the G phase takes its data
+    gradient, the D phase its weight gradients from the same activations.  VAEGAN is written that way in the reference
+    (`DGx.detach()`, `retain_graph`, :1277-1287); AEGAN re-runs D on the detached G(x) after the generator update
+    (:1105-1108), which reproduces the same outputs because that update does not touch D."""
+
+    def configure_optimizers(self, lr=2e-4, betas=(0.5, 0.999)):
+        self.optimizer_G = FusedAdam(self.G.parameters(), lr=lr, betas=betas)
+        self.optimizer_D = FusedAdam(self.D.parameters(), lr=lr, betas=betas)
+        return self.optimizer_G, self.optimizer_D
+
+    def save_optimizer_states(self):
+        if self.optimizer_G is None or self.optimizer_D is None:
+            raise ValueError("Optimizers have not been configured yet.")
+        return {"optimizer_G": self.optimizer_G.state_dict(), "optimizer_D": self.optimizer_D.state_dict()}
+
+    def load_optimizer_states(self, states):
+        if self.optimizer_G is None or self.optimizer_D is None:
+            raise ValueError("Optimizers have not been configured yet.")
+        for name in ("optimizer_G", "optimizer_D"):
+            if name not in states:
+                raise KeyError(f"{name} state not found in states")
+        self.optimizer_G.load_state_dict(states["optimizer_G"])
+        self.optimizer_D.load_state_dict(states["optimizer_D"])
+
+    def _gan_terms(self, t, DGx, Dy):
+        """LSGAN terms on one discriminator pass: generator (real -> 0, fake -> 1, Losses.py:67-83) and discriminator
+        (real -> 1, fake -> 0, :86-102) objectives, plus the output means AEGAN logs."""
+        t["gan_g_real"], t["d_y_mean"] = ops.mse_const(Dy, 0.0)
+        t["gan_g_fake"], t["d_gx_mean"] = ops.mse_const(DGx, 1.0)
+        t["gan_g"] = ops.weighted_sum([t["gan_g_real"], t["gan_g_fake"]], [1.0, 1.0])
+        t["D_loss_real"], _ = ops.mse_const(Dy, 1.0)
+        t["D_loss_fake"], _ = ops.mse_const(DGx, 0.0)
+        t["D_loss"] = ops.weighted_sum([t["D_loss_real"], t["D_loss_fake"]], [1.0, 1.0])
+
+    def _alternating_step(self, t):
+        g_params, d_params = self.optimizer_G.params, self.optimizer_D.params
+        red = self.grad_reducer
+        self.optimizer_G.zero_grad()
+        with ops.no_wgrad(d_params):
+            ops.backward_overlapped(t["G_loss"], inputs=g_params, retain_graph=True)
+        if red is not None:
+            red.start(self.optimizer_G)
+        self.optimizer_D.zero_grad()
+        with ops.no_dgrad([self.D.model[0]._spec]):
+            ops.backward_overlapped(t.get("D_loss_backward", t["D_loss"]), overlap=red is None, inputs=d_params)
+        if red is not None:
+            red.start(self.optimizer_D)
+            red.finish(self.optimizer_G)
+        self.optimizer_G.step(repack=red is None)
+        if red is not None:
+            red.finish(self.optimizer_D)
+        self.optimizer_D.step(repack=red is None)
+        if red is not None:
+            ops.repack_async(g_params + d_params)
+
+
+class AEGAN(_SingleGAN):
+    """Autoencoder generator + discriminator: L1(G(x), y) + lambda_gan * LSGAN + lambda_identity * L1(G(y), y)
+    (reference Networks.py:991-1188)."""
+
+    def __init__(self):
+        super().__init__()
+        self.G = Autoencoder()
+        self.D = Discriminator()
+        self.apply(self._init_weights_)
+        self.optimizer_G = None
+        self.optimizer_D = None
+        self.grad_reducer = None
+        self.loss_trans_fn = None
+        self.loss_gan_gen_fn = None
+        self.loss_gan_disc_fn = None
+        self.loss_identity_fn = None
+        self.lambda_gan = 0
+        self.lambda_identity = 0
+
+    def _init_weights_(self, module):
+        _kaiming_relu_init(module)
+
+    def forward(self, x, y):
+        x, y = ops.to_nhwc(x), ops.to_nhwc(y)
+        Gx = self.G(x)
+        Gy = self.G(y)
+        return Gx, Gy, self.D(Gx), self.D(y)
+
+    def configure_loss(self, **kwargs):
+        self.loss_trans_fn = TranslationLoss()
+        self.loss_gan_gen_fn = GANLossGenerator()
+        self.loss_gan_disc_fn = GANLossDiscriminator()
+        self.loss_identity_fn = TranslationLoss()
+        self.lambda_gan = kwargs.get("lambda_gan", 1.0)
+        self.lambda_identity = kwargs.get("lambda_identity", 5.0)
+
+    def _check_configured(self):
+        if self.optimizer_G is None or self.optimizer_D is None:
+            raise ValueError("Optimizers have not been configured yet.")
+        if self.loss_trans_fn is None:
+            raise ValueError("Translation loss function has not been configured yet.")
+        if self.loss_gan_gen_fn is None:
+            raise ValueError("GAN generator loss function has not been configured yet.")
+        if self.loss_gan_disc_fn is None:
+            raise ValueError("GAN discriminator loss function has not been configured yet.")
+        if self.loss_identity_fn is None:
+            raise ValueError("Identity loss function has not been configured yet.")
+
+    def _losses(self, batch):
+        x, y = ops.to_nhwc(batch["x"]), ops.to_nhwc(batch["y"])
+        Gx, Gy, DGx, Dy = self(x, y)
+        t = {"loss_trans": self.loss_trans_fn(Gx, y), "loss_identity": self.loss_identity_fn(Gy, y)}
+        self._gan_terms(t, DGx, Dy)
+        t["G_loss"] = ops.weighted_sum([t["loss_trans"], t["gan_g"], t["loss_identity"]], [1.0, self.lambda_gan, self.lambda_identity])
+        return t, Gx
+
+    def training_step(self, batch):
+        self._check_configured()
+        t, _ = self._losses(batch)
+        self._alternating_step(t)
+        h = _metrics_to_host(t, self.grad_reducer)
+        return {"G_loss": h["G_loss"], "D_loss": h["D_loss"], "D_loss_real": h["D_loss_real"], "D_loss_fake": h["D_loss_fake"],
+                "loss_trans": h["loss_trans"], "loss_gan_g": h["gan_g"], "loss_identity": h["loss_identity"],
+                "d_y_mean": h["d_y_mean"], "d_gx_mean": h["d_gx_mean"]}
+
+    def validation_step(self, batch):
+        self._check_configured()            # the reference's AEGAN wants its optimizers even to validate (:1145)
+        with torch.no_grad():
+            t, Gx = self._losses(batch)
+            h = _metrics_to_host(t)
+            return {"total_loss": h["G_loss"] + h["D_loss"], "G_loss": h["G_loss"], "D_loss": h["D_loss"],
+                    "D_loss_real": h["D_loss_real"], "D_loss_fake": h["D_loss_fake"], "loss_trans": h["loss_trans"],
+                    "loss_gan_g": h["gan_g"], "loss_gan_g_real": h["gan_g_real"], "loss_gan_g_fake": h["gan_g_fake"],
+                    "loss_identity": h["loss_identity"], "Gx": Gx}
+
+
+class VAEGAN(_SingleGAN):
+    """VAE generator + discriminator: lambda_recon * L1(G(x), y) + lambda_gan * LSGAN + lambda_identity * L1(G(y), y) +
+    lambda_kl * KL(mu_x, logvar_x)  (reference Networks.py:1190-1348; eps is drawn for G(x), then for G(y))."""
+
+    def __init__(self, latent_dim=64):
+        super().__init__()
+        self.G = VariationalAutoencoder(latent_dim)
+        self.D = Discriminator()
+        self.latent_dim = latent_dim
+        self.debug_mode = False
+        self.debug_info = {}
+        self.optimizer_G = None             # (left unset by the reference's __init__)
+        self.optimizer_D = None
+        self.grad_reducer = None
+
+    def forward(self, x, y):
+        x, y = ops.to_nhwc(x), ops.to_nhwc(y)
+        Gx, mu, logvar = self.G(x)
+        Gy, mu_y, logvar_y = self.G(y)
+        return Gx, mu, logvar, Gy, mu_y, logvar_y, self.D(Gx), self.D(y)
+
+    def configure_loss(self, **kwargs):
+        self.translation_loss = TranslationLoss()
+        self.gan_loss_gen = GANLossGenerator()
+        self.gan_loss_disc = GANLossDiscriminator()
+        self.identity_loss = TranslationLoss()
+        self.kl_loss = KLDivergenceLoss()
+        self.lambda_gan = kwargs.get("lambda_gan", 1.0)
+        self.lambda_identity = kwargs.get("lambda_identity", 5.0)
+        self.lambda_kl = kwargs.get("lambda_kl", 1e-5)
+        self.lambda_recon = kwargs.get("lambda_recon", 1.0)
+
+    def enable_debug_mode(self, enabled=True):
+        self.debug_mode = enabled
+
+    def _losses(self, batch):
+        x, y = ops.to_nhwc(batch["x"]), ops.to_nhwc(batch["y"])
+        Gx, mu, logvar, Gy, _, _, DGx, Dy = self(x, y)
+        t = {"loss_trans": self.translation_loss(Gx, y), "loss_identity": self.identity_loss(Gy, y),
+             "loss_kl": self.kl_loss(mu, logvar)}
+        self._gan_terms(t, DGx, Dy)
+        t["G_loss"] = ops.weighted_sum([t["loss_trans"], t["gan_g"], t["loss_identity"], t["loss_kl"]],
+                                       [self.lambda_recon, self.lambda_gan, self.lambda_identity, self.lambda_kl])
+        # the reference detaches the discriminator OUTPUT of the fake branch (`gan_loss_disc(Dy, DGx.detach())`, :1277),
+        # not its input: the fake term is a constant in D_loss and only (1 - D(y))^2 reaches D's parameters.  Kept as
+        # written — D_loss reports both terms, the backward pass sees the real one.
+        t["D_loss_backward"] = t["D_loss_real"]
+        return t, Gx
+
+    def training_step(self, batch):
+        if self.optimizer_G is None or self.optimizer_D is None:
+            raise ValueError("Optimizers have not been configured yet.")
+        t, _ = self._losses(batch)
+        self._alternating_step(t)
+        h = _metrics_to_host(t, self.grad_reducer)
+        m = {"G_loss": h["G_loss"], "D_loss": h["D_loss"], "loss_gan_disc_real": h["D_loss_real"],
+             "loss_gan_disc_fake": h["D_loss_fake"], "loss_trans": h["loss_trans"], "loss_gan_real": h["gan_g_real"],
+             "loss_gan_fake": h["gan_g_fake"], "loss_identity": h["loss_identity"], "loss_kl": h["loss_kl"]}
+        if self.debug_mode:
+            m["debug_info"] = self.debug_info
+        return m
+
+    def validation_step(self, batch):
+        with torch.no_grad():
+            t, Gx = self._losses(batch)
+            h = _metrics_to_host(t)
+            return {"total_loss": h["G_loss"] + h["D_loss"], "G_loss": h["G_loss"], "D_loss": h["D_loss"],
+                    "loss_trans": h["loss_trans"], "loss_gan_real": h["gan_g_real"], "loss_gan_fake": h["gan_g_fake"],
+                    "loss_identity": h["loss_identity"], "loss_kl": h["loss_kl"], "Gx": Gx}
+

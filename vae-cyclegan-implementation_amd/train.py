@@ -34,9 +34,9 @@ else:
     from . import Networks, ops, parallel, utils
 
 ALIASES = {"ae": "autoencoder", "vae_cyclegan": "cyclevaegan"}
-BUILT = ("autoencoder", "doubleae", "doublevae", "vae", "cycleae", "cyclevae", "cycleaegan", "cyclevaegan")
 REFERENCE_ARCHS = ["autoencoder", "doubleae", "doublevae", "vae", "aegan", "vaegan", "cycleae", "cyclevae",
                    "cycleaegan", "cyclevaegan"]
+BUILT = tuple(REFERENCE_ARCHS)
 
 
 def create_model(architecture, paired=True, latent_dim=64):
@@ -54,6 +54,12 @@ def create_model(architecture, paired=True, latent_dim=64):
     elif architecture == "doublevae":
         model = Networks.DoubleVariationalAutoencoder(latent_dim=latent_dim)
         print("Created Double VAE (shared encoder + 2 VAE blocks + 2 decoders)")
+    elif architecture == "aegan":
+        model = Networks.AEGAN()
+        print("Created AE-GAN")
+    elif architecture == "vaegan":
+        model = Networks.VAEGAN(latent_dim=latent_dim)
+        print("Created VAE-GAN")
     elif architecture == "cycleae":
         model = Networks.CycleAE(paired=paired)
         print(f"Created Cycle Autoencoder ({'paired' if paired else 'unpaired'} mode)")
