@@ -204,7 +204,9 @@ def test_oracle_vae_steps_match_reference(pkg, oracle, steps_golden, steps_meta)
     check_step_state(P, None, key, steps_golden, LR, nsteps=2)
 
 
-@pytest.mark.parametrize("key,paired,nsteps", [("cvg256_unpaired", False, 2), ("cvg256_paired", True, 1)])
+# (the unpaired fixture holds a second step; the CPU suite stops after the first — multi-step carry of the Adam state is
+# covered at 64x64 by the autoencoder / VAE tests above, and each 256x256 step costs the oracle ~30 s)
+@pytest.mark.parametrize("key,paired,nsteps", [("cvg256_unpaired", False, 1), ("cvg256_paired", True, 1)])
 def test_oracle_cyclevaegan_steps_match_reference(key, paired, nsteps, pkg, oracle, steps_golden, steps_meta):
     torch.set_num_threads(max(1, min(8, os.cpu_count() or 1)))
     P = _params(pkg, _model_shapes(pkg, key, lambda: pkg.Networks.CycleVAEGAN(64, paired)), STEP_BIAS_STD)
