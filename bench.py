@@ -35,7 +35,16 @@ WORKLOADS = {
     "cyclevaegan": "cyclevaegan unpaired, 3x256x256 synthetic summer<->winter, per-GPU batch 8, latent 64 (BASELINE.json configs[3]/[4])",
     "vae": "vae latent 1024, 3x256x256 synthetic, batch 16 (BASELINE.json configs[2])",
     "autoencoder": "autoencoder, 3x256x256 synthetic, batch 16 (BASELINE.json configs[1])",
+    # the other architectures of the reference's factory: same kernels, other wiring; not headline configs
+    "cycleaegan": "cycleaegan unpaired, 3x256x256 synthetic, per-GPU batch 8",
+    "cycleae": "cycleae unpaired, 3x256x256 synthetic, per-GPU batch 8",
+    "cyclevae": "cyclevae unpaired, 3x256x256 synthetic, per-GPU batch 8, latent 64",
+    "doubleae": "doubleae, 3x256x256 synthetic, per-GPU batch 8",
+    "doublevae": "doublevae, 3x256x256 synthetic, per-GPU batch 8, latent 64",
+    "aegan": "aegan, 3x256x256 synthetic, per-GPU batch 8",
+    "vaegan": "vaegan, 3x256x256 synthetic, per-GPU batch 8, latent 64",
 }
+SAME_XY = ("autoencoder", "vae")          # the reference trains these on (x, x) (train.py:448-452: same modality)
 
 
 def main():
@@ -79,16 +88,15 @@ def main():
     pkg._native.lib()                      # fail loudly if the HIP extension is missing
 
     wl = args.workload
-    B = args.batch or (8 if wl == "cyclevaegan" else 16)
+    B = args.batch or (16 if wl in SAME_XY else 8)
     S = args.size
     latent = args.latent or (1024 if wl == "vae" else 64)
     torch.manual_seed(1234)                # identical random-init replicas on every rank
-    if wl == "cyclevaegan":
-        model = N.CycleVAEGAN(latent_dim=latent, paired=False)
-    elif wl == "vae":
-        model = N.VariationalAutoencoder(latent_dim=latent)
-    else:
-        model = N.Autoencoder()
+    model = {"cyclevaegan": lambda: N.CycleVAEGAN(latent_dim=latent, paired=False), "vae": lambda: N.VariationalAutoencoder(latent_dim=latent),
+             "autoencoder": N.Autoencoder, "cycleaegan": lambda: N.CycleAEGAN(paired=False), "cycleae": lambda: N.CycleAE(paired=False),
+             "cyclevae": lambda: N.CycleVAE(latent_dim=latent, paired=False), "doubleae": N.DoubleAutoencoder,
+             "doublevae": lambda: N.DoubleVariationalAutoencoder(latent_dim=latent), "aegan": N.AEGAN,
+             "vaegan": lambda: N.VAEGAN(latent_dim=latent)}[wl]()
     model = model.to(dev).train()
     model.configure_optimizers(lr=2e-4)
     model.configure_loss(lambda_kl=1e-5, lambda_gan=1.0, lambda_identity=5.0, lambda_cycle=10.0, lambda_recon=1.0)
@@ -105,7 +113,7 @@ def main():
         base = ((rank * 4 + i) * 2) * nquads
         x = ops.to_nhwc(ops.rand_uniform((B, 3, S, S), dev, seed=1234, offset=base))
         y = ops.to_nhwc(ops.rand_uniform((B, 3, S, S), dev, seed=1234, offset=base + nquads))
-        pool.append({"x": x, "y": y if wl == "cyclevaegan" else x})
+        pool.append({"x": x, "y": x if wl in SAME_XY else y})
 
     def barrier():
         if world > 1:
@@ -152,7 +160,7 @@ def main():
         roof = measure_roofline(pkg, model, pool, wl, B, S, latent, ms_per_step, rank)
         if rank == 0:
             out.update(roof)
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and wl in ("cyclevaegan", "vae", "autoencoder"):
         out["cpu_baseline"] = cpu_baseline(pkg, wl, S, latent)
     if world > 1:
         dist.barrier()
