@@ -213,10 +213,13 @@ def measure_roofline(pkg, model, pool, wl, B, S, latent, ms_per_step, rank=0):
                               "k_fold_pad", "k_splitk_finish"],
                "conv_wgrad": ["k_conv_wgrad", "k_wino_in", "k_wino_dy", "k_wino_wgrad_reduce", "k_wgrad_reduce", "k_wgrad_scatter",
                               "k_slab_sum", "k_colsum_partial", "k_colsum_final"]}
-    traffic, traffic_src = profiled_traffic(dom, n // 2) if wl == "cyclevaegan" and B == 8 and S == 256 else (None, None)
+    headline = wl == "cyclevaegan" and B == 8 and S == 256
+    traffic, traffic_src = profiled_traffic(dom, n // 2) if headline else (None, None)
+    mfma_util = profiled_mfma_util(symbols_of(dom)) if headline else None
     return {
         "roofline": {"bound": "mfma", "kernel": dom, "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
+                     "mfma_pipe_util": mfma_util,
                      "launches": n // 2, "avg_launch_ms": round(secs / n * 1e3, 4),
                      "peak_is": "fp32 MFMA (v_mfma_f32_32x32x2_f32), the roofline BASELINE.json's north_star names",
                      "peak_bf16x3": round(BF16X3_FP32_EQUIV_PEAK_TFLOPS, 1),
@@ -231,6 +234,28 @@ def measure_roofline(pkg, model, pool, wl, B, S, latent, ms_per_step, rank=0):
         "step_conv_frac_of_peak": round(step_flops / (ms_per_step * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
         "kernels": kernels,
     }
+
+
+def symbols_of(family):
+    """rocprofv3 name prefixes of the MFMA kernels a family's C-ABI calls launch"""
+    return {"conv_fwd": ["k_gemm_split", "k_conv_fwd_split", "k_conv_fwd<"], "conv_dgrad": ["k_gemm_split", "k_conv_dgrad_split", "k_conv_dgrad<"],
+            "conv_wgrad": ["k_conv_wgrad_split", "k_conv_wgrad<"]}.get(family, [])
+
+
+def profiled_mfma_util(prefixes):
+    """MFMA-pipe busy share (SQ_VALU_MFMA_BUSY_CYCLES / (SIMDs x kernel cycles)) of the family's MFMA kernels and of all
+    MFMA kernels of the step, from the committed PMC pass over this command (profiles/r01_pmc_mfma_util.json, written by
+    tools/pmc_mfma_util.py).  None when the file is missing."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_mfma_util.json")
+    try:
+        with open(path) as fh:
+            js = json.load(fh)
+    except (OSError, ValueError):
+        return None
+    ks = {k: round(v["mfma_util"], 4) for k, v in js["kernels"].items() if any(k.startswith(p) for p in prefixes)}
+    return {"kernels": ks, "all_mfma_kernels_of_the_step": round(js["conv_kernels_mfma_util"], 4),
+            "pipe": "bf16 MFMA (v_mfma_f32_32x32x16_bf16; the fp32-MFMA thin-layer kernels count their own cycles)",
+            "source": "profiles/r01_pmc_mfma_util.json (rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE over bench.py, one stream)"}
 
 
 def profiled_traffic(family, launches_per_step):
