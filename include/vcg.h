@@ -60,14 +60,21 @@ int vcg_nhwc_to_nchw(const float* src, float* dst, int N, int C, int H, int W, i
 int vcg_fill(float* dst, float value, size_t n, void* stream);
 
 /* nn.Conv2d(padding_mode='reflect') — Networks.py:60,87,101,104,122,136,145 -- */
-/* OIHW -> Wf[K][Cout], K ordered (kh,kw,i,j,c) so PixelUnshuffle (Networks.py:86)
-   needs no data movement; for the 3x3 / stride-1 layers the buffer continues with the
-   Winograd F(2x2,3x3) transform U[16][(i,j,c)][Cout] that vcg_conv_fwd multiplies with.
+/* OIHW -> the packed buffer every conv entry point below takes as `wf` (repacked once per optimizer step):
+     Wf[K][Cout]          K ordered (kh,kw,i,j,c), so PixelUnshuffle (Networks.py:86) needs no data movement;
+                          the B operand of the data-gradient and weight-gradient GEMMs
+     U, Ud[16][..]        3x3 / stride-1 layers: the Winograd F(2x2,3x3) transforms G g G^T of the kernel (forward,
+                          [xi][Cout][K]) and of the flipped kernel (data gradient, [xi][K][Cout])
+     Wk, Wkd              7x7 layers with <= 4 channels on one side: kw folded into the GEMM's N (forward / data gradient)
+     WfT[Cout][K]         the transpose of Wf: B^T operand of the split-operand forward kernel
    vcg_pack_weight_floats: floats the caller must provide for `wf` (spatial fields of cd are ignored). */
 size_t vcg_pack_weight_floats(const int32_t* cd);
 int vcg_pack_weight(const float* w_oihw, float* wf, const int32_t* cd, void* stream);
-/* y = act(conv(x) + bias): implicit GEMM on v_mfma_f32_32x32x2_f32.  Layers with few output
-   tiles slice K across workgroups into fp32 slabs in `ws` (vcg_conv_fwd_workspace bytes, may be 0). */
+/* y = act(conv(x) + bias).  fp32 in, fp32 out, fp32 accumulate; the GEMMs run on the bf16 matrix pipe
+   (v_mfma_f32_32x32x16_bf16) with every fp32 operand split into three bf16 pieces and six products per
+   multiply-add (fp32-level rounding, csrc/gemm_split.hip); thin layers use v_mfma_f32_32x32x2_f32.
+   3x3 / stride-1 layers go through Winograd F(2x2,3x3) (16 batched GEMMs, V and M in `ws`); layers with few
+   output tiles slice K across workgroups into fp32 slabs in `ws` (vcg_conv_fwd_workspace bytes, may be 0). */
 size_t vcg_conv_fwd_workspace(const int32_t* cd);
 int vcg_conv_fwd(const float* x, const float* wf, const float* bias, float* y,
                  const int32_t* cd, void* ws, size_t ws_bytes, void* stream);

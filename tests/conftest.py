@@ -80,6 +80,23 @@ def single_gan_golden():
 
 
 @pytest.fixture(scope="session")
+def vae1024_golden():
+    """(arrays, metric dicts) of the reference's VariationalAutoencoder(latent_dim=1024) step and validation at 64x64
+    (BASELINE.json configs[2]'s architecture; make_golden.py vae1024)."""
+    with open(os.path.join(GOLDEN, "vae1024_meta.json")) as f:
+        meta = json.load(f)
+    return dict(np.load(os.path.join(GOLDEN, "vae1024.npz"))), meta
+
+
+@pytest.fixture(scope="session")
+def train_epoch_golden():
+    """(arrays, meta) of the reference's own train_epoch (train.py:80-128) on two synthetic batches (make_golden.py train_epoch)."""
+    with open(os.path.join(GOLDEN, "train_epoch_meta.json")) as f:
+        meta = json.load(f)
+    return dict(np.load(os.path.join(GOLDEN, "train_epoch.npz"))), meta
+
+
+@pytest.fixture(scope="session")
 def steps_meta():
     with open(os.path.join(GOLDEN, "steps_meta.json")) as f:
         return json.load(f)
@@ -149,27 +166,45 @@ def assert_checksum(t, ck, what, tol=RTOL):
         raise AssertionError(f"{what}: sampled elements differ by {err:.3e} = {err / ref:.2e} of their scale")
 
 
-FLIP_BUDGET = 3e-2
+FLIP_BUDGET = 1e-2
+
+# every deep-step gradient comparison is appended here as (fixture key, tensor, ours / ||g||, reference fp32 / ||g||,
+# bound / ||g||); VCG_GRAD_ERROR_LOG=<file> writes the table at the end of the session (profiles/r02_grad_error.txt)
+GRAD_ERROR_LOG = []
 
 
-def assert_grad_checksum(g, ck32, ck64, what, tol=RTOL, flip=FLIP_BUDGET, got=None):
+def pytest_sessionfinish(session, exitstatus):
+    path = os.environ.get("VCG_GRAD_ERROR_LOG")
+    if path and GRAD_ERROR_LOG:
+        with open(path, "w") as f:
+            f.write("# error of each weight gradient against the reference's float64 gradient, along 8 fixed random projections,\n"
+                    "# relative to ||g64||: this build | the reference's own fp32 run | bound = max(4e-3, 4 x reference, 1e-2)\n")
+            for key, name, mine, ref, bound in GRAD_ERROR_LOG:
+                f.write(f"{key:22s} {name:58s} {mine:9.2e} {ref:9.2e} {bound:9.2e}\n")
+
+
+def assert_grad_checksum(g, ck32, ck64, what, tol=RTOL, flip=FLIP_BUDGET, got=None, key=""):
     """Gradient parity calibrated by the reference itself.  ck64 is the reference's float64 gradient
     (the exact value), ck32 its float32 one.  E_ref = ||proj(ck32) - proj(ck64)|| is the reference's
-    own fp32 error; ours must satisfy E <= max(4*tol*||g64||, 4*E_ref, flip*||g64||).
+    own fp32 error; ours must satisfy E <= max(4*tol*||g64||, 4*E_ref, flip*||g64||), flip = 1e-2.
 
     `flip` is the allowance for ReLU-mask flips: a pre-activation within fp32 rounding of zero gets
     relu'(.) = 1 in one fp32 implementation and 0 in another, which moves that element's gradient by its
     full magnitude.  Measured (tools/grad_error_profile.py, VAE 64x64): ONE flip among 65 536 elements of
     encoder.model.3 (fp64 pre-activation -8.6e-7, HIP +6.7e-6) lifts the gradient error of that layer and
     everything upstream from 4.6e-3 to 1.2e-2; without flips HIP sits at 3.3e-4 (AE), below the CPU fp32
-    path's 5.5e-4.  The same mechanism is the reference's own 1e-3 floor against fp64.  Real indexing or
-    formula bugs give O(0.1..1) and cannot hide under this allowance; atom-sized cases are held to 1e-4."""
+    path's 5.5e-4.  The same mechanism is the reference's own floor against fp64, which is why the bound
+    scales with E_ref: where the reference itself sits at 1e-2 (the GAN step) we may sit at 4e-2, where it
+    sits at 1e-3 the constant 1e-2 — one flipped element — is all the slack there is.  Real indexing or formula
+    bugs give O(0.1..1); a dropped loss term (lambda_kl dKL is ~10 % of a bottleneck gradient) no longer fits.
+    Atom-sized cases are held to 1e-4."""
     got = checksum(g) if got is None else got
     norm = max(ck64[1], 1e-30)
     p = slice(2, 2 + N_PROJ)
     e_ref = np.abs(ck32[p] - ck64[p]).max()
     e_mine = np.abs(got[p] - ck64[p]).max()
     bound = max(4 * tol * norm, 4 * e_ref, flip * norm)
+    GRAD_ERROR_LOG.append((key, what.replace("grad ", ""), e_mine / norm, e_ref / norm, bound / norm))
     if not e_mine <= bound:
         raise AssertionError(f"{what}: error vs fp64 truth {e_mine / norm:.2e} ||g|| exceeds bound {bound / norm:.2e} "
                              f"(reference's own fp32 error {e_ref / norm:.2e})")
@@ -177,22 +212,33 @@ def assert_grad_checksum(g, ck32, ck64, what, tol=RTOL, flip=FLIP_BUDGET, got=No
         raise AssertionError(f"{what}: L2 norm {got[1]:.6e} vs {ck64[1]:.6e}")
 
 
-def assert_param_after_step(t, ck, what, lr, nsteps=1, got=None):
-    """Post-step parameters.  Adam's early updates are ~sign(g)*lr per element, so an element whose
-    gradient is at rounding-noise level may legitimately move by +-lr in either implementation:
-    sampled elements get an absolute bound of 2.5*lr per step, the tensor norm a relative one.
-    (The well-conditioned check is on the gradients: assert_checksum on the gck.* fixtures.)"""
+def assert_param_after_step(t, ck, what, lr, nsteps=1, got=None, gck32=None, gck64=None):
+    """Post-step parameters.  The tensor norm gets a relative bound.  For the FIRST step the sampled elements are
+    checked through the update itself: Adam's first update is -lr * g / (|g| + eps) = -lr * sign(g) for every element
+    whose gradient is above rounding noise, so on the sampled elements where the reference's fp64 gradient exceeds 100x
+    its own fp32-vs-fp64 per-element noise, our parameter must equal the reference's to 0.05 lr (a wrong sign, a missed
+    update or a wrong lr / bias correction shows as >= 1 lr).  Elements below that threshold may legitimately move by
+    +-lr in either implementation and are only held to 2.5 lr.  Later snapshots (nsteps > 1) keep the loose bound."""
     got = checksum(t) if got is None else got
     if not abs(got[1] - ck[1]) <= 1e-3 * max(ck[1], 1e-30):
         raise AssertionError(f"{what}: L2 norm {got[1]:.6e} vs {ck[1]:.6e}")
-    err = np.abs(got[2 + N_PROJ:] - ck[2 + N_PROJ:]).max()
-    if not err <= 2.5 * lr * nsteps:
-        raise AssertionError(f"{what}: sampled parameters differ by {err:.3e} (> 2.5 lr)")
+    s0 = 2 + N_PROJ
+    diff = np.abs(got[s0:] - ck[s0:])
+    if not diff.max() <= 2.5 * lr * nsteps:
+        raise AssertionError(f"{what}: sampled parameters differ by {diff.max():.3e} (> 2.5 lr)")
+    if nsteps == 1 and gck32 is not None and gck64 is not None:
+        n = max(t2n(t).size, 1)
+        noise = max(np.abs(gck32[2:s0] - gck64[2:s0]).max(), 1e-30) / np.sqrt(n)      # per-element fp32 noise of the reference
+        solid = np.abs(gck64[s0:]) > 100.0 * noise
+        if solid.any() and not diff[solid].max() <= 0.05 * lr:
+            raise AssertionError(f"{what}: {int(solid.sum())} sampled elements have a gradient well above rounding noise, "
+                                 f"yet their update differs from the reference's by {diff[solid].max() / lr:.3f} lr")
+    return int(0 if gck64 is None else (np.abs(gck64[s0:]) > 100.0 * max(np.abs(gck32[2:s0] - gck64[2:s0]).max(), 1e-30)
+                                        / np.sqrt(max(t2n(t).size, 1))).sum())
 
 
-GAN_FLIP_BUDGET = 1e-1   # CycleVAEGAN: two chained VAEs + discriminators between the losses and G's parameters;
-#                          measured (tools/grad_error_profile_gan.py): HIP 2.8e-2 (G), 1.1e-2 (F), 1.9e-3 (D) vs fp64,
-#                          the reference's CPU fp32 numerics 0.9e-2, 1.0e-2, 1.9e-3 (and 0.77 on D's spectral-norm weight)
+GAN_FLIP_BUDGET = FLIP_BUDGET   # round 1 allowed 1e-1 on the GAN steps; the 4 x E_ref term already scales the bound with the
+#                                 reference's own fp32 error there (0.9e-2 .. 1e-2 on G and F, 0.77 on D's spectral-norm weight)
 
 
 def check_step_state(params, grads, key, golden, lr, snap="", tol=RTOL, nsteps=1, flip=FLIP_BUDGET):
@@ -204,15 +250,21 @@ def check_step_state(params, grads, key, golden, lr, snap="", tol=RTOL, nsteps=1
     # GIL, so they are computed on a few threads
     with ThreadPoolExecutor(max_workers=max(1, min(6, os.cpu_count() or 1))) as pool:
         sums = list(pool.map(lambda nv: checksum(nv[1]), pw + gw))
+    solid = 0
     for (n, v), got in zip(pw, sums[:len(pw)]):
         try:
-            assert_param_after_step(v, golden[f"{key}{snap}/ck.{n}"], n, lr, nsteps, got=got)
+            g32, g64 = golden.get(f"{key}{snap}/gck.{n}"), golden.get(f"{key}{snap}/gck64.{n}")
+            if in_cancelled_bias(n) or grads is None:
+                g32 = g64 = None
+            solid += assert_param_after_step(v, golden[f"{key}{snap}/ck.{n}"], n, lr, nsteps, got=got, gck32=g32, gck64=g64) or 0
         except AssertionError as e:
             bad.append(str(e))
+    if grads is not None and nsteps == 1 and len(pw) > 4:
+        assert solid >= len(pw), f"{key}: the update check looked at only {solid} sampled elements over {len(pw)} tensors"
     for (n, g), got in zip(gw, sums[len(pw):]):
         try:
             assert_grad_checksum(g, golden[f"{key}{snap}/gck.{n}"], golden[f"{key}{snap}/gck64.{n}"], "grad " + n, tol=tol, flip=flip,
-                                 got=got)
+                                 got=got, key=key)
         except AssertionError as e:
             bad.append(str(e))
     assert not bad, f"{len(bad)} tensors off:\n" + "\n".join(b[:300] for b in bad[:8])

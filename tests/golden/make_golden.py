@@ -7,7 +7,7 @@ recipe (seed + names; the tensors are rebuilt by synth) and the reference's OUTP
 tensors for atom-sized cases, metric dicts, strided slices and per-tensor checksums for the
 full-size training steps.
 
-    python tests/golden/make_golden.py [atoms] [steps] [validation] [checkpoint]      # writes atoms.npz, steps.npz, validation.npz next to this file
+    python tests/golden/make_golden.py [atoms] [steps] [validation] [cycleaegan] ... [vae1024] [train_epoch] [checkpoint]      # writes atoms.npz, steps.npz, validation.npz next to this file
 """
 import importlib
 import json
@@ -409,6 +409,81 @@ def gen_single_gan(N, out, meta):
         print(key, meta[key], meta[key + "/validation"])
 
 
+def gen_vae1024(N, out, meta):
+    """BASELINE.json configs[2] is `vae` with latent_dim 1024 (the reference CLI cannot reach it; the class can: Networks.py:856).
+    64x64, batch 2, ONE training step from synthetic parameters (fp32 + fp64 gradients) and the eval-mode validation
+    step: this is the only fixture in which the 1024 -> 1024 bare convs of the bottleneck (Networks.py:214-237) run."""
+    torch.set_num_threads(8)
+    key = "vae1024"
+    ctor = lambda: N.VariationalAutoencoder(latent_dim=1024)   # noqa: E731
+    model = ctor()
+    load_synth_params(model, SEED, 0.02, prefix=key + ".")
+    model.configure_optimizers(lr=LR)
+    model.configure_loss(**LAMBDAS)
+    model.eval()
+    x, y = (torch.from_numpy(a) for a in synth.batch(2, 64, SEED, step=7))
+    with EpsInjector(synth.eps_list(1, (2, 1024, 4, 4), SEED, step=7)):
+        m = model.validation_step({"x": x, "y": y})
+    out[key + "/val_Gx"] = m.pop("Gx")[:, :, ::4, ::4].numpy()
+    meta[key + "/validation"] = m
+    model.train()
+    x, _ = synth.batch(2, 64, SEED, step=0)
+    xb = torch.from_numpy(x)
+    eps = synth.eps_list(1, (2, 1024, 4, 4), SEED, step=0)
+    with torch.no_grad(), EpsInjector(eps):
+        o, mu, lv = model(xb)
+        out[key + "/out0"] = o[:, :, ::4, ::4].numpy()
+        out[key + "/mu0"], out[key + "/logvar0"] = mu[:, ::16].numpy(), lv[:, ::16].numpy()
+    with EpsInjector(eps):
+        meta[key] = [model.training_step({"x": xb, "y": xb})]
+    param_checksums(model, out, key + "@step1")
+    fp64_truth(ctor, key, {"x": xb, "y": xb}, eps, out)
+    print(key, meta[key], meta[key + "/validation"])
+
+
+def import_reference_train():
+    """/root/reference/train.py needs two more stubs than Networks.py: torch.utils.tensorboard (absent here) and the
+    torchvision names Data_Manager.py touches at import time (none: it only imports the module)."""
+    tb = types.ModuleType("torch.utils.tensorboard")
+    tb.SummaryWriter = object
+    sys.modules.setdefault("torch.utils.tensorboard", tb)
+    import_reference()
+    import train as ref_train  # noqa
+    return sys.modules["train"]
+
+
+def gen_train_epoch(N, out, meta):
+    """The reference's own `train_epoch` (train.py:80-128) on a list of two synthetic batches: the averaged metric tuple and
+    a slice of `last_output`.  Its extra train-mode forward per batch (:112-117) draws eps too, so the stream of the SECOND
+    batch's training_step starts after it: VAE eps order = step0, viz0, step1, viz1; CycleVAEGAN 6 + 6 per batch."""
+    import argparse
+    T = import_reference_train()
+    torch.set_num_threads(8)
+    args = argparse.Namespace()
+    for key, ctor, S, B, ne, xy in (("ae64", N.Autoencoder, 64, 2, 0, False),
+                                    ("vae64", lambda: N.VariationalAutoencoder(latent_dim=64), 64, 2, 1, False),
+                                    ("cvg256_unpaired", lambda: N.CycleVAEGAN(latent_dim=64, paired=False), 256, 1, 6, True)):
+        model = ctor()
+        load_synth_params(model, SEED, 0.02, prefix=key + ".")
+        model.configure_optimizers(lr=LR)
+        model.configure_loss(**LAMBDAS)
+        batches = []
+        for step in range(2):
+            x, y = synth.batch(B, S, SEED, step=step)
+            batches.append({"x": torch.from_numpy(x), "y": torch.from_numpy(y if xy else x)})
+        lat = (B, 64, S // 16, S // 16)
+        eps = synth.eps_list(4 * ne, lat, SEED, step=100)       # [batch 0: step, viz][batch 1: step, viz]
+        with EpsInjector(eps) as inj:
+            avg_loss, comps, last_output, last_x, last_y = T.train_epoch(model, batches, torch.device("cpu"), args)
+        assert inj.i == 4 * ne, (inj.i, ne)
+        st = 16 if S == 256 else 4
+        lo = last_output if last_output.dim() == 4 else last_output[None]      # Autoencoder: model(x)[0] is ONE image
+        out[f"{key}/last_output"] = lo[:, :, ::st, ::st].numpy()
+        meta[key] = {"avg_loss": avg_loss, "components": comps, "last_output_shape": list(last_output.shape),
+                     "eps_draws": inj.i}
+        print("train_epoch", key, meta[key])
+
+
 def gen_checkpoint_skeleton(N):
     """Structure of the checkpoints the REFERENCE writes (utils.py:17-28: torch.save of {epoch, model_state_dict,
     optimizer_states, loss, args}) after one training step: key names, shapes and dtypes of every tensor, the optimizer
@@ -452,7 +527,8 @@ def main():
     torch.manual_seed(0)
     atoms, steps, meta = {}, {}, {"seed": SEED, "lr": LR, "lambdas": LAMBDAS,
                                   "torch": torch.__version__, "reference": "Baverne/VAE-CYCLEGAN-Implementation"}
-    which = sys.argv[1:] or ["atoms", "steps", "validation", "cycleaegan", "cycle_nogan", "double", "single_gan", "checkpoint"]
+    which = sys.argv[1:] or ["atoms", "steps", "validation", "cycleaegan", "cycle_nogan", "double", "single_gan", "vae1024", "train_epoch",
+                                 "checkpoint"]
     if "atoms" in which:
         gen_atoms(N, atoms)
         np.savez_compressed(os.path.join(HERE, "atoms.npz"), **atoms)
@@ -491,12 +567,25 @@ def main():
         np.savez_compressed(os.path.join(HERE, "single_gan.npz"), **arr)
         with open(os.path.join(HERE, "single_gan_meta.json"), "w") as f:
             json.dump(cmeta, f, indent=1)
+    if "vae1024" in which:
+        arr, cmeta = {}, {"seed": SEED, "lr": LR, "lambdas": LAMBDAS, "torch": torch.__version__}
+        gen_vae1024(N, arr, cmeta)
+        np.savez_compressed(os.path.join(HERE, "vae1024.npz"), **arr)
+        with open(os.path.join(HERE, "vae1024_meta.json"), "w") as f:
+            json.dump(cmeta, f, indent=1)
+    if "train_epoch" in which:
+        arr, cmeta = {}, {"seed": SEED, "lr": LR, "lambdas": LAMBDAS, "torch": torch.__version__, "eps_stream_step": 100}
+        gen_train_epoch(N, arr, cmeta)
+        np.savez_compressed(os.path.join(HERE, "train_epoch.npz"), **arr)
+        with open(os.path.join(HERE, "train_epoch_meta.json"), "w") as f:
+            json.dump(cmeta, f, indent=1)
     if "checkpoint" in which:
         with open(os.path.join(HERE, "checkpoint_skeleton.json"), "w") as f:
             json.dump(gen_checkpoint_skeleton(N), f, indent=0)
     for fn in ("atoms.npz", "steps.npz", "steps_meta.json", "validation.npz", "validation_meta.json", "cycleaegan.npz",
                "cycleaegan_meta.json", "cycle_nogan.npz", "cycle_nogan_meta.json", "double.npz",
-               "double_meta.json", "single_gan.npz", "single_gan_meta.json", "checkpoint_skeleton.json"):
+               "double_meta.json", "single_gan.npz", "single_gan_meta.json", "vae1024.npz", "vae1024_meta.json", "train_epoch.npz",
+               "train_epoch_meta.json", "checkpoint_skeleton.json"):
         p = os.path.join(HERE, fn)
         if os.path.exists(p):
             print(fn, os.path.getsize(p), "bytes")

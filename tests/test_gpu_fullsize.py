@@ -1,5 +1,6 @@
-"""Every conv layer of the headline configuration (BASELINE.json configs[3]: CycleVAEGAN, batch 8, 3x256x256,
-latent 64) at its FULL size, through the C ABI.
+"""Every conv layer of the BASELINE.json configurations that run on one MI355X — configs[3] (CycleVAEGAN, batch 8, 3x256x256,
+latent 64: the headline), configs[1] (`ae`, batch 16) and configs[2] (`vae`, latent 1024, batch 16) — at its FULL size,
+through the C ABI.
 
 The CPU oracle cannot run these sizes in test time, so the three directions of each layer are pinned by properties
 that do not depend on the size (the shapes below take the Winograd, split-operand 128x128 / 128x64, stream-K,
@@ -19,8 +20,9 @@ import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
 
-B, S = 8, 256
+S = 256
 SEED = 20261003
+B = 8            # the D-block and loss-reduction tests below run at the headline batch
 
 # (name, logical conv cin, cout, k, stride, pad, ups, physical input channels, input H = W)
 LAYERS = [
@@ -44,6 +46,13 @@ LAYERS = [
     ("discriminator 256->512 k4 s2", 256, 512, 4, 2, 1, 1, 256, S // 8),
 ]
 
+# BASELINE.json configs[1] (`ae`, batch 16) and configs[2] (`vae` latent 1024, batch 16) run the same layers at twice the
+# pixel count — M doubles, so gemm_plan / wgrad_plan pick other tiles, split factors and stream-K runs — and latent 1024
+# adds the bare 1024 -> 1024 bottleneck convs (mu, logvar x2, latent -> 1024; Networks.py:214-237).  No discriminator there.
+AE_LAYERS = [l for l in LAYERS if not l[0].startswith(("discriminator", "mu /", "logvar", "latent"))]
+VAE1024_ONLY = [("bare 1024->1024 (latent 1024: mu / logvar / latent->1024)", 1024, 1024, 3, 1, 1, 1, 1024, S // 16)]
+CASES = ([(8, l) for l in LAYERS] + [(16, l) for l in AE_LAYERS] + [(16, l) for l in VAE1024_ONLY])
+
 Y_TOL = 2e-6        # rel. L2 over the sampled outputs: fp32 rounding of a K <= 18432 sum is ~3e-7
 DW_TOL = 4e-6       # sampled dw elements: sums over up to 524288 positions
 DOT_TOL = 2e-5      # inner-product identities, relative to ||a|| ||b|| / sqrt(n) (the size of a random inner product)
@@ -57,12 +66,12 @@ def _scale(a, b):
     return (a.double().norm() * b.double().norm()).item() / a.numel() ** 0.5
 
 
-@pytest.mark.parametrize("layer", LAYERS, ids=[l[0] for l in LAYERS])
-def test_conv_layer_at_headline_size(layer, pkg, device):
+@pytest.mark.parametrize("B,layer", CASES, ids=[f"B{b} {l[0]}" for b, l in CASES])
+def test_conv_layer_at_headline_size(B, layer, pkg, device):
     name, cin, cout, k, stride, pad, ups, cphys, h = layer
     ops = pkg.ops
     gen = torch.Generator(device="cpu").manual_seed(SEED)
-    lid = LAYERS.index(layer)
+    lid = (LAYERS + VAE1024_ONLY).index(layer) + (100 if B != 8 else 0)
     x = ops.randn((B, cphys, h, h), device, seed=SEED, offset=lid << 32)               # NCHW, the reference's layout
     w = ops.randn((cout, cin, k, k), device, seed=SEED + 1, offset=lid << 32) * (2.0 / (k * k * cout)) ** 0.5
     b = ops.randn((cout,), device, seed=SEED + 2, offset=lid << 32) * 0.1

@@ -15,6 +15,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "gol
 from cases import ATOM_BIAS_STD, ATOM_CASES, DISC_BIAS_STD, LAMBDAS, LR, STEP_BIAS_STD  # noqa: E402
 
 pytestmark = pytest.mark.gpu
+VAL_STEP = 7          # synth batch / eps stream index the validation fixtures were made with
 
 
 def load_synth(pkg, module, key, bias_std, seed=SEED):
@@ -270,6 +271,63 @@ def test_fused_adam_matches_oracle_formula(pkg, oracle, device):
     assert set(ref.state_dict()["param_groups"][0]) <= set(st["param_groups"][0])
 
 
+def test_fused_adam_matches_torch_optim_adam(pkg, device):
+    """k_adam against torch.optim.Adam itself (third-party, the optimizer the reference constructs at Networks.py:312, 894,
+    1928-1935: lr 2e-4, betas (0.5, 0.999), eps 1e-8), run on the CPU inside this test: five steps with gradients of mixed
+    scale (some elements at 1e-9, where eps matters), parameters and both moment buffers compared after every step."""
+    shapes = {"a.weight": (16, 8, 3, 3), "a.bias": (16,), "b.weight": (5, 16, 1, 1), "c.bias": (3,)}
+    sd = pkg.synth.state_dict_like(shapes, SEED + 11, bias_std=0.1)
+    mine = [torch.nn.Parameter(torch.from_numpy(v).to(device)) for v in sd.values()]
+    ref = [torch.nn.Parameter(torch.from_numpy(v).clone()) for v in sd.values()]
+    opt = pkg.optim.FusedAdam(mine, lr=LR, betas=(0.5, 0.999))
+    topt = torch.optim.Adam(ref, lr=LR, betas=(0.5, 0.999))
+    for step in range(5):
+        opt.zero_grad()
+        for p, r, (k, shp) in zip(mine, ref, shapes.items()):
+            g = torch.from_numpy(pkg.synth.normal(shp, SEED, f"adam-t/{step}/{k}"))
+            g = g * torch.from_numpy(10.0 ** (-9.0 * pkg.synth.uniform(shp, SEED, f"adam-s/{step}/{k}")))   # 1 .. 1e-9
+            p.grad.copy_(g.to(device))
+            r.grad = g.clone()
+        opt.step()
+        topt.step()
+        st = opt.state_dict()["state"]
+        for i, (p, r, k) in enumerate(zip(mine, ref, shapes)):
+            assert_close(p.detach(), r.detach(), f"step {step} {k}", l2=1e-6, mx=2e-6)
+            assert_close(st[i]["exp_avg"], topt.state[r]["exp_avg"], f"step {step} {k} exp_avg", l2=1e-6, mx=2e-6)
+            assert_close(st[i]["exp_avg_sq"], topt.state[r]["exp_avg_sq"], f"step {step} {k} exp_avg_sq", l2=1e-6, mx=2e-6)
+            assert float(st[i]["step"]) == float(topt.state[r]["step"]) == step + 1
+    # the two state_dicts are interchangeable: torch's loads ours and continues identically for one more step
+    topt2 = torch.optim.Adam([torch.nn.Parameter(p.detach().cpu().clone()) for p in mine], lr=LR, betas=(0.5, 0.999))
+    topt2.load_state_dict(pkg.utils._to_cpu(opt.state_dict()))
+    assert all(float(v["step"]) == 5.0 for v in topt2.state_dict()["state"].values())
+
+
+def test_autoencoder_nan_guard_skips_the_update(pkg, device):
+    """reference Networks.py:357-372: a NaN / Inf loss returns {'nan_detected': True, ...NaN} WITHOUT touching the parameters
+    or the optimizer state, and the next clean batch trains normally."""
+    model = pkg.Networks.Autoencoder()
+    load_synth(pkg, model, "nan", STEP_BIAS_STD)
+    model = model.to(device).train()
+    model.configure_optimizers(lr=LR)
+    model.configure_loss(**LAMBDAS)
+    x, _ = pkg.synth.batch(2, 64, SEED, step=3)
+    xb = torch.from_numpy(x).to(device)
+    bad = xb.clone()
+    bad[1, 2, 5, 7] = float("nan")
+    before = model.optimizer.flat_param.clone()
+    m = model.training_step({"x": bad, "y": bad})
+    assert m["nan_detected"] is True and all(v != v for k, v in m.items() if k != "nan_detected")
+    assert list(m) == ["nan_detected", "G_loss", "loss_trans", "total_loss"]
+    assert torch.equal(before, model.optimizer.flat_param) and model.optimizer.step_count == 0
+    assert model.optimizer.flat_grad.abs().max().item() == 0.0
+    inf = xb.clone()
+    inf[0, 0, 0, 0] = float("inf")
+    assert model.training_step({"x": inf, "y": xb})["nan_detected"] is True and model.optimizer.step_count == 0
+    m = model.training_step({"x": xb, "y": xb})
+    assert "nan_detected" not in m and m["G_loss"] == m["G_loss"] and model.optimizer.step_count == 1
+    assert not torch.equal(before, model.optimizer.flat_param)
+
+
 # ------------------------------------------------------------------ training steps vs the reference's own numbers
 def _check_metrics(got, ref, what, tol=1e-3):
     assert list(got) == list(ref), f"{what}: metric keys/order {list(got)} vs {list(ref)}"
@@ -328,6 +386,38 @@ def test_vae_steps_match_reference_golden(pkg, device, steps_golden, steps_meta)
             _check_state(model, key, steps_golden)
 
 
+def test_vae_latent1024_step_and_validation_match_reference_golden(pkg, device, vae1024_golden):
+    """BASELINE.json configs[2]'s architecture, `vae` with latent_dim 1024: the bottleneck's bare 1024 -> 1024 convs
+    (reference Networks.py:214-237) against the reference's own step (fp32 metrics, outputs, fp64-calibrated gradients)."""
+    arrays, meta = vae1024_golden
+    key = "vae1024"
+    model = pkg.Networks.VariationalAutoencoder(latent_dim=1024)
+    load_synth(pkg, model, key, STEP_BIAS_STD)
+    model = model.to(device)
+    model.configure_optimizers(lr=LR)
+    model.configure_loss(**LAMBDAS)
+    model.eval()
+    x, y = (torch.from_numpy(a).to(device) for a in pkg.synth.batch(2, 64, SEED, step=VAL_STEP))
+    pkg.ops.inject_eps([torch.from_numpy(e) for e in pkg.synth.eps_list(1, (2, 1024, 4, 4), SEED, step=VAL_STEP)])
+    m = model.validation_step({"x": x, "y": y})
+    assert_close(nchw(m.pop("Gx"))[:, :, ::4, ::4], arrays[key + "/val_Gx"], "val Gx", l2=1e-3)
+    _check_metrics(m, meta[key + "/validation"], f"{key} validation")
+    model.train()
+    x, _ = pkg.synth.batch(2, 64, SEED, step=0)
+    xb = torch.from_numpy(x).to(device)
+    eps = [torch.from_numpy(e) for e in pkg.synth.eps_list(1, (2, 1024, 4, 4), SEED, step=0)]
+    with torch.no_grad():
+        pkg.ops.inject_eps(eps)
+        o, mu, lv = model(xb)
+    assert_close(nchw(o)[:, :, ::4, ::4], arrays[key + "/out0"], "VAE-1024 out", l2=1e-3)
+    assert_close(nchw(mu)[:, ::16], arrays[key + "/mu0"], "mu", l2=1e-3)
+    assert_close(nchw(lv)[:, ::16], arrays[key + "/logvar0"], "logvar", l2=1e-3)
+    pkg.ops.inject_eps(eps)
+    m = model.training_step({"x": xb, "y": xb})
+    _check_metrics(m, meta[key][0], f"{key} step 0")
+    _check_state(model, key, arrays)
+
+
 def test_side_stream_changes_no_bit(pkg, device):
     """The weight-gradient side stream and the ahead-of-time weight repack only reorder launches across streams: two
     CycleVAEGAN steps from the same state must give bit-identical metrics, gradients and parameters with the overlap
@@ -383,6 +473,67 @@ def test_cyclevaegan_step_matches_reference_golden(key, paired, pkg, device, ste
     m = model.training_step({"x": xb, "y": yb})
     _check_metrics(m, steps_meta[key][0], f"{key} step 0")
     _check_state(model, key, steps_golden, flip=GAN_FLIP_BUDGET)
+    if len(steps_meta[key]) > 1:
+        # the fixture's SECOND step: both optimizers hand over their state (Adam moments, step counters, the packs keyed
+        # on each optimizer's own epoch) and the spectral-norm vectors carry on.  GAN dynamics amplify rounding step over
+        # step (D_loss 1.4 -> 261 -> 29), so the bound is the 2e-2 the CPU oracle test uses for it
+        x, y = pkg.synth.batch(1, 256, SEED, step=1)
+        pkg.ops.inject_eps([torch.from_numpy(e) for e in pkg.synth.eps_list(6, (1, 64, 16, 16), SEED, step=1)])
+        m = model.training_step({"x": torch.from_numpy(x).to(device), "y": torch.from_numpy(y).to(device)})
+        _check_metrics(m, steps_meta[key][1], f"{key} step 1", tol=2e-2)
+        assert model.optimizer_G.step_count == 2 and model.optimizer_D.step_count == 2
+        params = {n: v for n, v in model.state_dict().items()}
+        check_step_state(params, None, key, steps_golden, LR, nsteps=2)
+
+
+@pytest.mark.parametrize("key", ["ae64", "vae64", "cvg256_unpaired"])
+def test_train_epoch_matches_the_reference_train_epoch(key, pkg, device, train_epoch_golden):
+    """the reference's own `train_epoch` (train.py:80-128) on two synthetic batches — the averaged metric
+    tuple and `last_output`.  With --reference_viz_forward ours reproduces the extra train-mode forward per batch
+    (:112-117), which draws eps (and runs the spectral-norm power iteration) between two training steps: without it the
+    second step would consume the wrong eps tensors and the averages below would not match."""
+    import importlib
+    arrays, meta = train_epoch_golden
+    train = importlib.import_module("vae-cyclegan-implementation_amd.train")
+    ctor, S, B, ne, xy = {"ae64": (pkg.Networks.Autoencoder, 64, 2, 0, False),
+                          "vae64": (lambda: pkg.Networks.VariationalAutoencoder(latent_dim=64), 64, 2, 1, False),
+                          "cvg256_unpaired": (lambda: pkg.Networks.CycleVAEGAN(latent_dim=64, paired=False), 256, 1, 6, True)}[key]
+    model = ctor()
+    load_synth(pkg, model, key, STEP_BIAS_STD)
+    model = model.to(device)
+    model.configure_optimizers(lr=LR)
+    model.configure_loss(**LAMBDAS)
+    batches = []
+    for step in range(2):
+        x, y = pkg.synth.batch(B, S, SEED, step=step)
+        batches.append({"x": torch.from_numpy(x), "y": torch.from_numpy(y if xy else x)})
+    pkg.ops.inject_eps([torch.from_numpy(e) for e in pkg.synth.eps_list(4 * ne, (B, 64, S // 16, S // 16), SEED, step=100)])
+    args = type("A", (), {"reference_viz_forward": True})()
+    avg, comps, last_output, last_x, last_y = train.train_epoch(model, batches, device, args)
+    assert not pkg.ops._EPS_QUEUE, "train_epoch consumed fewer eps draws than the reference's"
+    ref = meta[key]
+    tol = 2e-2 if key.startswith("cvg") else 1e-3          # the GAN's second step amplifies rounding (SURVEY.md §7)
+    assert list(comps) == list(ref["components"])
+    assert abs(avg - ref["avg_loss"]) <= tol * abs(ref["avg_loss"])
+    for k, v in ref["components"].items():
+        assert abs(comps[k] - v) <= tol * max(abs(v), 1e-6), f"{key}: averaged {k} = {comps[k]!r}, reference {v!r}"
+    assert list(last_output.shape) == ref["last_output_shape"]          # Autoencoder: model(x)[0] is ONE image (:114)
+    lo = nchw(last_output if last_output.dim() == 4 else last_output[None])
+    st = 16 if S == 256 else 4
+    assert_close(lo[:, :, ::st, ::st], arrays[key + "/last_output"], "last_output", l2=5e-2 if key.startswith("cvg") else 2e-3, mx=1e-1)
+    assert last_x.device.type == "cuda" and tuple(last_x.shape) == (B, 3, S, S)
+    # and without the flag the second step sees other eps: the averages must move (the fixture pins the reference's order)
+    if ne:
+        model2 = ctor()
+        load_synth(pkg, model2, key, STEP_BIAS_STD)
+        model2 = model2.to(device)
+        model2.configure_optimizers(lr=LR)
+        model2.configure_loss(**LAMBDAS)
+        pkg.ops.inject_eps([torch.from_numpy(e) for e in pkg.synth.eps_list(4 * ne, (B, 64, S // 16, S // 16), SEED, step=100)])
+        _, comps2, out2, _, _ = train.train_epoch(model2, batches, device, type("A", (), {"reference_viz_forward": False})())
+        pkg.ops.inject_eps([])
+        assert out2 is None
+        assert abs(comps2["loss_kl"] - ref["components"]["loss_kl"]) > 1e-3 * abs(ref["components"]["loss_kl"])
 
 
 def test_cyclevaegan_unconfigured_raises_like_the_reference(pkg, device):
@@ -397,7 +548,6 @@ def test_cyclevaegan_unconfigured_raises_like_the_reference(pkg, device):
 
 
 # ------------------------------------------------------------------ validation_step under model.eval()
-VAL_STEP = 7
 
 
 def test_ae_and_vae_validation_match_reference_golden(pkg, device, validation_golden):
@@ -487,20 +637,21 @@ def test_checkpoint_has_the_reference_format_and_resumes_bit_identically(arch, p
     ck = torch.load(fn, map_location="cpu", weights_only=False)
     got = _describe(ck)
     got["loss"]["value"] = None
-    assert list(got) == list(skel)
+    assert list(got)[:len(skel)] == list(skel)                      # the reference's five keys, in its order ...
+    assert set(list(got)[len(skel):]) <= {"vcg_eps_rng", "vcg_best_test_loss"}   # ... then ours (its loader ignores them)
     assert got["model_state_dict"] == skel["model_state_dict"]
     assert got["optimizer_states"] == skel["optimizer_states"]
     assert got["epoch"] == skel["epoch"] and got["args"] == skel["args"] and got["loss"]["py"] == skel["loss"]["py"]
 
-    pkg.ops.manual_seed(123)                       # same eps stream for both continuations
-    m1 = a.training_step(batch(1))
+    m1 = a.training_step(batch(1))                 # the uninterrupted run: the eps stream simply continues
     b = make()
     with torch.no_grad():                          # different values until the checkpoint is loaded
         for p in b.parameters():
             p.mul_(0.5)
+    pkg.ops.manual_seed(4242)                      # ... and another eps stream: the checkpoint restores the saved one
     epoch, loss = pkg.utils.load_checkpoint(b, fn, device)
     assert epoch == 3 and loss == m0["G_loss"]
-    pkg.ops.manual_seed(123)
+    assert pkg.ops._RNG["seed"] == 99 and pkg.utils.LAST_EXTRAS == {}
     m1b = b.training_step(batch(1))
     assert m1b == m1, f"resumed step differs: {m1b} vs {m1}"
     sa, sb = a.state_dict(), b.state_dict()

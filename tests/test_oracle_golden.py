@@ -152,6 +152,9 @@ def test_oracle_discriminator_matches_reference(pkg, oracle, atoms_golden):
     assert_checksum(sn[name + ".model.4.weight_v"], atoms_golden[name + "/v_ck"], "v", tol=1e-5)
 
 
+VAL_STEP = 7          # synth batch / eps stream index the validation fixtures were made with
+
+
 # ------------------------------------------------------------------------------------- steps
 def _model_shapes(pkg, key, ctor):
     model = ctor()
@@ -204,6 +207,30 @@ def test_oracle_vae_steps_match_reference(pkg, oracle, steps_golden, steps_meta)
     check_step_state(P, None, key, steps_golden, LR, nsteps=2)
 
 
+def test_oracle_vae_latent1024_step_and_validation_match_reference(pkg, oracle, vae1024_golden):
+    """BASELINE.json configs[2]'s architecture (latent_dim 1024: 1024 -> 1024 bare convs for mu, logvar x2 and latent -> 1024)."""
+    arrays, meta = vae1024_golden
+    key = "vae1024"
+    P = _params(pkg, _model_shapes(pkg, key, lambda: pkg.Networks.VariationalAutoencoder(1024)), STEP_BIAS_STD)
+    P = {k[len(key) + 1:]: v for k, v in P.items()}
+    x, y = (torch.from_numpy(a) for a in pkg.synth.batch(2, 64, SEED, step=VAL_STEP))
+    eps = torch.from_numpy(pkg.synth.eps_list(1, (2, 1024, 4, 4), SEED, step=VAL_STEP)[0])
+    m, o = oracle.vae_validation(P, x, y, eps, LAMBDAS["lambda_kl"])
+    _check_metrics(m, meta[key + "/validation"], f"{key} validation", tol=1e-4)
+    assert_close(o["Gx"][:, :, ::4, ::4], arrays[key + "/val_Gx"], "val Gx", l2=1e-4, mx=1e-3)
+    x, _ = pkg.synth.batch(2, 64, SEED, step=0)
+    xb = torch.from_numpy(x)
+    eps = torch.from_numpy(pkg.synth.eps_list(1, (2, 1024, 4, 4), SEED, step=0)[0])
+    with torch.no_grad():
+        o, mu, lv = oracle.vae_forward(xb, P, "", eps)
+    assert_close(o[:, :, ::4, ::4], arrays[key + "/out0"], "VAE-1024 out", l2=1e-4, mx=1e-3)
+    assert_close(mu[:, ::16], arrays[key + "/mu0"], "mu", l2=1e-4, mx=1e-3)
+    assert_close(lv[:, ::16], arrays[key + "/logvar0"], "logvar", l2=1e-4, mx=1e-3)
+    m, _, grads = oracle.vae_step(P, {}, xb, xb, eps, LR, LAMBDAS["lambda_kl"])
+    _check_metrics(m, meta[key][0], f"{key} step 0", tol=1e-4)
+    check_step_state(P, grads, key, arrays, LR, snap="@step1", tol=1e-3)
+
+
 # (the unpaired fixture holds a second step; the CPU suite stops after the first — multi-step carry of the Adam state is
 # covered at 64x64 by the autoencoder / VAE tests above, and each 256x256 step costs the oracle ~30 s)
 @pytest.mark.parametrize("key,paired,nsteps", [("cvg256_unpaired", False, 1), ("cvg256_paired", True, 1)])
@@ -231,7 +258,6 @@ def test_oracle_cyclevaegan_steps_match_reference(key, paired, nsteps, pkg, orac
 
 
 # ------------------------------------------------------------------ validation_step in eval mode
-VAL_STEP = 7          # synth batch / eps stream index the validation fixtures were made with
 
 
 def test_oracle_ae_and_vae_validation_match_reference(pkg, oracle, validation_golden):

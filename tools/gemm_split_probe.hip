@@ -1,6 +1,6 @@
 // Diagnostic: accuracy (against float64) and speed of the split-operand bf16 GEMM next to the fp32-MFMA GEMM the
-// Winograd layers use.  Build: C=vae-cyclegan-implementation_amd/csrc; hipcc --offload-arch=gfx950 -O3 -std=c++17 \
-//   -o tools/_build/gemm_split_probe tools/gemm_split_probe.hip $C/conv_igemm.hip $C/conv_thin.hip $C/conv_wino.hip $C/gemm_split.hip $C/norm.hip $C/misc.hip
+// Winograd layers use.  Build: C=vae-cyclegan-implementation_amd/csrc; hipcc --offload-arch=gfx950 -O3 -std=c++17 -DVCG_PP_STAMP \
+//   -o tools/_build/gemm_split_probe tools/gemm_split_probe.hip $C/conv_igemm.hip $C/conv_thin.hip $C/conv_wino.hip $C/gemm_split.hip $C/gemm_pp.hip $C/norm.hip $C/misc.hip
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdio.h>
@@ -9,7 +9,27 @@
 
 int vcg_gemm_split_batched(const float* A, const float* Bt, float* C, int rows, int K, int N, int batches, hipStream_t st);
 int vcg_gemm_batched(const float* A, const float* B, float* C, int rows, int K, int Ncols, int batches, hipStream_t st);
+int vcg_gemm_pp_batched(const float* A, const float* Bt, float* C, int rows, int K, int N, int batches, hipStream_t st);
 extern "C" const char* vcg_last_error();
+
+int vcg_pp_set_stamp(void* buf);
+static void stamps(const float* A, const float* Bt, float* C3, int rows, int K, int N, int batches) {
+  const int wgs = ((rows + 255) / 256) * (N / 128) * batches;
+  unsigned long long* d; hipMalloc(&d, (size_t)wgs * 8 * 4 * 8); hipMemset(d, 0, (size_t)wgs * 8 * 4 * 8);
+  vcg_pp_set_stamp(d);
+  for (int r = 0; r < 3; ++r) vcg_gemm_pp_batched(A, Bt, C3, rows, K, N, batches, 0);
+  hipDeviceSynchronize();
+  vcg_pp_set_stamp(nullptr);
+  std::vector<unsigned long long> h((size_t)wgs * 8 * 4);
+  hipMemcpy(h.data(), d, h.size() * 8, hipMemcpyDeviceToHost);
+  double s[2][4] = {};
+  for (int w = 0; w < wgs; ++w) for (int v = 0; v < 8; ++v) for (int q = 0; q < 4; ++q) s[v >= 4][q] += (double)h[((size_t)w * 8 + v) * 4 + q];
+  const double nk = (K + 31) / 32, cnt = (double)wgs * 4;
+  for (int g = 0; g < 2; ++g)
+    printf("   stamps %s waves: per K-step  matrix phase %7.0f  split+store(+load issue) %7.0f  barrier wait %7.0f  | whole kernel %8.0f shader clocks (%d K-steps)\n",
+           g ? "late (4-7) " : "early (0-3)", s[g][0] / cnt / nk, s[g][1] / cnt / nk, s[g][2] / cnt / nk, s[g][3] / cnt, (int)nk);
+  hipFree(d);
+}
 
 static void run(int rows, int K, int N, int batches) {
   const size_t na = (size_t)batches * rows * K, nb = (size_t)batches * N * K, nc = (size_t)batches * rows * N;
@@ -20,8 +40,9 @@ static void run(int rows, int K, int N, int batches) {
   for (size_t z = 0; z < (size_t)batches; ++z)
     for (int n = 0; n < N; ++n)
       for (int k = 0; k < K; ++k) { float v = rnd(); hbt[(z * N + n) * K + k] = v; hb[(z * K + k) * N + n] = v; }
-  float *A, *Bt, *B, *C, *C2;
-  hipMalloc(&A, na * 4); hipMalloc(&Bt, nb * 4); hipMalloc(&B, nb * 4); hipMalloc(&C, nc * 4); hipMalloc(&C2, nc * 4);
+  float *A, *Bt, *B, *C, *C2, *C3;
+  hipMalloc(&A, na * 4); hipMalloc(&Bt, nb * 4); hipMalloc(&B, nb * 4); hipMalloc(&C, nc * 4); hipMalloc(&C2, nc * 4); hipMalloc(&C3, nc * 4);
+  hipMemset(C3, 0, nc * 4);
   hipMemcpy(A, ha.data(), na * 4, hipMemcpyHostToDevice);
   hipMemcpy(Bt, hbt.data(), nb * 4, hipMemcpyHostToDevice);
   hipMemcpy(B, hb.data(), nb * 4, hipMemcpyHostToDevice);
@@ -39,7 +60,28 @@ static void run(int rows, int K, int N, int batches) {
   hipEventRecord(e0, 0);
   for (int r = 0; r < reps; ++r) vcg_gemm_batched(A, B, C2, rows, K, N, batches, 0);
   hipEventRecord(e1, 0); hipEventSynchronize(e1); hipEventElapsedTime(&ms_f32, e0, e1);
-  std::vector<float> hc(nc), hc2(nc);
+  float ms_pp = 0;
+  const bool pp = N % 128 == 0;
+  if (pp) {
+    for (int w = 0; w < 2; ++w) if (vcg_gemm_pp_batched(A, Bt, C3, rows, K, N, batches, 0)) { printf("pp failed: %s\n", vcg_last_error()); return; }
+    hipDeviceSynchronize();
+    for (int round = 0; round < 3; ++round) {          // interleaved rounds: split, pp, split, pp ...
+      float a = 0, b = 0;
+      hipEventRecord(e0, 0);
+      for (int r = 0; r < reps; ++r) vcg_gemm_split_batched(A, Bt, C, rows, K, N, batches, 0);
+      hipEventRecord(e1, 0); hipEventSynchronize(e1); hipEventElapsedTime(&a, e0, e1);
+      hipEventRecord(e0, 0);
+      for (int r = 0; r < reps; ++r) vcg_gemm_pp_batched(A, Bt, C3, rows, K, N, batches, 0);
+      hipEventRecord(e1, 0); hipEventSynchronize(e1); hipEventElapsedTime(&b, e0, e1);
+      printf("   round %d: split %8.1f us   ping-pong %8.1f us\n", round, a * 1e3 / reps, b * 1e3 / reps);
+      ms_pp = b;
+    }
+  }
+  if (pp) stamps(A, Bt, C3, rows, K, N, batches);
+  std::vector<float> hc(nc), hc2(nc), hc3(nc);
+  hipMemcpy(hc3.data(), C3, nc * 4, hipMemcpyDeviceToHost);
+  double e_pp = 0, maxdiff = 0;
+  if (pp) for (size_t i = 0; i < nc; ++i) { }
   hipMemcpy(hc.data(), C, nc * 4, hipMemcpyDeviceToHost);
   hipMemcpy(hc2.data(), C2, nc * 4, hipMemcpyDeviceToHost);
   double e_split = 0, e_f32 = 0, nrm = 0;
@@ -51,12 +93,17 @@ static void run(int rows, int K, int N, int batches) {
     for (int k = 0; k < K; ++k) ref += (double)ha[(z * rows + m) * K + k] * hbt[(z * N + n) * K + k];
     const size_t ci = (z * rows + m) * N + n;
     e_split += (hc[ci] - ref) * (hc[ci] - ref); e_f32 += (hc2[ci] - ref) * (hc2[ci] - ref); nrm += ref * ref;
+    e_pp += (hc3[ci] - ref) * (hc3[ci] - ref);
   }
+  size_t nbad = 0;
+  if (pp) for (size_t i = 0; i < nc; ++i) { const double d = fabs((double)hc3[i] - hc[i]); if (d > maxdiff) maxdiff = d; if (!(d <= 1e-3)) ++nbad; }
+  if (pp) printf("   ping-pong %8.1f us %6.1f TF  rel err %.2e | max |pp - split| over ALL outputs %.3e (%zu beyond 1e-3)\n", ms_pp * 1e3 / reps,
+                 2.0 * batches * rows * N * (double)K / (ms_pp * 1e-3 / reps) * 1e-12, sqrt(e_pp / nrm), maxdiff, nbad);
   const double fl = 2.0 * batches * rows * N * (double)K;
   printf("rows %6d K %5d N %5d x%2d | split %8.1f us %6.1f TF  rel err %.2e | fp32 MFMA %8.1f us %6.1f TF  rel err %.2e\n", rows, K, N,
          batches, ms_split * 1e3 / reps, fl / (ms_split * 1e-3 / reps) * 1e-12, sqrt(e_split / nrm), ms_f32 * 1e3 / reps,
          fl / (ms_f32 * 1e-3 / reps) * 1e-12, sqrt(e_f32 / nrm));
-  hipFree(A); hipFree(Bt); hipFree(B); hipFree(C); hipFree(C2);
+  hipFree(A); hipFree(Bt); hipFree(B); hipFree(C); hipFree(C2); hipFree(C3);
 }
 
 int main() {
@@ -66,5 +113,8 @@ int main() {
   run(648, 1024, 1024, 16);    // R data gradient
   run(2048, 1024, 512, 16);    // D3 forward
   run(32768, 256, 128, 16);    // D1 forward
+  run(2312, 512, 1024, 16);    // D3 data gradient
+  run(8192, 256, 256, 16);     // U2-like
+  run(300, 100, 128, 3);       // ragged: row and K tails
   return 0;
 }

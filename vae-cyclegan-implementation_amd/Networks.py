@@ -3,9 +3,9 @@
 Class names, constructor signatures, attribute names, `forward` return order, metric keys
 and state_dict keys/shapes follow the reference (file:line cited per class) so a
 reference checkpoint loads and `train.py` drives these classes unchanged.  Underneath,
-every block is a fused HIP launch sequence (`ops.conv_block`): implicit-GEMM conv on the
-fp32 matrix core with bias/activation epilogue, two-stage InstanceNorm statistics, and a
-normalise(+activation)(+residual)(+PixelShuffle) store.  torch modules (`nn.Conv2d`,
+every block is a fused HIP launch sequence (`ops.conv_block`): implicit-GEMM / Winograd conv on the
+bf16 matrix pipe with split fp32 operands (fp32-level rounding) and a bias/activation epilogue,
+two-stage InstanceNorm statistics, and a normalise(+activation)(+residual)(+PixelShuffle) store.  torch modules (`nn.Conv2d`,
 `spectral_norm`) are used only as parameter containers — their forwards are never run.
 
 Tensors crossing module boundaries keep the logical (N, C, H, W) shape and are stored

@@ -53,7 +53,8 @@ class FusedAdam:
                 view.copy_(p.data)          # one-time re-homing of the initial values
                 p.data = view
                 p.grad = self.flat_grad[o:o + p.numel()].view(p.shape)
-        self.step_count = 0
+        self.step_count = 0                     # steps taken by the parameters' common counter (max over `steps`)
+        self.steps = [0] * len(plist)           # torch.optim.Adam keeps one counter per parameter; so do we
         self.grad_scale = 1.0
         self._epoch = [0]                       # bumped by step(); ConvSpec.packed() keys its cache on it
         for p in plist:
@@ -78,10 +79,21 @@ class FusedAdam:
         all-reduce; parallel.GradReducer sets `self.grad_scale`).  `repack=False` leaves the side-stream repack of
         the conv weights to the caller (ops.repack_async), e.g. until no collective is in flight any more."""
         g = self.param_groups[0]
-        self.step_count += 1
         scale = self.grad_scale if grad_scale is None else grad_scale
-        ops.adam_step_flat(self.flat_param, self.flat_grad, self.exp_avg, self.exp_avg_sq, self.step_count,
-                           g["lr"], g["betas"][0], g["betas"][1], g["eps"], scale)
+        self.steps = [t + 1 for t in self.steps]
+        self.step_count = max(self.steps)
+        # one launch per run of consecutive parameters that share a step counter: ONE launch unless a loaded state
+        # carried different counters (a reference run that re-created its optimizer for part of the model)
+        i = 0
+        while i < len(self.params):
+            j = i
+            while j + 1 < len(self.params) and self.steps[j + 1] == self.steps[i]:
+                j += 1
+            lo = self.offsets[i]
+            hi = self.offsets[j + 1] if j + 1 < len(self.params) else self.total
+            ops.adam_step_flat(self.flat_param[lo:hi], self.flat_grad[lo:hi], self.exp_avg[lo:hi], self.exp_avg_sq[lo:hi],
+                               self.steps[i], g["lr"], g["betas"][0], g["betas"][1], g["eps"], scale)
+            i = j + 1
         self._epoch[0] += 1
         if repack:
             ops.repack_async(self.params)
@@ -90,8 +102,10 @@ class FusedAdam:
         state = {}
         if self.step_count > 0:
             for i, (p, o) in enumerate(zip(self.params, self.offsets)):
+                if self.steps[i] == 0:
+                    continue                      # torch creates a parameter's state at its first step
                 state[i] = {
-                    "step": torch.tensor(float(self.step_count)),
+                    "step": torch.tensor(float(self.steps[i])),
                     "exp_avg": self.exp_avg[o:o + p.numel()].view(p.shape).clone(),
                     "exp_avg_sq": self.exp_avg_sq[o:o + p.numel()].view(p.shape).clone(),
                 }
@@ -100,20 +114,42 @@ class FusedAdam:
         return {"state": state, "param_groups": [group]}
 
     def load_state_dict(self, sd):
+        """torch.optim.Adam's state_dict (ours or the reference's).  The parameter list must be the one the state was
+        saved for: a reference checkpoint written after `configure_optimizers(decoder_only=True)` (Networks.py:307-313)
+        holds the decoder's tensors only and loads into an optimizer configured the same way.  Per-parameter step
+        counters are kept as they are (they may differ, and a parameter without state starts at step 0)."""
         groups = sd["param_groups"]
-        if len(groups) != 1 or len(groups[0]["params"]) != len(self.params):
-            raise ValueError("optimizer state does not match the parameter list")
+        n_saved = sum(len(g["params"]) for g in groups)
+        if n_saved != len(self.params):
+            raise ValueError(f"optimizer state holds {n_saved} parameter(s), this optimizer {len(self.params)}: the state was "
+                             "saved for another parameter list (e.g. a reference Autoencoder run with "
+                             "configure_optimizers(decoder_only=True) — configure this model the same way before loading)")
+        if len(groups) != 1:
+            hyper = [(g.get("lr"), tuple(g.get("betas", ())), g.get("eps"), g.get("weight_decay", 0)) for g in groups]
+            if len(set(hyper)) != 1:
+                raise ValueError("FusedAdam runs one hyper-parameter set over its flat buffer; the loaded state has "
+                                 f"{len(groups)} param groups with different lr / betas / eps")
+        if groups[0].get("weight_decay", 0) or groups[0].get("amsgrad", False) or groups[0].get("maximize", False):
+            raise ValueError("FusedAdam implements plain Adam (no weight decay / amsgrad / maximize), as the reference uses it")
         for k in ("lr", "betas", "eps"):
             if k in groups[0]:
                 self.param_groups[0][k] = tuple(groups[0][k]) if k == "betas" else groups[0][k]
-        steps = set()
+        order = [i for g in groups for i in g["params"]]           # saved index of our i-th parameter
+        steps = [0] * len(self.params)
         with torch.no_grad():
-            for idx, st in sd["state"].items():
-                i = int(idx)
-                p, o = self.params[i], self.offsets[i]
+            for i, (p, o) in enumerate(zip(self.params, self.offsets)):
+                st = sd["state"].get(order[i], sd["state"].get(str(order[i])))
+                if st is None:
+                    ops.fill_(self.exp_avg[o:o + p.numel()], 0.0)
+                    ops.fill_(self.exp_avg_sq[o:o + p.numel()], 0.0)
+                    continue
+                if tuple(st["exp_avg"].shape) != tuple(p.shape):
+                    raise ValueError(f"optimizer state of parameter {i} has shape {tuple(st['exp_avg'].shape)}, expected {tuple(p.shape)}")
                 self.exp_avg[o:o + p.numel()].view(p.shape).copy_(st["exp_avg"])
                 self.exp_avg_sq[o:o + p.numel()].view(p.shape).copy_(st["exp_avg_sq"])
-                steps.add(int(float(st["step"])))
-        if len(steps) > 1:
-            raise ValueError("FusedAdam keeps one step counter; the loaded state has several")
-        self.step_count = steps.pop() if steps else 0
+                t = float(st["step"])
+                if abs(t - round(t)) > 1e-3 or t < 0:
+                    raise ValueError(f"optimizer state of parameter {i} has a non-integral step counter {t!r}")
+                steps[i] = int(round(t))
+        self.steps = steps
+        self.step_count = max(steps) if steps else 0

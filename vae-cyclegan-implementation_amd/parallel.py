@@ -51,10 +51,21 @@ class GradReducer:
 
 
 def broadcast_parameters(model, src=0, group=None):
-    """Identical replicas at start (parameters and spectral-norm buffers)."""
+    """Identical replicas (parameters and spectral-norm buffers).  The broadcast writes through `.data`, which bumps
+    neither a tensor's version counter nor its optimizer's step epoch — the two things `ConvSpec.packed()` keys its cache
+    on — so every weight pack is invalidated explicitly: a rank that had already run a forward (warm-up, validation, a
+    checkpoint load) would otherwise keep convolving with its pre-broadcast weights."""
+    from . import ops
     with torch.no_grad():
         for t in list(model.parameters()) + list(model.buffers()):
             dist.broadcast(t.data, src=src, group=group)
+    ops.PARAM_EPOCH[0] += 1
+    seen = set()
+    for p in model.parameters():
+        ep = getattr(p, "_vcg_epoch", None)
+        if ep is not None and id(ep) not in seen:
+            seen.add(id(ep))
+            ep[0] += 1
 
 
 def attach(model, group=None, bucket_bytes=128 << 20):

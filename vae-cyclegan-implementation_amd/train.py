@@ -7,8 +7,9 @@ its argparse lacks it: create_model always used 64), `--steps_per_epoch`, `--see
 aliases `ae` / `vae_cyclegan` for `--architecture`.  Under `torch.distributed.run` each rank trains
 its shard of the global batch and gradients are exchanged by `parallel.GradReducer` (RCCL).
 
-Out of scope here, as in SURVEY.md §2: the image datasets / torchvision pipelines (`Data_Manager.py`),
-TensorBoard, checkpoint resume and the seven other composites.  Asking for them raises.
+Built beyond the three benchmarked architectures: every architecture of the reference's factory,
+`validate`, the checkpoint wire format with `--resume`, the pretraining hand-over (`--pretrained_double*`).
+Out of scope, as in SURVEY.md §2: TensorBoard and the reference's PIL / torchvision dataset classes (`Data_Manager.py`).
 
 `create_model` and `train_epoch` mirror the reference's functions of the same name (train.py:43-128).
 """
@@ -72,9 +73,6 @@ def create_model(architecture, paired=True, latent_dim=64):
     elif architecture == "cyclevaegan":
         model = Networks.CycleVAEGAN(latent_dim=latent_dim, paired=paired)
         print(f"Created Cycle VAE-GAN ({'paired' if paired else 'unpaired'} mode)")
-    elif architecture in REFERENCE_ARCHS:
-        raise NotImplementedError(f"architecture '{architecture}' is not on the accelerated path yet "
-                                  f"(built: {', '.join(BUILT)}); it reuses the same kernels and is listed as a next step")
     else:
         raise ValueError(f"Unknown architecture: {architecture}")
     return model
@@ -99,6 +97,19 @@ class SyntheticLoader:
             yield {"x": x, "y": y}
 
 
+_FROZEN = [False]
+
+
+def _freeze_long_lived_objects():
+    """Once per process: collect, then move the survivors (modules, parameters, ctypes tables) out of the cyclic GC's way.
+    A full collection walks all of them (~30 ms of host time, with the GPU idle behind it); freezing every epoch would pin
+    each epoch's garbage for good, so it is done once."""
+    if not _FROZEN[0]:
+        gc.collect()
+        gc.freeze()
+        _FROZEN[0] = True
+
+
 def train_epoch(model, dataloader, device, args, writer=None, epoch=None):
     """reference train.py:80-128: per-batch training_step, metric sums averaged by len(dataloader),
     G_loss as the headline loss.  The reference also runs one extra train-mode forward per batch for a
@@ -108,8 +119,7 @@ def train_epoch(model, dataloader, device, args, writer=None, epoch=None):
     total_loss = 0.0
     loss_components = {}
     last_output = last_x = last_y = None
-    gc.collect()
-    gc.freeze()          # keep full collections (~30 ms of host time each, with the GPU idle behind them) off the step loop
+    _freeze_long_lived_objects()
     for batch in dataloader:
         batch["x"] = batch["x"].to(device)
         batch["y"] = batch["y"].to(device)
@@ -224,7 +234,6 @@ def main(args):
                          lambda_cycle=args.lambda_cycle, lambda_recon=args.lambda_recon)
     if world > 1:
         parallel.attach(model)
-        parallel.broadcast_parameters(model)
     same_xy = args.architecture in ("autoencoder", "vae")
     # reference train.py:448-463: a pretraining checkpoint initialises the generators of a Cycle model
     if args.pretrained_doubleae is not None and args.pretrained_doublevae is not None:
@@ -244,7 +253,11 @@ def main(args):
             print(f"Resuming from checkpoint: {args.resume}")
         start_epoch, _ = utils.load_checkpoint(model, Path(args.resume), device)
         start_epoch += 1
-    best_test_loss = float("inf")
+    if world > 1:
+        # identical replicas: AFTER every load above, so that replica identity never depends on each rank having read
+        # the same file; the broadcast also invalidates the weight packs of anything a load or a warm-up forward packed
+        parallel.broadcast_parameters(model)
+    best_test_loss = utils.LAST_EXTRAS.get("best_test_loss", float("inf")) if args.resume else float("inf")
     for epoch in range(start_epoch, args.epochs):
         loader = SyntheticLoader(args.batch_size, args.image_size, args.steps_per_epoch, device, args.seed, rank,
                                  same_xy, epoch)
@@ -270,10 +283,10 @@ def main(args):
                     print(f"  {k}: {v:.6f}")
                 if test_loss < best_test_loss:       # reference train.py:565-570
                     best_test_loss = test_loss
-                    utils.save_checkpoint(model, epoch, test_loss, args, output_dir / "best_model.pth")
+                    utils.save_checkpoint(model, epoch, test_loss, args, output_dir / "best_model.pth", best_test_loss)
                     print(f"New best model saved (test_loss: {test_loss:.4f})")
         if rank == 0 and (epoch + 1) % args.save_freq == 0:      # reference train.py:573-575 (replicas are identical)
-            utils.save_checkpoint(model, epoch, train_loss, args, output_dir / f"checkpoint_epoch_{epoch + 1}.pth")
+            utils.save_checkpoint(model, epoch, train_loss, args, output_dir / f"checkpoint_epoch_{epoch + 1}.pth", best_test_loss)
     if world > 1:
         dist.destroy_process_group()
     if rank == 0:

@@ -12,17 +12,28 @@ import os
 
 import torch
 
+from . import ops
 
-def save_checkpoint(model, epoch, loss, args, filename):
+# extra keys of the last checkpoint `load_checkpoint` read ({} for a file the reference wrote): `best_test_loss`
+LAST_EXTRAS = {}
+
+
+def save_checkpoint(model, epoch, loss, args, filename, best_test_loss=None):
     """reference utils.py:17-28.  Tensors are written from the CPU so the file loads on a machine without a GPU
-    (the reference's own loader passes map_location anyway)."""
+    (the reference's own loader passes map_location anyway).  Two keys are ADDED to the reference's five (its loader
+    reads the ones it knows and ignores the rest): the position of the on-device eps stream (`vcg_eps_rng`) so that a
+    resumed run draws the eps it would have drawn, and the best test loss so far (`vcg_best_test_loss`) so that a
+    resumed run does not overwrite best_model.pth with a worse model."""
     checkpoint = {
         "epoch": epoch,
         "model_state_dict": {k: v.detach().cpu() for k, v in model.state_dict().items()},
         "optimizer_states": _to_cpu(model.save_optimizer_states()),
         "loss": loss,
         "args": vars(args),
+        "vcg_eps_rng": {"seed": int(ops._RNG["seed"]), "offset": int(ops._RNG["offset"])},
     }
+    if best_test_loss is not None:
+        checkpoint["vcg_best_test_loss"] = float(best_test_loss)
     torch.save(checkpoint, filename)
     print(f"Checkpoint saved to {filename}")
 
@@ -41,6 +52,13 @@ def load_checkpoint(model, filename, device):
             pass
     if "optimizer_states" in checkpoint:
         model.load_optimizer_states(checkpoint["optimizer_states"])
+    LAST_EXTRAS.clear()
+    if "vcg_eps_rng" in checkpoint:                      # ours: continue the eps stream where the saved run stood
+        ops._RNG["seed"] = int(checkpoint["vcg_eps_rng"]["seed"])
+        ops._RNG["offset"] = int(checkpoint["vcg_eps_rng"]["offset"])
+    if "vcg_best_test_loss" in checkpoint:
+        LAST_EXTRAS["best_test_loss"] = float(checkpoint["vcg_best_test_loss"])
+    ops.PARAM_EPOCH[0] += 1                              # load_state_dict wrote through .data: drop every weight pack
     epoch, loss = checkpoint["epoch"], checkpoint["loss"]
     print(f"Loaded checkpoint from {filename} (epoch {epoch}, loss {loss:.4f})")
     return epoch, loss
