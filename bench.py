@@ -7,7 +7,7 @@
 A "step" is one `CycleVAEGAN.training_step` (generator update + discriminator update) on one
 synthetic batch per rank; batches are generated on the device before the timed region.  Rank 0
 prints ONE JSON line.  `roofline` is measured live with HIP events around every launch of the
-dominant kernel family during extra instrumented steps (ops.PROFILE); `cpu_baseline` times the
+dominant DEVICE kernel during two extra instrumented steps (events recorded inside libvcg, vcg_profile_enable); `cpu_baseline` times the
 oracle's CPU restatement of the same step on a bounded sample (rank 0, N=1 only).
 """
 import argparse
@@ -170,17 +170,41 @@ def main():
         dist.destroy_process_group()
 
 
+PROFILE_ROUND = "r02"          # profiles/<round>_pmc_*.json: the committed PMC passes `traffic` and `mfma_pipe_util` are quoted from
+
+
+def read_kernel_profile(lib):
+    """{device kernel: (launches, seconds, executed FLOPs)} since vcg_profile_enable(1): HIP events recorded by the library
+    around each MFMA kernel launch, on the stream the kernel was launched on."""
+    import ctypes
+    n = lib.vcg_profile_read(None, 0)
+    buf = ctypes.create_string_buffer(max(int(n), 1) + 64)
+    lib.vcg_profile_read(buf, len(buf))
+    out = {}
+    for line in buf.value.decode().splitlines():
+        name, cnt, ms, fl = line.split("\t")
+        out[name] = (int(cnt), float(ms) * 1e-3, float(fl))
+    return out
+
+
 def measure_roofline(pkg, model, pool, wl, B, S, latent, ms_per_step, rank=0):
-    """HIP events around every conv launch of two extra steps; the dominant family's algorithmic
-    FLOPs / its summed launch time, against the fp32 MFMA peak."""
+    """Two extra (untimed) steps on ONE stream with HIP events around every launch: per C-ABI call from Python (kernel
+    families, algorithmic direct-convolution FLOPs) and per device kernel inside the library (the FLOPs that launch
+    executes).  `roofline` describes the dominant DEVICE kernel against the pipe it runs on."""
     ops = pkg.ops
+    lib = pkg._native.lib()
     ops.PROFILE = []
+    lib.vcg_profile_read(None, 0)                                 # drop anything recorded earlier
+    lib.vcg_profile_enable(1)
     overlap, ops.OVERLAP_ENABLED = ops.OVERLAP_ENABLED, False     # kernel rates are measured one family at a time:
-    for i in range(2):                                            # the timed steps above run the weight gradients on a
+    nsteps = 2
+    for i in range(nsteps):                                       # the timed steps above run the weight gradients on a
         model.training_step(pool[i % len(pool)])                  # side stream, where co-running families stretch each other
     torch.cuda.synchronize()
+    lib.vcg_profile_enable(0)
     ops.OVERLAP_ENABLED = overlap
     recs, ops.PROFILE = ops.PROFILE, None
+    dev = read_kernel_profile(lib)
     fam, shapes = {}, {}
     for name, flops, e0, e1, tag in recs:
         dt = e0.elapsed_time(e1) * 1e-3
@@ -197,81 +221,104 @@ def measure_roofline(pkg, model, pool, wl, B, S, latent, ms_per_step, rank=0):
     if dump:                                   # per-shape table for kernel work (not part of the JSON line)
         with open(dump, "w") as fh:
             for (name, tag), (fl, sec, cnt) in sorted(shapes.items(), key=lambda kv: -kv[1][1]):
-                fh.write(f"{name:11s} {tag:34s} n={cnt // 2:3d} ms/step={sec / 2 * 1e3:8.3f} us/launch={sec / cnt * 1e6:9.1f} "
+                fh.write(f"{name:11s} {tag:34s} n={cnt // nsteps:3d} ms/step={sec / nsteps * 1e3:8.3f} us/launch={sec / cnt * 1e6:9.1f} "
                          f"TF={fl / sec / 1e12:7.2f}\n")
+            for name, (cnt, sec, fl) in sorted(dev.items(), key=lambda kv: -kv[1][1]):
+                fh.write(f"device {name:28s} n={cnt // nsteps:3d} ms/step={sec / nsteps * 1e3:8.3f} us/launch={sec / cnt * 1e6:9.1f} "
+                         f"executed TF={fl / sec / 1e12:7.2f}\n")
     conv = {k: v for k, v in fam.items() if k.startswith("conv_")}
-    dom = max(conv, key=lambda k: conv[k][1])
-    flops, secs, n = conv[dom]
-    ach = flops / secs / 1e12
-    kernels = {k: {"launches_per_step": v[2] // 2, "ms_per_step": round(v[1] / 2 * 1e3, 3),
+    kernels = {k: {"launches_per_step": v[2] // nsteps, "ms_per_step": round(v[1] / nsteps * 1e3, 3),
                    "tflops": round(v[0] / max(v[1], 1e-12) / 1e12, 2) if v[0] else None} for k, v in sorted(fam.items())}
     # necessary conv FLOPs of one step: fwd + bwd-data + bwd-weight, nothing redundant
-    step_flops = sum(v[0] for v in conv.values()) / 2
-    # one "launch" = one C-ABI call of that family; these are the device kernels it issues (rocprofv3 names)
-    symbols = {"conv_fwd": ["k_conv_fwd", "k_wino_in", "k_wino_out", "k_conv_thin<0>", "k_splitk_finish"],
-               "conv_dgrad": ["k_conv_dgrad", "k_wino_in", "k_conv_fwd (batched)", "k_wino_out_pad", "k_wino_fold", "k_conv_thin<1>",
-                              "k_fold_pad", "k_splitk_finish"],
-               "conv_wgrad": ["k_conv_wgrad", "k_wino_in", "k_wino_dy", "k_wino_wgrad_reduce", "k_wgrad_reduce", "k_wgrad_scatter",
-                              "k_slab_sum", "k_colsum_partial", "k_colsum_final"]}
+    step_flops = sum(v[0] for v in conv.values()) / nsteps
+
+    def pipe_peak(name):              # the dense peak of the matrix pipe a device kernel issues to, in fp32-equivalent FLOPs
+        return FP32_MFMA_PEAK_TFLOPS if "fp32 MFMA" in name else BF16X3_FP32_EQUIV_PEAK_TFLOPS
+    device = {}
+    for name, (cnt, sec, fl) in dev.items():
+        tf = fl / max(sec, 1e-12) / 1e12
+        device[name] = {"launches_per_step": cnt // nsteps, "ms_per_step": round(sec / nsteps * 1e3, 3),
+                        "avg_launch_ms": round(sec / cnt * 1e3, 4), "executed_tflops": round(tf, 2),
+                        "frac_of_pipe_peak": round(tf / pipe_peak(name), 4)}
+    dom = max(dev, key=lambda k: dev[k][1])
+    cnt, sec, fl = dev[dom]
+    ach = fl / sec / 1e12
     headline = wl == "cyclevaegan" and B == 8 and S == 256
-    traffic, traffic_src = profiled_traffic(dom, n // 2) if headline else (None, None)
-    mfma_util = profiled_mfma_util(symbols_of(dom)) if headline else None
+    traffic = profiled_traffic(dom) if headline else None
+    mfma_util = profiled_mfma_util() if headline else None
+    famdom = max(conv, key=lambda k: conv[k][1])
+    ffl, fsec, fn = conv[famdom]
+    fach = ffl / fsec / 1e12
+    roof = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 2), "peak": round(pipe_peak(dom), 1), "unit": "TFLOP/s",
+            "frac": round(ach / pipe_peak(dom), 4),
+            "peak_is": "dense bf16 MFMA peak (2516.8 TFLOP/s, v_mfma_f32_32x32x16_bf16) / 6: the pipe this kernel executes on, in "
+                       "fp32-equivalent FLOPs — every fp32 product is six bf16 MFMAs (3-way operand split, fp32 accumulate, "
+                       "fp32-level rounding)" if pipe_peak(dom) != FP32_MFMA_PEAK_TFLOPS else "fp32 MFMA (v_mfma_f32_32x32x2_f32)",
+            "flops_counted": "the FLOPs the launch executes: 2*M*N*K of its GEMM (for a Winograd layer the 16 transformed GEMMs, "
+                             "2.25x fewer than the direct convolution's)",
+            "launches": cnt // nsteps, "avg_launch_ms": round(sec / cnt * 1e3, 4),
+            "measured": "HIP events recorded by libvcg around each launch of this device kernel, on its launch stream, in two extra "
+                        "steps run on ONE stream (the timed steps overlap weight gradients with data gradients on a second stream)",
+            "frac_vs_fp32_mfma_target": round(ach / FP32_MFMA_PEAK_TFLOPS, 4),
+            "frac_vs_fp32_mfma_target_is": "the same rate against the 157.3 TFLOP/s fp32-MFMA roof BASELINE.json's north_star names "
+                                           "(target >= 0.40)",
+            "traffic": None if traffic is None else traffic["bytes_per_launch"],
+            "traffic_detail": traffic, "mfma_pipe_util": mfma_util,
+            "device_kernels": device,
+            "family": {"kernel": famdom, "achieved_algorithmic_tflops": round(fach, 2),
+                       "is": "the C-ABI call family with the most time (one call = several device kernels: transforms, GEMM, reduces); "
+                             "FLOPs = the direct convolution's 2*M*Cout*K per call, the layer's algorithmic work",
+                       "frac_of_bf16x3_peak": round(fach / BF16X3_FP32_EQUIV_PEAK_TFLOPS, 4),
+                       "frac_vs_fp32_mfma_target": round(fach / FP32_MFMA_PEAK_TFLOPS, 4),
+                       "launches": fn // nsteps, "avg_launch_ms": round(fsec / fn * 1e3, 4)}}
+    if traffic is not None:
+        # which roof is nearer for this kernel: its fabric bytes per second against HBM3E's 8 TB/s, or its MFMA rate
+        hbm_frac = traffic["bytes_per_launch"] / (sec / cnt) / 8.0e12
+        roof["hbm_frac_from_profiled_traffic"] = round(hbm_frac, 4)
+        roof["bound"] = "hbm" if hbm_frac > roof["frac"] else "mfma"
     return {
-        "roofline": {"bound": "mfma", "kernel": dom, "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                     "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
-                     "mfma_pipe_util": mfma_util,
-                     "launches": n // 2, "avg_launch_ms": round(secs / n * 1e3, 4),
-                     "peak_is": "fp32 MFMA (v_mfma_f32_32x32x2_f32), the roofline BASELINE.json's north_star names",
-                     "peak_bf16x3": round(BF16X3_FP32_EQUIV_PEAK_TFLOPS, 1),
-                     "frac_bf16x3": round(ach / BF16X3_FP32_EQUIV_PEAK_TFLOPS, 4),
-                     "peak_bf16x3_is": "dense bf16 MFMA peak / 6: the GEMMs execute on the bf16 pipe as 6 bf16 products per fp32 "
-                                       "product (3-way operand split, fp32 accumulate, fp32-level rounding)",
-                     "flops_counted": "direct-convolution 2*M*Cout*K per call (the Winograd layers execute 2.25x fewer)",
-                     "measured": "HIP events around every call of the family in two extra steps run on ONE stream "
-                                 "(the timed steps overlap weight gradients with data gradients on a second stream)",
-                     "device_kernels": symbols.get(dom, [])},
+        "roofline": roof,
         "step_conv_tflops": round(step_flops / (ms_per_step * 1e-3) / 1e12, 2),
-        "step_conv_frac_of_peak": round(step_flops / (ms_per_step * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
+        "step_conv_frac_of_fp32_mfma_target": round(step_flops / (ms_per_step * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
         "kernels": kernels,
     }
 
 
-def symbols_of(family):
-    """rocprofv3 name prefixes of the MFMA kernels a family's C-ABI calls launch"""
-    return {"conv_fwd": ["k_gemm_split", "k_conv_fwd_split", "k_conv_fwd<"], "conv_dgrad": ["k_gemm_split", "k_conv_dgrad_split", "k_conv_dgrad<"],
-            "conv_wgrad": ["k_conv_wgrad_split", "k_conv_wgrad<"]}.get(family, [])
-
-
-def profiled_mfma_util(prefixes):
-    """MFMA-pipe busy share (SQ_VALU_MFMA_BUSY_CYCLES / (SIMDs x kernel cycles)) of the family's MFMA kernels and of all
-    MFMA kernels of the step, from the committed PMC pass over this command (profiles/r01_pmc_mfma_util.json, written by
-    tools/pmc_mfma_util.py).  None when the file is missing."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_mfma_util.json")
+def _profile_json(stem):
+    path = os.path.join(ROOT, "profiles", f"{PROFILE_ROUND}_{stem}.json")
     try:
         with open(path) as fh:
-            js = json.load(fh)
+            return json.load(fh), os.path.relpath(path, ROOT)
     except (OSError, ValueError):
-        return None
-    ks = {k: round(v["mfma_util"], 4) for k, v in js["kernels"].items() if any(k.startswith(p) for p in prefixes)}
-    return {"kernels": ks, "all_mfma_kernels_of_the_step": round(js["conv_kernels_mfma_util"], 4),
-            "pipe": "bf16 MFMA (v_mfma_f32_32x32x16_bf16; the fp32-MFMA thin-layer kernels count their own cycles)",
-            "source": "profiles/r01_pmc_mfma_util.json (rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE over bench.py, one stream)"}
-
-
-def profiled_traffic(family, launches_per_step):
-    """Fabric-side bytes per launch (= per C-ABI call) of a kernel family, from the committed rocprofv3 PMC passes over
-    this command at the headline config (profiles/r01_pmc_step_traffic.json, written by tools/pmc_summary.py; not
-    measured live: counters need the profiler).  None when the file is missing."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_step_traffic.json")
-    try:
-        with open(path) as fh:
-            fam = json.load(fh)["families"][family]
-    except (OSError, KeyError, ValueError):
         return None, None
-    per_launch = (fam["read"] + fam["write"]) / max(launches_per_step, 1)
-    return round(per_launch), ("profiles/r01_pmc_step_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over "
-                               "bench.py, read = 2 x FETCH_SIZE (gfx950), Infinity-Cache hits included; bytes per C-ABI call, "
-                               "averaged over the family's launches of one step")
+
+
+def profiled_mfma_util():
+    """MFMA-pipe busy share (SQ_VALU_MFMA_BUSY_CYCLES / (SIMDs x kernel cycles)) of every MFMA kernel of the step, from the
+    committed PMC pass over this command (tools/final_profiles.sh, tools/pmc_mfma_util.py).  NOT measured in this run
+    (counters need the profiler): the record says so and names the commit the pass was taken at.  None when the file is missing."""
+    js, path = _profile_json("pmc_mfma_util")
+    if js is None:
+        return None
+    return {"measured_in_this_run": False, "source": path, "head": js.get("head", "unknown"),
+            "kernels": {k: round(v["mfma_util"], 4) for k, v in js["kernels"].items()},
+            "all_mfma_kernels_of_the_step": round(js["conv_kernels_mfma_util"], 4),
+            "is": "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE over bench.py, one stream"}
+
+
+def profiled_traffic(kernel):
+    """Fabric-side bytes per launch of one device kernel from the committed rocprofv3 PMC passes over this command at the
+    headline config (tools/final_profiles.sh, tools/pmc_summary.py: separate FETCH_SIZE / WRITE_SIZE passes, read = 2 x
+    FETCH_SIZE on gfx950, Infinity-Cache hits included).  NOT measured in this run; None when the file or kernel is missing."""
+    js, path = _profile_json("pmc_step_traffic")
+    if js is None or kernel not in js.get("kernels", {}):
+        return None
+    k = js["kernels"][kernel]
+    return {"measured_in_this_run": False, "source": path, "head": js.get("head", "unknown"),
+            "bytes_per_launch": round((k["read"] + k["write"]) / max(k["launches"], 1e-9)),
+            "read_bytes_per_launch": round(k["read"] / max(k["launches"], 1e-9)),
+            "write_bytes_per_launch": round(k["write"] / max(k["launches"], 1e-9)),
+            "step_total_bytes": round(js["all"]["read"] + js["all"]["write"])}
 
 
 def cpu_baseline(pkg, wl, S, latent):
@@ -307,9 +354,11 @@ def cpu_baseline(pkg, wl, S, latent):
             oracle.autoencoder_step(P, state, x, x, 2e-4)
         times.append(time.perf_counter() - t0)
     t = sum(times[1:]) / len(times[1:])
+    ref = {"cyclevaegan": "0.200 images/s (batch 8)", "vae": "0.89 images/s (batch 16, latent 1024)", "autoencoder": "1.39 images/s (batch 16)"}[wl]
     return {"value": round(b / t, 4), "unit": "images/s", "cores": cores, "kind": "port",
             "sample": f"oracle (functional PyTorch fp32 CPU restatement) {wl} step, batch {b}, {S}x{S}, mean of steps 2-3 of 3 "
-                      f"({sum(times):.1f} s of CPU work in all)"}
+                      f"({sum(times):.1f} s of CPU work in all); the reference's own module on the 8-core build container: {ref} "
+                      "(BASELINE.md §2; it cannot travel to this box)"}
 
 
 if __name__ == "__main__":

@@ -53,6 +53,13 @@ enum { VCG_ACT_NONE = 0, VCG_ACT_RELU = 1, VCG_ACT_LEAKY02 = 2 };
 int vcg_abi_version(void);
 const char* vcg_last_error(void);
 
+/* Diagnostic (bench.py's `roofline` object; the training path never enables it): while enabled, every MFMA kernel launch
+   is bracketed by HIP events on its launch stream.  vcg_profile_read WAITS for those events (the one call of this library
+   that synchronises) and writes one line per device kernel: name \t launches \t total ms \t executed FLOPs
+   (fp32-equivalent: 2*M*N*K of the GEMM the launch ran); returns the bytes written (or needed, when buf is NULL). */
+int vcg_profile_enable(int on);
+long vcg_profile_read(char* buf, size_t cap);
+
 /* layout ------------------------------------------------------------------- */
 /* x.to(channels-last); images get channel pitch P (pad channels zeroed).     */
 int vcg_nchw_to_nhwc(const float* src, float* dst, int N, int C, int H, int W, int P, void* stream);
@@ -153,10 +160,11 @@ int vcg_fullmap_wgrad(const float* g, const float* x, const float* wsn_k, const 
 
 /* torch.optim.Adam.step — call sites Networks.py:312,894,1928-1935 ---------- */
 /* single-tensor torch formula on one flat buffer:
-   m += (1-b1)(g-m); v = b2 v + (1-b2) g^2; p -= step_size * m / (sqrt(v)/bc2_sqrt + eps) */
+   m += (1-b1)(g-m); v = b2 v + (1-b2) g^2; p -= step_size * m / (sqrt(v)/bc2_sqrt + eps)
+   one_minus_beta1/2: 1 - beta computed in double by the caller and rounded once, as torch passes them to lerp_ / addcmul_ */
 int vcg_adam_step(float* p, const float* g, float* m, float* v, size_t n,
-                  float step_size, float beta1, float beta2, float eps, float bc2_sqrt,
-                  float grad_scale, void* stream);
+                  float step_size, float beta1, float beta2, float one_minus_beta1, float one_minus_beta2,
+                  float eps, float bc2_sqrt, float grad_scale, void* stream);
 
 #ifdef __cplusplus
 }

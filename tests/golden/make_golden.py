@@ -409,6 +409,29 @@ def gen_single_gan(N, out, meta):
         print(key, meta[key], meta[key + "/validation"])
 
 
+def gen_steps_fp64(N, meta):
+    """The two unpaired CycleVAEGAN steps of `steps` again in float64: what the step-2 metrics would be without fp32
+    rounding.  |fp32 - fp64| of the REFERENCE calibrates how far a second GAN step of another fp32 implementation may
+    land (Adam's first update is lr * sign(g): wherever a gradient element is rounding noise — the reference's own fp32
+    gradient of D's spectral-normed weight is 77 % away from its fp64 one — the two runs take opposite steps)."""
+    torch.set_num_threads(8)
+    key = "cvg256_unpaired"
+    model = N.CycleVAEGAN(latent_dim=64, paired=False)
+    load_synth_params(model, SEED, 0.02, prefix=key + ".")
+    model = model.double()
+    model.configure_optimizers(lr=LR)
+    model.configure_loss(**LAMBDAS)
+    model.train()
+    ms = []
+    for step in range(2):
+        x, y = synth.batch(1, 256, SEED, step=step)
+        eps = synth.eps_list(6, (1, 64, 16, 16), SEED, step=step)
+        with EpsInjector([e.astype(np.float64) for e in eps]):
+            ms.append(model.training_step({"x": torch.from_numpy(x).double(), "y": torch.from_numpy(y).double()}))
+        print(key, "fp64 step", step, ms[-1])
+    meta[key] = ms
+
+
 def gen_vae1024(N, out, meta):
     """BASELINE.json configs[2] is `vae` with latent_dim 1024 (the reference CLI cannot reach it; the class can: Networks.py:856).
     64x64, batch 2, ONE training step from synthetic parameters (fp32 + fp64 gradients) and the eval-mode validation
@@ -481,6 +504,20 @@ def gen_train_epoch(N, out, meta):
         out[f"{key}/last_output"] = lo[:, :, ::st, ::st].numpy()
         meta[key] = {"avg_loss": avg_loss, "components": comps, "last_output_shape": list(last_output.shape),
                      "eps_draws": inj.i}
+        # the same epoch in float64: `last_output` is a forward AFTER two Adam updates, and Adam's early updates are
+        # lr * sign(g) — every gradient element at rounding-noise level steps the other way in another fp32 run — so the
+        # reference's own fp32 `last_output` sits tens of percent from its fp64 one.  The fp64 copy calibrates the test.
+        model = ctor()
+        load_synth_params(model, SEED, 0.02, prefix=key + ".")
+        model = model.double()
+        model.configure_optimizers(lr=LR)
+        model.configure_loss(**LAMBDAS)
+        b64 = [{k: v.double() for k, v in b.items()} for b in batches]
+        with EpsInjector([e.astype(np.float64) for e in eps]):
+            avg64, comps64, lo64, _, _ = T.train_epoch(model, b64, torch.device("cpu"), args)
+        lo64 = lo64 if lo64.dim() == 4 else lo64[None]
+        out[f"{key}/last_output64"] = lo64[:, :, ::st, ::st].numpy()
+        meta[key]["avg_loss64"], meta[key]["components64"] = avg64, comps64
         print("train_epoch", key, meta[key])
 
 
@@ -527,7 +564,7 @@ def main():
     torch.manual_seed(0)
     atoms, steps, meta = {}, {}, {"seed": SEED, "lr": LR, "lambdas": LAMBDAS,
                                   "torch": torch.__version__, "reference": "Baverne/VAE-CYCLEGAN-Implementation"}
-    which = sys.argv[1:] or ["atoms", "steps", "validation", "cycleaegan", "cycle_nogan", "double", "single_gan", "vae1024", "train_epoch",
+    which = sys.argv[1:] or ["atoms", "steps", "validation", "cycleaegan", "cycle_nogan", "double", "single_gan", "steps_fp64", "vae1024", "train_epoch",
                                  "checkpoint"]
     if "atoms" in which:
         gen_atoms(N, atoms)
@@ -566,6 +603,11 @@ def main():
         gen_single_gan(N, arr, cmeta)
         np.savez_compressed(os.path.join(HERE, "single_gan.npz"), **arr)
         with open(os.path.join(HERE, "single_gan_meta.json"), "w") as f:
+            json.dump(cmeta, f, indent=1)
+    if "steps_fp64" in which:
+        cmeta = {"seed": SEED, "lr": LR, "lambdas": LAMBDAS, "torch": torch.__version__}
+        gen_steps_fp64(N, cmeta)
+        with open(os.path.join(HERE, "steps_fp64_meta.json"), "w") as f:
             json.dump(cmeta, f, indent=1)
     if "vae1024" in which:
         arr, cmeta = {}, {"seed": SEED, "lr": LR, "lambdas": LAMBDAS, "torch": torch.__version__}

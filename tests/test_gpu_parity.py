@@ -476,11 +476,23 @@ def test_cyclevaegan_step_matches_reference_golden(key, paired, pkg, device, ste
     if len(steps_meta[key]) > 1:
         # the fixture's SECOND step: both optimizers hand over their state (Adam moments, step counters, the packs keyed
         # on each optimizer's own epoch) and the spectral-norm vectors carry on.  GAN dynamics amplify rounding step over
-        # step (D_loss 1.4 -> 261 -> 29), so the bound is the 2e-2 the CPU oracle test uses for it
+        # step: Adam's first update is lr * sign(g), so wherever a gradient element is rounding noise two
+        # fp32 runs step in opposite directions.  The bound is therefore calibrated by the reference itself, like the
+        # gradients: tests/golden/steps_fp64_meta.json holds the same two steps run by the reference in float64, and ours
+        # must be within max(2e-2, 4 x |reference fp32 - reference fp64|) of that truth (the reference's own fp32 run is
+        # 2.1 % off on D_loss, 6 % on D_loss_y_fake, 20 % on the near-zero loss_gan_g_x_fake).
+        import json
+        with open(os.path.join(os.path.dirname(__file__), "golden", "steps_fp64_meta.json")) as fh:
+            f64 = json.load(fh)[key][1]
         x, y = pkg.synth.batch(1, 256, SEED, step=1)
         pkg.ops.inject_eps([torch.from_numpy(e) for e in pkg.synth.eps_list(6, (1, 64, 16, 16), SEED, step=1)])
         m = model.training_step({"x": torch.from_numpy(x).to(device), "y": torch.from_numpy(y).to(device)})
-        _check_metrics(m, steps_meta[key][1], f"{key} step 1", tol=2e-2)
+        f32 = steps_meta[key][1]
+        assert list(m) == list(f32)
+        for k, truth in f64.items():
+            bound = max(2e-2 * abs(truth), 4 * abs(f32[k] - truth))
+            assert abs(m[k] - truth) <= bound, (f"{key} step 1: {k} = {m[k]!r}, reference fp64 {truth!r} (its fp32 run {f32[k]!r}); "
+                                               f"off by {abs(m[k] - truth):.3e} > {bound:.3e}")
         assert model.optimizer_G.step_count == 2 and model.optimizer_D.step_count == 2
         params = {n: v for n, v in model.state_dict().items()}
         check_step_state(params, None, key, steps_golden, LR, nsteps=2)
@@ -512,15 +524,46 @@ def test_train_epoch_matches_the_reference_train_epoch(key, pkg, device, train_e
     avg, comps, last_output, last_x, last_y = train.train_epoch(model, batches, device, args)
     assert not pkg.ops._EPS_QUEUE, "train_epoch consumed fewer eps draws than the reference's"
     ref = meta[key]
-    tol = 2e-2 if key.startswith("cvg") else 1e-3          # the GAN's second step amplifies rounding
     assert list(comps) == list(ref["components"])
-    assert abs(avg - ref["avg_loss"]) <= tol * abs(ref["avg_loss"])
+    gan_tol = {}
+    if key.startswith("cvg"):
+        # the GAN's second step amplifies rounding (see test_cyclevaegan_step_matches_reference_golden): per metric, what the
+        # reference's own fp32 run deviates from its float64 run at a second step, x 2.5 (the average halves it, and we may
+        # land on the other side of the truth)
+        import json
+        with open(os.path.join(os.path.dirname(__file__), "golden", "steps_fp64_meta.json")) as fh:
+            f64 = json.load(fh)["cvg256_unpaired"][1]
+        with open(os.path.join(os.path.dirname(__file__), "golden", "steps_meta.json")) as fh:
+            f32 = json.load(fh)["cvg256_unpaired"][1]
+        gan_tol = {k: 2.5 * abs(f32[k] - f64[k]) / max(abs(f64[k]), 1e-6) for k in f64}
+
+    def tol(k):
+        return max(2e-2, gan_tol.get(k, 0.0)) if key.startswith("cvg") else 1e-3
+    assert abs(avg - ref["avg_loss"]) <= tol("G_loss") * abs(ref["avg_loss"])
     for k, v in ref["components"].items():
-        assert abs(comps[k] - v) <= tol * max(abs(v), 1e-6), f"{key}: averaged {k} = {comps[k]!r}, reference {v!r}"
+        assert abs(comps[k] - v) <= tol(k) * max(abs(v), 1e-6), f"{key}: averaged {k} = {comps[k]!r}, reference {v!r}"
     assert list(last_output.shape) == ref["last_output_shape"]          # Autoencoder: model(x)[0] is ONE image (:114)
     lo = nchw(last_output if last_output.dim() == 4 else last_output[None])
     st = 16 if S == 256 else 4
-    assert_close(lo[:, :, ::st, ::st], arrays[key + "/last_output"], "last_output", l2=5e-2 if key.startswith("cvg") else 2e-3, mx=1e-1)
+    # `last_output` is the forward of the LAST batch through the weights AFTER its update, in train mode, eps drawn from
+    # the stream: (a) it must be exactly what our model computes there (same eps re-injected) ...
+    viz_eps = pkg.synth.eps_list(4 * ne, (B, 64, S // 16, S // 16), SEED, step=100)[3 * ne:]
+    with torch.no_grad():
+        pkg.ops.inject_eps([torch.from_numpy(e) for e in viz_eps])
+        again = model(last_x) if not xy else model(last_x, last_y)
+        again = again if torch.is_tensor(again) else again[0]
+        pkg.ops.inject_eps([])
+    again = nchw(again[0][None] if key == "ae64" else again)
+    assert_close(lo, again, "last_output vs our own forward of the last batch", l2=1e-6, mx=1e-5)
+    # ... and (b) against the reference's.  Two Adam updates sit between the initial weights and this forward, and Adam's
+    # early updates are lr * sign(g): every gradient element at rounding-noise level steps the other way in another fp32
+    # run.  The fixture holds the reference's own float64 epoch: its fp32 `last_output` is 22 % (AE) away from it, so the
+    # bound is calibrated as for the gradients — within 4 x the reference's own fp32-vs-fp64 distance of the fp64 truth.
+    # (What pins the eps order and the averaging is the metric tuple above, which IS well conditioned.)
+    t64, t32 = arrays[key + "/last_output64"], arrays[key + "/last_output"]
+    e_ref = np.linalg.norm(t32 - t64) / np.linalg.norm(t64)
+    e_mine = np.linalg.norm(lo[:, :, ::st, ::st].numpy() - t64) / np.linalg.norm(t64)
+    assert e_mine <= max(2e-3, 4 * e_ref), f"last_output is {e_mine:.3f} from the reference's fp64 epoch (its own fp32 run: {e_ref:.3f})"
     assert last_x.device.type == "cuda" and tuple(last_x.shape) == (B, 3, S, S)
     # and without the flag the second step sees other eps: the averages must move (the fixture pins the reference's order)
     if ne:

@@ -15,19 +15,19 @@ extern "C" const char* vcg_last_error();
 int vcg_pp_set_stamp(void* buf);
 static void stamps(const float* A, const float* Bt, float* C3, int rows, int K, int N, int batches) {
   const int wgs = ((rows + 255) / 256) * (N / 128) * batches;
-  unsigned long long* d; hipMalloc(&d, (size_t)wgs * 8 * 4 * 8); hipMemset(d, 0, (size_t)wgs * 8 * 4 * 8);
+  unsigned long long* d; hipMalloc(&d, (size_t)wgs * 8 * 8 * 8); hipMemset(d, 0, (size_t)wgs * 8 * 8 * 8);
   vcg_pp_set_stamp(d);
   for (int r = 0; r < 3; ++r) vcg_gemm_pp_batched(A, Bt, C3, rows, K, N, batches, 0);
   hipDeviceSynchronize();
   vcg_pp_set_stamp(nullptr);
-  std::vector<unsigned long long> h((size_t)wgs * 8 * 4);
+  std::vector<unsigned long long> h((size_t)wgs * 8 * 8);
   hipMemcpy(h.data(), d, h.size() * 8, hipMemcpyDeviceToHost);
-  double s[2][4] = {};
-  for (int w = 0; w < wgs; ++w) for (int v = 0; v < 8; ++v) for (int q = 0; q < 4; ++q) s[v >= 4][q] += (double)h[((size_t)w * 8 + v) * 4 + q];
-  const double nk = (K + 31) / 32, cnt = (double)wgs * 4;
+  double s[2][8] = {};
+  for (int w = 0; w < wgs; ++w) for (int v = 0; v < 8; ++v) for (int q = 0; q < 8; ++q) s[v >= 4][q] += (double)h[((size_t)w * 8 + v) * 8 + q];
+  const double nk = ((K + 31) / 32 + 1) / 2 * 2, cnt = (double)wgs * 4;
   for (int g = 0; g < 2; ++g)
-    printf("   stamps %s waves: per K-step  matrix phase %7.0f  split+store(+load issue) %7.0f  barrier wait %7.0f  | whole kernel %8.0f shader clocks (%d K-steps)\n",
-           g ? "late (4-7) " : "early (0-3)", s[g][0] / cnt / nk, s[g][1] / cnt / nk, s[g][2] / cnt / nk, s[g][3] / cnt, (int)nk);
+    printf("   stamps %s waves: per K-step  matrix %6.0f  vmcnt wait %6.0f  split+store %6.0f  load issue %6.0f  barrier %6.0f | kernel %8.0f clocks (%d K-steps)\n",
+           g ? "late (4-7) " : "early (0-3)", s[g][0] / cnt / nk, s[g][4] / cnt / nk, s[g][1] / cnt / nk, s[g][5] / cnt / nk, s[g][2] / cnt / nk, s[g][3] / cnt, (int)nk);
   hipFree(d);
 }
 
@@ -107,14 +107,12 @@ static void run(int rows, int K, int N, int batches) {
 }
 
 int main() {
-  run(8192, 512, 256, 16);     // D2 forward
-  run(8712, 256, 512, 16);     // D2 data gradient
-  run(512, 1024, 1024, 16);    // R forward
-  run(648, 1024, 1024, 16);    // R data gradient
+  run(512, 1024, 1024, 16);    // R forward: row pitch 4096 B
+  run(512, 1056, 1024, 16);    // same with a row pitch of 4224 B (33 K-steps): L2 / memory channel camping?
+  run(512, 1088, 1024, 16);    // 4352 B (34 K-steps)
+  run(8192, 512, 256, 16);     // D2 forward: 2048 B
+  run(8192, 544, 256, 16);     // 2176 B (17 K-steps)
   run(2048, 1024, 512, 16);    // D3 forward
-  run(32768, 256, 128, 16);    // D1 forward
-  run(2312, 512, 1024, 16);    // D3 data gradient
-  run(8192, 256, 256, 16);     // U2-like
-  run(300, 100, 128, 3);       // ragged: row and K tails
+  run(2048, 1056, 512, 16);
   return 0;
 }

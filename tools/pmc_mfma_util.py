@@ -39,7 +39,8 @@ def main():
     all_c = sum(k["gui"] / 8 * 1024 for k in per.values())
     print(f"MFMA-pipe utilisation per kernel ({steps} steps in the trace, one stream; kernels that issue MFMAs)")
     print(f"{'kernel':34s} {'launches/step':>13s} {'ms/step':>8s} {'MFMA pipe busy':>15s} {'clock GHz':>10s}")
-    js = {"kernels": {}}
+    import os
+    js = {"head": os.environ.get("VCG_HEAD", "unknown"), "kernels": {}}
     for n, k in rows:
         util = k["mfma"] / max(k["gui"] / 8 * 1024, 1)
         ghz = k["gui"] / 8 / max(k["ns"], 1)

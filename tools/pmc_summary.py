@@ -99,7 +99,10 @@ def main():
     print(f"{'all kernels':34s} {'':8s} {tot['read'] / steps / 1e6:10.1f} {tot['write'] / steps / 1e6:10.1f} {tot['ns'] / steps / 1e6:8.3f} "
           f"{(tot['read'] + tot['write']) / max(tot['ns'], 1):8.0f}")
     print("\nper family (C-ABI call groups)")
-    js = {"steps": steps, "unit": "bytes per step", "note": "read = 2 x FETCH_SIZE x 1024 (gfx950 correction), write = WRITE_SIZE x 1024; "
+    import os
+    js = {"steps": steps, "unit": "bytes per step", "head": os.environ.get("VCG_HEAD", "unknown"), "kernels": {
+        name: {"read": k["read"] / steps, "write": k["write"] / steps, "launches": k["n"] / steps, "ms": k["ns"] / steps / 1e6}
+        for name, k in per.items()}, "note": "read = 2 x FETCH_SIZE x 1024 (gfx950 correction), write = WRITE_SIZE x 1024; "
           "fabric-side counters (Infinity-Cache hits included); profiled with VCG_WGRAD_OVERLAP=0", "families": {}}
     for f, x in fams.items():
         print(f"{f:12s} read {x['read'] / steps / 1e6:9.1f} MB  write {x['write'] / steps / 1e6:9.1f} MB  kernel time {x['ns'] / steps / 1e6:7.3f} ms  "

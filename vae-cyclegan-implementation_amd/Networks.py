@@ -254,8 +254,12 @@ def _metrics_to_host(named, reducer=None):
     return dict(zip(keys, vec.tolist()))
 
 
-def _reduced_step(optimizer, reducer):
-    """optimizer.step(), preceded by the data-parallel gradient exchange when one is attached."""
+def _backward_and_step(loss, optimizer, reducer):
+    """zero_grad -> backward -> [data-parallel gradient exchange, its buckets launched from inside the backward] -> step."""
+    optimizer.zero_grad()
+    if reducer is not None:
+        reducer.begin(optimizer)
+    ops.backward_overlapped(loss)
     if reducer is not None:
         reducer.start(optimizer)
         reducer.finish(optimizer)
@@ -321,13 +325,19 @@ class Autoencoder(_OptimizerStatesMixin, nn.Module):
         output = self(x)
         loss_trans = self.loss_fn(output, y)
         value = float(loss_trans.detach())             # the reference's isnan/isinf guard syncs here too (:357)
-        if math.isnan(value) or math.isinf(value):
+        bad = math.isnan(value) or math.isinf(value)
+        red = self.grad_reducer
+        if red is not None:
+            # data parallel: the decision is collective — a rank that skipped alone would never join the gradient
+            # exchange the others enter, and the replicas would diverge
+            bad = red.any_rank(bad)
+        if bad:
             print("NaN or Inf detected in loss during training step; skipping the update.")
             self.optimizer.zero_grad()
             return {"nan_detected": True, "G_loss": float("nan"), "loss_trans": float("nan"), "total_loss": float("nan")}
-        self.optimizer.zero_grad()
-        ops.backward_overlapped(loss_trans)
-        _reduced_step(self.optimizer, self.grad_reducer)
+        _backward_and_step(loss_trans, self.optimizer, red)
+        if red is not None:
+            value = _metrics_to_host({"loss_trans": loss_trans}, red)["loss_trans"]      # the global-batch mean, as every other model logs
         return {"G_loss": value, "loss_trans": value, "total_loss": value}
 
     def validation_step(self, batch):
@@ -393,9 +403,7 @@ class VariationalAutoencoder(_OptimizerStatesMixin, nn.Module):
     def training_step(self, batch):
         self._check_configured()
         _, G_loss, loss_trans, loss_kl = self._losses(batch)
-        self.optimizer.zero_grad()
-        ops.backward_overlapped(G_loss)
-        _reduced_step(self.optimizer, self.grad_reducer)
+        _backward_and_step(G_loss, self.optimizer, self.grad_reducer)
         return _metrics_to_host({"G_loss": G_loss, "loss_trans": loss_trans, "loss_kl": loss_kl}, self.grad_reducer)
 
     def validation_step(self, batch):
@@ -575,28 +583,28 @@ class CycleVAEGAN(nn.Module):
         red = self.grad_reducer
         self.optimizer_G.zero_grad()
         t, _, _ = self._generator_losses(x, y)
+        if red is not None:
+            red.begin(self.optimizer_G)          # F+G buckets are all-reduced from inside the backward as they complete
         # generator gradients reach F and G only (the discriminators contribute their data gradient)
         with ops.no_wgrad(d_params):
             ops.backward_overlapped(t["G_loss"], inputs=g_params, retain_graph=True)
         if red is not None:
-            red.start(self.optimizer_G)          # F+G all-reduce runs under the D backward below
+            red.start(self.optimizer_G)          # whatever is left; it runs under the D backward below
         # discriminator gradients from the same activations reach DX and DY only — what detaching
         # G(x), F(y) achieves in the reference (:2028-2029).  Neither this backward nor D_loss reads a
         # generator parameter, so running it before optimizer_G.step() changes nothing.
         self.optimizer_D.zero_grad()
+        if red is not None:
+            red.begin(self.optimizer_D)
         with ops.no_dgrad([self.DX.model[0]._spec, self.DY.model[0]._spec]):
-            # data parallel: the F+G exchange is in flight here, so this backward stays on the one stream it was
-            # ordered against (no side stream beside a running collective)
-            ops.backward_overlapped(t["D_loss"], overlap=red is None, inputs=d_params)
+            ops.backward_overlapped(t["D_loss"], inputs=d_params)
         if red is not None:
             red.start(self.optimizer_D)
             red.finish(self.optimizer_G)
-        self.optimizer_G.step(repack=red is None)
+        self.optimizer_G.step()
         if red is not None:
             red.finish(self.optimizer_D)
-        self.optimizer_D.step(repack=red is None)
-        if red is not None:
-            ops.repack_async(g_params + d_params)        # both exchanges are done: repack on the side stream now
+        self.optimizer_D.step()
         return self._metrics(t, with_means=True)
 
     def validation_step(self, batch):
@@ -747,9 +755,7 @@ class _CycleNoGAN(_OptimizerStatesMixin, nn.Module):
     def training_step(self, batch):
         self._check_configured()
         t, _, _ = self._losses(batch)
-        self.optimizer.zero_grad()
-        ops.backward_overlapped(t["G_loss"])
-        _reduced_step(self.optimizer, self.grad_reducer)
+        _backward_and_step(t["G_loss"], self.optimizer, self.grad_reducer)
         host = _metrics_to_host(t, self.grad_reducer)
         m = self._ordered(host)
         if self.paired:
@@ -881,9 +887,7 @@ class DoubleAutoencoder(_OptimizerStatesMixin, nn.Module):
         if self.optimizer is None:
             raise ValueError("Optimizer has not been configured yet.")
         t, _, _ = self._losses(batch)
-        self.optimizer.zero_grad()
-        ops.backward_overlapped(t["G_loss"])
-        _reduced_step(self.optimizer, self.grad_reducer)
+        _backward_and_step(t["G_loss"], self.optimizer, self.grad_reducer)
         h = _metrics_to_host(t, self.grad_reducer)
         return {"G_loss": h["G_loss"], "loss_recon_A": h["loss_recon_A"], "loss_recon_B": h["loss_recon_B"], "total_loss": h["G_loss"]}
 
@@ -973,9 +977,7 @@ class DoubleVariationalAutoencoder(_OptimizerStatesMixin, nn.Module):
         if self.optimizer is None:
             raise ValueError("Optimizer has not been configured yet.")
         t, _, _ = self._losses(batch)
-        self.optimizer.zero_grad()
-        ops.backward_overlapped(t["G_loss"])
-        _reduced_step(self.optimizer, self.grad_reducer)
+        _backward_and_step(t["G_loss"], self.optimizer, self.grad_reducer)
         h = _metrics_to_host(t, self.grad_reducer)
         return {"G_loss": h["G_loss"], "loss_recon_A": h["loss_recon_A"], "loss_recon_B": h["loss_recon_B"], "loss_kl": h["loss_kl"],
                 "loss_kl_A": h["loss_kl_A"], "loss_kl_B": h["loss_kl_B"], "total_loss": h["G_loss"]}
@@ -1031,22 +1033,24 @@ class _SingleGAN(nn.Module):
         g_params, d_params = self.optimizer_G.params, self.optimizer_D.params
         red = self.grad_reducer
         self.optimizer_G.zero_grad()
+        if red is not None:
+            red.begin(self.optimizer_G)
         with ops.no_wgrad(d_params):
             ops.backward_overlapped(t["G_loss"], inputs=g_params, retain_graph=True)
         if red is not None:
             red.start(self.optimizer_G)
         self.optimizer_D.zero_grad()
+        if red is not None:
+            red.begin(self.optimizer_D)
         with ops.no_dgrad([self.D.model[0]._spec]):
-            ops.backward_overlapped(t.get("D_loss_backward", t["D_loss"]), overlap=red is None, inputs=d_params)
+            ops.backward_overlapped(t.get("D_loss_backward", t["D_loss"]), inputs=d_params)
         if red is not None:
             red.start(self.optimizer_D)
             red.finish(self.optimizer_G)
-        self.optimizer_G.step(repack=red is None)
+        self.optimizer_G.step()
         if red is not None:
             red.finish(self.optimizer_D)
-        self.optimizer_D.step(repack=red is None)
-        if red is not None:
-            ops.repack_async(g_params + d_params)
+        self.optimizer_D.step()
 
 
 class AEGAN(_SingleGAN):

@@ -1915,8 +1915,11 @@ int vcg_gemm_batched(const float* A, const float* B, float* C, int rows, int K, 
   int bm, bn, nsplit, kt_per;
   gemm_plan(rows, Ncols, (K + BK - 1) / BK, false, bm, bn, nsplit, kt_per, batches, false, K <= 2048);
   dim3 grid((rows + bm - 1) / bm, (Ncols + bn - 1) / bn, batches);
-  if (bm == 128 && bn == 128 && K <= 2048) hipLaunchKernelGGL((k_conv_fwd<128, 128, 2, false>), grid, dim3(256), 0, st, p);
-  else DISPATCH_FWD(bm, bn, grid, st, p);
+  {
+    VcgProfScope prof("k_conv_fwd<fp32 MFMA>", 2.0 * rows * (double)K * Ncols * batches, st);
+    if (bm == 128 && bn == 128 && K <= 2048) hipLaunchKernelGGL((k_conv_fwd<128, 128, 2, false>), grid, dim3(256), 0, st, p);
+    else DISPATCH_FWD(bm, bn, grid, st, p);
+  }
   VCG_LAUNCH_CHECK("vcg_gemm_batched");
   return 0;
 }
@@ -1942,7 +1945,10 @@ int vcg_fwd_launch(const ConvGeom& g, const float* x, const float* wf, float* y,
   int bm, bn, nsplit, kt_per;
   gemm_plan(g.M, g.Cout, (g.K + BK - 1) / BK, false, bm, bn, nsplit, kt_per, 1, true);
   dim3 grid((g.M + bm - 1) / bm, (g.Cout + bn - 1) / bn, 1);
-  DISPATCH_FWD(bm, bn, grid, st, p);
+  {
+    VcgProfScope prof("k_conv_fwd<fp32 MFMA>", 2.0 * g.M * (double)g.K * g.Cout, st);
+    DISPATCH_FWD(bm, bn, grid, st, p);
+  }
   VCG_LAUNCH_CHECK("vcg_conv_fwd(raw)");
   return 0;
 }
@@ -2033,12 +2039,17 @@ extern "C" int vcg_conv_fwd(const float* x, const float* wf, const float* bias, 
   }
   dim3 grid((g.M + bm - 1) / bm, (g.Cout + bn - 1) / bn, nsplit);
   hipStream_t st = (hipStream_t)stream;
+  const double gemm_flops = 2.0 * g.M * (double)g.K * g.Cout;
   if (bm == 128 && bn >= 64 && wft_wanted(g)) {          // split-operand bf16 kernel, B^T from the WfT region of the pack
     p.b = wf + wft_offset(g);
+    VcgProfScope prof(bn == 128 ? "k_conv_fwd_split<128>" : "k_conv_fwd_split<64>", gemm_flops, st);
     if (bn == 128) hipLaunchKernelGGL((k_conv_fwd_split<128>), grid, dim3(256), 0, st, p);
     else hipLaunchKernelGGL((k_conv_fwd_split<64>), grid, dim3(256), 0, st, p);
-  } else if (bm == 128 && bn == 128 && g.K <= 2048) hipLaunchKernelGGL((k_conv_fwd<128, 128, 2, false>), grid, dim3(256), 0, st, p);
-  else DISPATCH_FWD(bm, bn, grid, st, p);
+  } else {
+    VcgProfScope prof("k_conv_fwd<fp32 MFMA>", gemm_flops, st);
+    if (bm == 128 && bn == 128 && g.K <= 2048) hipLaunchKernelGGL((k_conv_fwd<128, 128, 2, false>), grid, dim3(256), 0, st, p);
+    else DISPATCH_FWD(bm, bn, grid, st, p);
+  }
   if (nsplit > 1)
     hipLaunchKernelGGL(k_splitk_finish, dim3(ew_grid((size_t)g.M * g.Cout / 4)), dim3(256), 0, st, (const float*)ws, bias,
                        y, (size_t)g.M, g.Cout, nsplit, g.cout_log, g.act);
@@ -2099,11 +2110,18 @@ extern "C" int vcg_conv_dgrad(const float* dy, const float* wf, float* dx, const
   }
   dim3 grid((p.Mc + bm - 1) / bm, (p.NB + bn - 1) / bn, nsplit > 1 ? nsplit : g.stride * g.stride);
   hipStream_t st = (hipStream_t)stream;
-  if (bm == 128 && bn >= 64) {                            // split-operand bf16 kernel
-    if (bn == 128) hipLaunchKernelGGL((k_conv_dgrad_split<128, 2>), grid, dim3(256), 0, st, p);
-    else hipLaunchKernelGGL((k_conv_dgrad_split<64, 2>), grid, dim3(256), 0, st, p);
-  } else if (bn == 32) hipLaunchKernelGGL((k_conv_dgrad_split<32, 1>), grid, dim3(256), 0, st, p);
-  else DISPATCH_DGRAD(bm, bn, grid, st, p);
+  {
+    const double gemm_flops = 2.0 * g.M * (double)g.K * g.Cout;   // stride 2: the parity classes together visit every tap once
+    const bool split = (bm == 128 && bn >= 64) || bn == 32;
+    VcgProfScope prof(!split ? "k_conv_dgrad<fp32 MFMA>" : bn == 128 ? "k_conv_dgrad_split<128, 2>" : bn == 64 ? "k_conv_dgrad_split<64, 2>"
+                                                                                                             : "k_conv_dgrad_split<32, 1>",
+                      gemm_flops, st);
+    if (bm == 128 && bn >= 64) {                            // split-operand bf16 kernel
+      if (bn == 128) hipLaunchKernelGGL((k_conv_dgrad_split<128, 2>), grid, dim3(256), 0, st, p);
+      else hipLaunchKernelGGL((k_conv_dgrad_split<64, 2>), grid, dim3(256), 0, st, p);
+    } else if (bn == 32) hipLaunchKernelGGL((k_conv_dgrad_split<32, 1>), grid, dim3(256), 0, st, p);
+    else DISPATCH_DGRAD(bm, bn, grid, st, p);
+  }
   if (nsplit > 1)
     hipLaunchKernelGGL(k_splitk_finish, dim3(ew_grid((size_t)g.N * g.H * g.W * g.Cin / 4)), dim3(256), 0, st,
                        (const float*)ws, (const float*)nullptr, dx, (size_t)g.N * g.H * g.W, g.Cin, nsplit, g.Cin,
@@ -2207,10 +2225,14 @@ int vcg_wino_wgrad_core(const ConvGeom& g, const float* V, const float* dM, int 
   p.sk_ntr_pb = wp.ntr / 16;
   p.fd_sklen = make_fastdiv((uint32_t)wp.len);
   dim3 grid(wp.grid);
-  if (wp.bm == 128 && wp.bn == 128) hipLaunchKernelGGL(k_conv_wgrad_split<128>, grid, dim3(256), 0, st, p);        // split-operand bf16
-  else if (wp.bm == 128 && wp.bn == 64) hipLaunchKernelGGL(k_conv_wgrad_split<64>, grid, dim3(256), 0, st, p);
-  else if (wp.bm == 64 && wp.bn == 128) hipLaunchKernelGGL((k_conv_wgrad<64, 128>), grid, dim3(256), 0, st, p);
-  else hipLaunchKernelGGL((k_conv_wgrad<64, 64>), grid, dim3(256), 0, st, p);
+  {
+    VcgProfScope prof(wp.bm == 128 ? (wp.bn == 128 ? "k_conv_wgrad_split<128>" : "k_conv_wgrad_split<64>") : "k_conv_wgrad<fp32 MFMA>",
+                      2.0 * 16 * (double)T * q.K * q.Cout, st);
+    if (wp.bm == 128 && wp.bn == 128) hipLaunchKernelGGL(k_conv_wgrad_split<128>, grid, dim3(256), 0, st, p);        // split-operand bf16
+    else if (wp.bm == 128 && wp.bn == 64) hipLaunchKernelGGL(k_conv_wgrad_split<64>, grid, dim3(256), 0, st, p);
+    else if (wp.bm == 64 && wp.bn == 128) hipLaunchKernelGGL((k_conv_wgrad<64, 128>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((k_conv_wgrad<64, 64>), grid, dim3(256), 0, st, p);
+  }
   VCG_LAUNCH_CHECK("vcg_conv_wgrad(winograd gemm)");
   hipLaunchKernelGGL(k_wino_wgrad_reduce, dim3(g.Cout / 64, (g.Cin + 7) / 8, g.ups * g.ups), dim3(256), 0, st,
                      (const float*)ws, gw_oihw, p, g.Cin, g.ups, g.cin_log, g.cout_log);
@@ -2290,11 +2312,15 @@ extern "C" int vcg_conv_wgrad(const float* x, const float* dy, float* gw_oihw, f
   p.fd_sklen = make_fastdiv((uint32_t)wp.len);
   dim3 grid(wp.grid);
   hipStream_t st = (hipStream_t)stream;
-  if (bm == 256) hipLaunchKernelGGL((k_conv_wgrad<256, 128, 512>), grid, dim3(512), 0, st, p);
-  else if (bm == 128 && bn == 128) hipLaunchKernelGGL(k_conv_wgrad_split<128>, grid, dim3(256), 0, st, p);     // split-operand bf16
-  else if (bm == 128 && bn == 64) hipLaunchKernelGGL(k_conv_wgrad_split<64>, grid, dim3(256), 0, st, p);
-  else if (bm == 64 && bn == 128) hipLaunchKernelGGL((k_conv_wgrad<64, 128>), grid, dim3(256), 0, st, p);
-  else hipLaunchKernelGGL((k_conv_wgrad<64, 64>), grid, dim3(256), 0, st, p);
+  {
+    VcgProfScope prof(bm == 128 ? (bn == 128 ? "k_conv_wgrad_split<128>" : "k_conv_wgrad_split<64>") : "k_conv_wgrad<fp32 MFMA>",
+                      2.0 * g.M * (double)g.K * g.Cout, st);
+    if (bm == 256) hipLaunchKernelGGL((k_conv_wgrad<256, 128, 512>), grid, dim3(512), 0, st, p);
+    else if (bm == 128 && bn == 128) hipLaunchKernelGGL(k_conv_wgrad_split<128>, grid, dim3(256), 0, st, p);     // split-operand bf16
+    else if (bm == 128 && bn == 64) hipLaunchKernelGGL(k_conv_wgrad_split<64>, grid, dim3(256), 0, st, p);
+    else if (bm == 64 && bn == 128) hipLaunchKernelGGL((k_conv_wgrad<64, 128>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((k_conv_wgrad<64, 64>), grid, dim3(256), 0, st, p);
+  }
   VCG_LAUNCH_CHECK("vcg_conv_wgrad");
   const size_t totalw = (size_t)g.K * g.Cout;
   const size_t slab_bytes = (((size_t)nsplit * totalw * sizeof(float) + 255) / 256) * 256;

@@ -27,9 +27,31 @@ struct GemmPPParams {
   size_t c_bstride;
 };
 
-__device__ __forceinline__ float4 pp_bload4(__amdgpu_buffer_rsrc_t r, uint32_t off) {
-  u32x4p v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0);
-  return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+// The staging loads are issued from inline asm so that hipcc does not count them: with two tiles in flight it waits
+// vmcnt(0) before the first use of the OLDER tile (it cannot tell the two register sets' loads apart across the loop
+// back-edge), which drains the newer tile too and turns a two-step prefetch back into a one-step one.  The waits are
+// therefore ours: pp_wait<N> leaves the N youngest loads in flight and names every destination register as an operand,
+// so that no use of them can be scheduled above it (cdna_hip_programming.md §5.7, item 1, form (ii)).
+__device__ __forceinline__ u32x4p pp_srd(const float* ptr, uint32_t bytes) {
+  const uint64_t a = (uint64_t)ptr;
+  u32x4p r;
+  r.x = __builtin_amdgcn_readfirstlane((uint32_t)a);
+  r.y = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32) & 0xFFFFu);
+  r.z = __builtin_amdgcn_readfirstlane(bytes);
+  r.w = 0x00020000u;
+  return r;
+}
+__device__ __forceinline__ f32x4 pp_aload4(u32x4p srd, uint32_t off) {
+  f32x4 dst;
+  asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(dst) : "v"(off), "s"(srd) : "memory");
+  return dst;
+}
+template <int N>
+__device__ __forceinline__ void pp_wait(f32x4 (&a)[4], f32x4 (&b)[2]) {
+  f32x4 x0 = a[0], x1 = a[1], x2 = a[2], x3 = a[3], y0 = b[0], y1 = b[1];
+  asm volatile("s_waitcnt vmcnt(%6)" : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(y0), "+v"(y1) : "n"(N) : "memory");
+  __builtin_amdgcn_sched_barrier(0);
+  a[0] = x0; a[1] = x1; a[2] = x2; a[3] = x3; b[0] = y0; b[1] = y1;
 }
 #define PP_OOB 0x80000000u
 
@@ -65,26 +87,14 @@ __global__ __launch_bounds__(512, 2) void k_gemm_pp(GemmPPParams p) {
     nt = (int)(l - (uint32_t)mt * gridDim.y);
   }
   const int m0 = mt * BM, n0 = nt * BN;
-  const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)(p.a + (size_t)zb * p.a_bstride), 0, (int)p.a_bytes, 0x00020000),
-                               rb = __builtin_amdgcn_make_buffer_rsrc((void*)(p.bt + (size_t)zb * p.b_bstride), 0, (int)p.b_bytes, 0x00020000);
+  const u32x4p ra = pp_srd(p.a + (size_t)zb * p.a_bstride, p.a_bytes), rb = pp_srd(p.bt + (size_t)zb * p.b_bstride, p.b_bytes);
   const int s_row = tid >> 3, s_u = tid & 7;                    // staging: row (+64 i), k quad
-  uint32_t aoff[AR], boff[BR];
-#pragma unroll
-  for (int i = 0; i < AR; ++i) {
-    const int r = m0 + s_row + 64 * i;
-    aoff[i] = r < p.rows ? (uint32_t)(((size_t)r * p.K + s_u * 4) * 4) : PP_OOB;
-  }
-#pragma unroll
-  for (int i = 0; i < BR; ++i) {
-    const int r = n0 + s_row + 64 * i;
-    boff[i] = r < p.N ? (uint32_t)(((size_t)r * p.K + s_u * 4) * 4) : PP_OOB;
-  }
-  uint32_t soff[AR];
-#pragma unroll
-  for (int i = 0; i < AR; ++i) {
-    const int r = s_row + 64 * i;
-    soff[i] = (uint32_t)(r * 64 + (((s_u >> 1) ^ ((r >> 2) & 3)) << 4) + ((s_u & 1) << 3));
-  }
+  // Rows past the operand fall off the end of the buffer (a_bytes = rows * K * 4) and read as zeros, so one base offset
+  // per operand and a scalar row stride are all the address state there is (registers are what this kernel is short of).
+  const uint32_t aoff0 = (uint32_t)(((size_t)(m0 + s_row) * p.K + s_u * 4) * 4), boff0 = (uint32_t)(((size_t)(n0 + s_row) * p.K + s_u * 4) * 4);
+  const uint32_t rstride = (uint32_t)p.K * 256u;                // 64 rows
+  // LDS byte offset of this thread's quad in a piece image; row + 64 i keeps the swizzle term, so image offsets are + 4096 i
+  const uint32_t soff0 = (uint32_t)(s_row * 64 + (((s_u >> 1) ^ ((s_row >> 2) & 3)) << 4) + ((s_u & 1) << 3));
 
   f32x16 acc[MI][NI], lo[MI][NI];
 #pragma unroll
@@ -94,39 +104,45 @@ __global__ __launch_bounds__(512, 2) void k_gemm_pp(GemmPPParams p) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = lo[i][j][e] = 0.f;
 
-  float4 va[AR], vb[BR];
+  // Two staging register sets: tile t lives in set t & 1 from its loads' issue (during step t - 3) to its split (step
+  // t - 1), so every load has two full K-steps to return.  With one set the loads of the waves that stage first had only
+  // their own matrix phase (~1 us) to come back — under load a miss beyond the L2 takes 2-3 us, and in-kernel stamps
+  // showed those waves stalled for two thirds of every K-step (tools/gemm_split_probe.hip, profiles/r02_gemm_pp_stamps.txt).
+#ifdef VCG_PP_STAMP
+  unsigned long long st_mma = 0, st_stage = 0, st_bar = 0, st_wait = 0, st_issue = 0;
+  const unsigned long long t_begin = PP_T();
+#endif
+  f32x4 va0[AR], vb0[BR], va1[AR], vb1[BR];
   const int nkt = (p.K + 31) / 32;
-  auto load_tiles = [&](int kt) {
-    const bool kv = kt * 32 + s_u * 4 < p.K;                    // K is a multiple of 4
+  auto load_tiles = [&](f32x4 (&va)[AR], f32x4 (&vb)[BR], int kt) {
+    const bool kv = kt * 32 + s_u * 4 < p.K;                    // K is a multiple of 4; also false for every kt >= nkt
+    const uint32_t ao = kv ? aoff0 + (uint32_t)kt * 128u : PP_OOB, bo = kv ? boff0 + (uint32_t)kt * 128u : PP_OOB;
 #pragma unroll
-    for (int i = 0; i < AR; ++i) va[i] = pp_bload4(ra, (kv && aoff[i] != PP_OOB) ? aoff[i] + (uint32_t)kt * 128u : PP_OOB);
+    for (int i = 0; i < AR; ++i) va[i] = pp_aload4(ra, kv ? ao + (uint32_t)i * rstride : PP_OOB);
 #pragma unroll
-    for (int i = 0; i < BR; ++i) vb[i] = pp_bload4(rb, (kv && boff[i] != PP_OOB) ? boff[i] + (uint32_t)kt * 128u : PP_OOB);
+    for (int i = 0; i < BR; ++i) vb[i] = pp_aload4(rb, kv ? bo + (uint32_t)i * rstride : PP_OOB);
   };
-  auto store_tiles = [&](int buf) {
+  auto store_tiles = [&](const f32x4 (&va)[AR], const f32x4 (&vb)[BR], int buf) {
 #pragma unroll
     for (int i = 0; i < AR; ++i) {
       uint2 h, m, l;
-      split4(va[i], h, m, l);
-      *reinterpret_cast<uint2*>(&As[buf][0][soff[i]]) = h;
-      *reinterpret_cast<uint2*>(&As[buf][1][soff[i]]) = m;
-      *reinterpret_cast<uint2*>(&As[buf][2][soff[i]]) = l;
+      split4(make_float4(va[i][0], va[i][1], va[i][2], va[i][3]), h, m, l);
+      *reinterpret_cast<uint2*>(&As[buf][0][soff0 + 4096 * i]) = h;
+      *reinterpret_cast<uint2*>(&As[buf][1][soff0 + 4096 * i]) = m;
+      *reinterpret_cast<uint2*>(&As[buf][2][soff0 + 4096 * i]) = l;
     }
 #pragma unroll
     for (int i = 0; i < BR; ++i) {
       uint2 h, m, l;
-      split4(vb[i], h, m, l);
-      *reinterpret_cast<uint2*>(&Bs[buf][0][soff[i]]) = h;
-      *reinterpret_cast<uint2*>(&Bs[buf][1][soff[i]]) = m;
-      *reinterpret_cast<uint2*>(&Bs[buf][2][soff[i]]) = l;
+      split4(make_float4(vb[i][0], vb[i][1], vb[i][2], vb[i][3]), h, m, l);
+      *reinterpret_cast<uint2*>(&Bs[buf][0][soff0 + 4096 * i]) = h;
+      *reinterpret_cast<uint2*>(&Bs[buf][1][soff0 + 4096 * i]) = m;
+      *reinterpret_cast<uint2*>(&Bs[buf][2][soff0 + 4096 * i]) = l;
     }
   };
-  uint32_t fa[MI], fb[NI];
-  int sa[MI], sb[NI];
-#pragma unroll
-  for (int i = 0; i < MI; ++i) { const int r = wm * 64 + i * 32 + l31; fa[i] = (uint32_t)(r * 64); sa[i] = (r >> 2) & 3; }
-#pragma unroll
-  for (int j = 0; j < NI; ++j) { const int r = wn * 64 + j * 32 + l31; fb[j] = (uint32_t)(r * 64); sb[j] = (r >> 2) & 3; }
+  // fragment rows: wave row block + 32 i + l31; + 32 i keeps the swizzle term, so fragment offsets are + 2048 i
+  const uint32_t fa0 = (uint32_t)((wm * 64 + l31) * 64), fb0 = (uint32_t)((wn * 64 + l31) * 64);
+  const int sa0 = (l31 >> 2) & 3;                               // (row >> 2) & 3 for both operands (wave blocks are multiples of 64)
   auto mma = [&](int buf) {
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
@@ -134,9 +150,9 @@ __global__ __launch_bounds__(512, 2) void k_gemm_pp(GemmPPParams p) {
 #pragma unroll
       for (int pc = 0; pc < 3; ++pc) {
 #pragma unroll
-        for (int i = 0; i < MI; ++i) a[pc][i] = *reinterpret_cast<const bf16x8*>(&As[buf][pc][fa[i] + (((2 * s + lh) ^ sa[i]) << 4)]);
+        for (int i = 0; i < MI; ++i) a[pc][i] = *reinterpret_cast<const bf16x8*>(&As[buf][pc][fa0 + 2048 * i + (((2 * s + lh) ^ sa0) << 4)]);
 #pragma unroll
-        for (int j = 0; j < NI; ++j) b[pc][j] = *reinterpret_cast<const bf16x8*>(&Bs[buf][pc][fb[j] + (((2 * s + lh) ^ sb[j]) << 4)]);
+        for (int j = 0; j < NI; ++j) b[pc][j] = *reinterpret_cast<const bf16x8*>(&Bs[buf][pc][fb0 + 2048 * j + (((2 * s + lh) ^ sa0) << 4)]);
       }
 #pragma unroll
       for (int i = 0; i < MI; ++i)
@@ -154,39 +170,56 @@ __global__ __launch_bounds__(512, 2) void k_gemm_pp(GemmPPParams p) {
     }
   };
 
-#ifdef VCG_PP_STAMP
-  unsigned long long st_mma = 0, st_stage = 0, st_bar = 0;
-  const unsigned long long t_begin = PP_T();
-#endif
-  load_tiles(0);
-  store_tiles(0);
-  if (nkt > 1) load_tiles(1);                 // both halves enter the loop holding the next tile in registers
+  load_tiles(va0, vb0, 0);
+  pp_wait<0>(va0, vb0);
+  store_tiles(va0, vb0, 0);
+  load_tiles(va1, vb1, 1);                    // past the last tile every offset is out of bounds: zeros, never multiplied
+  load_tiles(va0, vb0, 2);
+  pp_wait<0>(va1, vb1);                       // the loop is entered with landed registers (any copy hipcc places at the
+  pp_wait<0>(va0, vb0);                       //  loop's entry must not read a register whose load is still in flight)
   __syncthreads();
-  for (int kt = 0; kt < nkt; ++kt) {
-    const int cur = kt & 1;
+  // One K-step.  `va`/`vb` is the register set of tile kt + 1 (parity known at compile time: the loop is unrolled by
+  // two).  Its reload — tile kt + 3 — is issued at ONE program point for both wave halves, the end of the step, and
+  // unconditionally, so that the asm loads' destinations never meet another definition in a phi (hipcc would resolve
+  // that with v_mov copies of registers whose data has not landed).
+  auto step = [&](f32x4 (&va)[AR], f32x4 (&vb)[BR], int kt, int cur) {
     const unsigned long long t0 = PP_T();
+    // tile kt + 1's loads are the older ones; tile kt + 2's (the other set, 6 loads) stay in flight across this wait
+    unsigned long long tw = t0;
     if (late) {
-      if (kt + 1 < nkt) store_tiles(cur ^ 1);
-      if (kt + 2 < nkt) load_tiles(kt + 2);
+      pp_wait<6>(va, vb);
+      tw = PP_T();
+      store_tiles(va, vb, cur ^ 1);
     }
     const unsigned long long t1 = PP_T();
-    mma(cur);                                   // one code copy: the accumulators live in one place
+    mma(cur);                                   // one code copy per parity: the accumulators live in one place
     const unsigned long long t2 = PP_T();
+    unsigned long long tw2 = t2;
     if (!late) {
-      if (kt + 1 < nkt) store_tiles(cur ^ 1);
-      if (kt + 2 < nkt) load_tiles(kt + 2);
+      pp_wait<6>(va, vb);
+      tw2 = PP_T();
+      store_tiles(va, vb, cur ^ 1);
     }
+    const unsigned long long ts = PP_T();
+    load_tiles(va, vb, kt + 3);
     const unsigned long long t3 = PP_T();
     __syncthreads();
 #ifdef VCG_PP_STAMP
     const unsigned long long t4 = PP_T();
-    st_mma += t2 - t1; st_stage += (t1 - t0) + (t3 - t2); st_bar += t4 - t3;
+    st_mma += t2 - t1; st_stage += (t1 - tw) + (ts - tw2); st_bar += t4 - t3; st_wait += (tw - t0) + (tw2 - t2); st_issue += t3 - ts;
+#else
+    (void)t0; (void)t1; (void)t2; (void)t3; (void)tw; (void)tw2; (void)ts;
 #endif
+  };
+  for (int kt = 0; kt < nkt; kt += 2) {        // a step past the last tile stores zeros into the idle image: harmless
+    step(va1, vb1, kt, 0);
+    step(va0, vb0, kt + 1, 1);
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #ifdef VCG_PP_STAMP
   if (g_pp_stamp && lane == 0) {
-    unsigned long long* o = g_pp_stamp + 4ull * ((blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) * 8 + wid);
-    o[0] = st_mma; o[1] = st_stage; o[2] = st_bar; o[3] = PP_T() - t_begin;
+    unsigned long long* o = g_pp_stamp + 8ull * ((blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) * 8 + wid);
+    o[0] = st_mma; o[1] = st_stage; o[2] = st_bar; o[3] = PP_T() - t_begin; o[4] = st_wait; o[5] = st_issue;
   }
 #endif
   float* const dst = p.c + (size_t)zb * p.c_bstride;
@@ -219,6 +252,7 @@ int vcg_gemm_pp_batched(const float* A, const float* Bt, float* C, int rows, int
   p.a_bstride = (uint32_t)((size_t)rows * K); p.b_bstride = (uint32_t)((size_t)N * K);
   p.c_bstride = (size_t)rows * N;
   dim3 grid((rows + 255) / 256, N / 128, batches);
+  VcgProfScope prof("k_gemm_pp", 2.0 * rows * (double)K * N * batches, st);
   hipLaunchKernelGGL(k_gemm_pp, grid, dim3(512), 0, st, p);
   VCG_LAUNCH_CHECK("vcg_gemm_pp_batched");
   return 0;

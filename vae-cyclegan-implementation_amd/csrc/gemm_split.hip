@@ -189,6 +189,7 @@ int vcg_gemm_split_batched(const float* A, const float* Bt, float* C, int rows, 
   p.c_bstride = (size_t)rows * N;
   const int bn = (N % 128 == 0) ? 128 : 64;
   dim3 grid((rows + 127) / 128, N / bn, batches);
+  VcgProfScope prof(bn == 128 ? "k_gemm_split<128>" : "k_gemm_split<64>", 2.0 * rows * (double)K * N * batches, st);
   if (bn == 128) hipLaunchKernelGGL(k_gemm_split<128>, grid, dim3(256), 0, st, p);
   else hipLaunchKernelGGL(k_gemm_split<64>, grid, dim3(256), 0, st, p);
   VCG_LAUNCH_CHECK("vcg_gemm_split_batched");

@@ -18,6 +18,56 @@ void vcg_set_error(const char* fmt, ...) {
 extern "C" const char* vcg_last_error(void) { return g_err; }
 extern "C" int vcg_abi_version(void) { return VCG_ABI_VERSION; }
 
+// ---- per-device-kernel timing (diagnostic: bench.py's roofline object) -------------------------------------------
+// The training path never enables it.  Enabled, every MFMA kernel launch records two HIP events on its own launch
+// stream; vcg_profile_read waits for them (the ONE place this library synchronises), sums time / FLOPs / launches per
+// kernel name and returns the table as text.
+#include <map>
+#include <string>
+#include <vector>
+bool g_vcg_prof_on = false;
+namespace {
+struct ProfRec { const char* name; double flops; hipEvent_t e0, e1; };
+std::vector<ProfRec> g_prof;
+}
+void vcg_prof_begin(const char* kernel, double flops, hipStream_t st) {
+  ProfRec r; r.name = kernel; r.flops = flops;
+  if (hipEventCreate(&r.e0) != hipSuccess || hipEventCreate(&r.e1) != hipSuccess) return;
+  hipEventRecord(r.e0, st);
+  g_prof.push_back(r);
+}
+void vcg_prof_end(hipStream_t st) {
+  if (!g_prof.empty()) hipEventRecord(g_prof.back().e1, st);
+}
+extern "C" int vcg_profile_enable(int on) {
+  g_vcg_prof_on = on != 0;
+  return 0;
+}
+extern "C" long vcg_profile_read(char* buf, size_t cap) {
+  struct Agg { double ms = 0, flops = 0; long n = 0; };
+  std::map<std::string, Agg> agg;
+  for (auto& r : g_prof) {
+    float ms = 0.f;
+    if (hipEventSynchronize(r.e1) == hipSuccess && hipEventElapsedTime(&ms, r.e0, r.e1) == hipSuccess) {
+      Agg& a = agg[r.name];
+      a.ms += ms; a.flops += r.flops; a.n += 1;
+    }
+    hipEventDestroy(r.e0); hipEventDestroy(r.e1);
+  }
+  g_prof.clear();
+  std::string out;
+  char line[256];
+  for (auto& kv : agg) {
+    snprintf(line, sizeof line, "%s\t%ld\t%.6f\t%.6e\n", kv.first.c_str(), kv.second.n, kv.second.ms, kv.second.flops);
+    out += line;
+  }
+  if (!buf || cap == 0) return (long)out.size() + 1;
+  const size_t n = out.size() < cap - 1 ? out.size() : cap - 1;
+  memcpy(buf, out.data(), n);
+  buf[n] = 0;
+  return (long)n;
+}
+
 static int ew_blocks(size_t work) {
   size_t b = (work + 255) / 256;
   if (b > 2048) b = 2048;
@@ -562,10 +612,11 @@ extern "C" int vcg_fullmap_wgrad(const float* g, const float* x, const float* ws
 // One launch over the model's flat parameter buffer: 28 B/param of HBM traffic, float4 per lane.
 __global__ __launch_bounds__(256) void k_adam(float* __restrict__ p, const float* __restrict__ g,
                                               float* __restrict__ m, float* __restrict__ v, size_t n,
-                                              float step_size, float b1, float b2, float eps, float bc2_sqrt,
+                                              float step_size, float b2, float w1, float w2, float eps, float bc2_sqrt,
                                               float gscale) {
+  // w1 = 1 - beta1 and w2 = 1 - beta2 arrive rounded from DOUBLE, as torch passes them (lerp_ weight, addcmul_ value):
+  // 1.f - 0.999f is 1.3e-5 away from float(1 - 0.999), and that relative error would sit in every exp_avg_sq
   const size_t n4 = n / 4;
-  const float w1 = 1.f - b1, w2 = 1.f - b2;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
     float4 pv = reinterpret_cast<float4*>(p)[i];
     float4 gv = reinterpret_cast<const float4*>(g)[i];
@@ -595,12 +646,12 @@ __global__ __launch_bounds__(256) void k_adam(float* __restrict__ p, const float
       v[i] = vv;
     }
 }
-extern "C" int vcg_adam_step(float* p, const float* g, float* m, float* v, size_t n, float step_size, float beta1,
-                             float beta2, float eps, float bc2_sqrt, float grad_scale, void* stream) {
+extern "C" int vcg_adam_step(float* p, const float* g, float* m, float* v, size_t n, float step_size, float beta1, float beta2,
+                             float one_minus_beta1, float one_minus_beta2, float eps, float bc2_sqrt, float grad_scale, void* stream) {
   VCG_CHECK_ARG(p && g && m && v, "vcg_adam_step: null pointer");
   if (n == 0) return 0;
   hipLaunchKernelGGL(k_adam, dim3(ew_blocks(n / 4 + 1)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, step_size,
-                     beta1, beta2, eps, bc2_sqrt, grad_scale);
+                     beta2, one_minus_beta1, one_minus_beta2, eps, bc2_sqrt, grad_scale);
   VCG_LAUNCH_CHECK("vcg_adam_step");
   return 0;
 }

@@ -29,6 +29,18 @@ void vcg_set_error(const char* fmt, ...);
     }                                                                       \
   } while (0)
 
+// Optional per-device-kernel timing (vcg_profile_enable / vcg_profile_read, misc.hip): while enabled, the MFMA kernel
+// launches bracket themselves with HIP events on their launch stream and carry the FLOPs they execute.  Off: one branch.
+extern bool g_vcg_prof_on;
+void vcg_prof_begin(const char* kernel, double flops, hipStream_t st);
+void vcg_prof_end(hipStream_t st);
+struct VcgProfScope {
+  hipStream_t st;
+  bool on;
+  VcgProfScope(const char* kernel, double flops, hipStream_t s) : st(s), on(g_vcg_prof_on) { if (on) vcg_prof_begin(kernel, flops, s); }
+  ~VcgProfScope() { if (on) vcg_prof_end(st); }
+};
+
 // division by a runtime constant: q = (umulhi(n, mul) + n) >> sh, valid for n < 2^31
 struct FastDiv {
   uint32_t d, mul, sh;
@@ -69,8 +81,9 @@ __host__ __device__ static inline int reflect_idx(int i, int L) {
   return i;
 }
 
+// NaN goes through both (torch.relu(nan) is nan: the reference's NaN guard, Networks.py:357, relies on it reaching the loss)
 __device__ static inline float act_apply(float v, int act) {
-  if (act == VCG_ACT_RELU) return v > 0.f ? v : 0.f;
+  if (act == VCG_ACT_RELU) return v < 0.f ? 0.f : v;
   if (act == VCG_ACT_LEAKY02) return v > 0.f ? v : 0.2f * v;
   return v;
 }

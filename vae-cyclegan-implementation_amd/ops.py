@@ -121,8 +121,7 @@ class wgrad_overlap:
 
 def backward_overlapped(loss, overlap=True, **kw):
     """loss.backward(**kw) with the weight gradients on the side stream (joined before returning).
-    `overlap=False`: one stream — used while a gradient exchange is in flight (data parallel), so that the
-    collective only ever runs beside the one compute stream it was ordered against."""
+    `overlap=False`: one stream."""
     if OVERLAP_ENABLED and overlap:
         with wgrad_overlap():
             loss.backward(**kw)
@@ -294,6 +293,11 @@ def repack_async(params):
             sp.packed(w)
 
 
+# Data parallelism: parallel.GradReducer.note — told about every weight gradient the backward has issued (and on which
+# stream), so that a gradient bucket can be exchanged as soon as its last contribution is in flight.
+GRAD_READY_HOOK = [None]
+
+
 # Phase control of the alternating GAN update.  `ctx.needs_input_grad` is fixed at forward
 # time, so the G phase (which needs only the discriminators' data gradient) and the D phase
 # (which must not spend a data gradient on the generators' images) say so explicitly.
@@ -432,8 +436,12 @@ class _ConvBlockFn(torch.autograd.Function):
                     run_wgrad()
                 xp.record_stream(side)                                # the allocator must not recycle them under the side stream
                 dt.record_stream(side)
+                wstream = side
             else:
                 run_wgrad()
+                wstream = torch.cuda.current_stream(dev)
+            if GRAD_READY_HOOK[0] is not None:
+                GRAD_READY_HOOK[0](wparam, bparam, wstream)
         dx = None
         if ctx.needs_input_grad[0] and id(spec) not in _NO_DGRAD:
             dxp = torch.empty_like(xp)
@@ -745,6 +753,8 @@ class _FullMapSNFn(torch.autograd.Function):
             ws = workspace((k + 256) * 4, dev)
             _native.check(lib.vcg_fullmap_wgrad(_ptr(g), _ptr(xp), _ptr(wsn), _ptr(sigma), _ptr(u), _ptr(v), _ptr(gw),
                                                 _ptr(gb), n, c, kh, kw, _ptr(ws), ws.numel() * 4, _stream()), "vcg_fullmap_wgrad")
+            if GRAD_READY_HOOK[0] is not None:
+                GRAD_READY_HOOK[0](wparam, bparam, torch.cuda.current_stream(dev))
         dx = None
         if ctx.needs_input_grad[0]:
             dxp = torch.empty_like(xp)
@@ -786,5 +796,5 @@ def adam_step_flat(p, g, m, v, step, lr, beta1, beta2, eps, grad_scale=1.0):
     step_size = lr / bc1
     bc2_sqrt = math.sqrt(bc2)
     _native.check(_native.lib().vcg_adam_step(_ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), step_size, beta1, beta2,
-                                              eps, bc2_sqrt, grad_scale, _stream()), "vcg_adam_step")
+                                              1.0 - beta1, 1.0 - beta2, eps, bc2_sqrt, grad_scale, _stream()), "vcg_adam_step")
     PARAM_EPOCH[0] += 1

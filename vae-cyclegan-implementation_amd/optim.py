@@ -68,6 +68,9 @@ class FusedAdam:
     # -- torch.optim.Optimizer surface -------------------------------------------------
     def zero_grad(self, set_to_none=False):
         """Gradients are accumulation targets of the backward kernels, so they are zeroed, never dropped."""
+        if getattr(self, "_exchange_pending", False):
+            raise RuntimeError("zero_grad() while this optimizer's gradient exchange is in flight (parallel.GradReducer): "
+                               "finish() the exchange and step() first")
         for p, o in zip(self.params, self.offsets):
             g = p.grad
             if g is None or g.data_ptr() != self.flat_grad.data_ptr() + 4 * o:

@@ -3,51 +3,191 @@
 The reference is single-process; this is the new piece the north_star asks for.
 Every op of the step is per-sample independent (InstanceNorm, one discriminator scalar per image)
 and every loss is a batch mean, so averaging per-rank gradients over equal shards IS the
-big-batch gradient.  The only exchange is therefore one all-reduce per optimizer:
+big-batch gradient.  The only exchange is therefore one sum-all-reduce per optimizer, cut into
+buckets that are launched FROM INSIDE the backward pass as they complete:
 
-  G phase  F+G gradients (132.4 M floats) — started right after `G_loss.backward()`, it runs on
-           RCCL's stream WHILE the discriminator backward runs on the compute stream;
-  D phase  DX+DY gradients (5.8 M floats).
+  * gradients already sit in ONE flat fp32 buffer per optimizer (optim.FusedAdam), in parameter order, and the
+    backward kernels accumulate into it directly.  A bucket is a run of whole parameters (>= `bucket_bytes`), i.e. a
+    contiguous slice: no flatten / unflatten copies;
+  * the backward reports every weight gradient it has issued (`ops.GRAD_READY_HOOK` -> `note`).  The first step
+    learns how many reports each parameter receives per backward (G's parameters are used by two forwards of the
+    step, the shared encoder of the Double models too); from the second step on a bucket is all-reduced the moment
+    its last report arrives — F's gradients while G(x) is still being differentiated, G's decoder while its encoder
+    is — and only the tail of the exchange is left for the discriminator backward to hide;
+  * the collective is ordered after the stream the weight gradients ran on (the side stream when
+    `ops.wgrad_overlap` is on): it is launched with that stream current, so RCCL's stream waits for exactly those
+    kernels and the data-gradient chain on the main stream is never blocked;
+  * the 1/world scaling is folded into the fused Adam launch (`grad_scale`): no extra pass over the gradients;
+  * gradients the generator phase deposits on the discriminators as a by-product are never produced here
+    (`ops.no_wgrad`), so nothing spurious is reduced.
 
-Gradients already sit in ONE flat fp32 buffer per optimizer (optim.FusedAdam), so a bucket is a
-contiguous slice: no flatten/unflatten copies.  The 1/world scaling is folded into the fused Adam
-launch (`grad_scale`), so the exchange adds no extra pass over the gradients.  xGMI is
-point-to-point (7 links x ~153 GB/s per GPU): buckets are large (default 128 MiB) so each RCCL
-launch can keep all links busy; the ~0.5 GB/step payload is a few ms against >100 ms of compute.
+xGMI is point-to-point (7 links x ~153 GB/s per GPU): buckets are large (default 64 MiB) so that every RCCL launch can
+keep all links busy.  `stats` accumulates what the step still waits for (HIP events around `finish`): bench.py prints it
+as `exchange_exposed_ms` for N > 1.
 """
 import torch
 import torch.distributed as dist
 
 
+class _Plan:
+    """Buckets of one optimizer: runs of whole parameters of its flat gradient buffer."""
+
+    def __init__(self, optimizer, bucket_elems):
+        params = getattr(optimizer, "params", None)
+        total = optimizer.flat_grad.numel()
+        self.buckets = []                        # (lo, hi) element ranges
+        self.bucket_of = {}                      # id(param) -> bucket index
+        if params:
+            offs = list(optimizer.offsets) + [total]
+            lo, members = 0, []
+            for i, p in enumerate(params):
+                members.append(p)
+                if offs[i + 1] - lo >= bucket_elems or i + 1 == len(params):
+                    for q in members:
+                        self.bucket_of[id(q)] = len(self.buckets)
+                    self.buckets.append((lo, offs[i + 1]))
+                    lo, members = offs[i + 1], []
+        else:                                    # a bare flat buffer (tests): fixed-size slices
+            for lo in range(0, total, bucket_elems):
+                self.buckets.append((lo, min(total, lo + bucket_elems)))
+        self.expected = None                     # id(param) -> reports per backward, learned in the first one
+        self.learning = {}
+        self.remaining = None                    # per bucket: reports still to come in this backward
+        self.launched = set()
+
+
 class GradReducer:
-    def __init__(self, group=None, bucket_bytes=128 << 20):
+    def __init__(self, group=None, bucket_bytes=64 << 20):
         if not dist.is_initialized():
             raise RuntimeError("torch.distributed is not initialised")
         self.group = group
         self.world = dist.get_world_size(group)
         self.bucket_elems = max(1, bucket_bytes // 4)
+        self._plans = {}
         self._pending = {}
+        self._armed = None                       # the optimizer whose backward is running
+        self.log = []                            # (tag, bucket, lo, hi, "backward" | "start") in launch order
+        self.stats = {"exposed_ms_events": [], "buckets_from_backward": 0, "buckets_at_start": 0}
+
+    def _plan(self, optimizer):
+        pl = self._plans.get(id(optimizer))
+        if pl is None or pl.total != optimizer.flat_grad.numel():
+            pl = _Plan(optimizer, self.bucket_elems)
+            pl.total = optimizer.flat_grad.numel()
+            self._plans[id(optimizer)] = pl
+        return pl
+
+    # ---- called by the model's training_step -------------------------------------------------------------------
+    def begin(self, optimizer):
+        """Right after `optimizer.zero_grad()`: arm the countdowns for the backward that fills its flat gradient."""
+        if self._pending.get(id(optimizer)):
+            raise RuntimeError("gradient exchange still pending on this optimizer: finish() it before the next backward")
+        pl = self._plan(optimizer)
+        pl.launched = set()
+        pl.learning = {}
+        if pl.expected is not None:
+            pl.remaining = [0] * len(pl.buckets)
+            pl.left = dict(pl.expected)
+            for pid, n in pl.expected.items():
+                pl.remaining[pl.bucket_of[pid]] += n
+        self._armed = optimizer
+        self._pending[id(optimizer)] = []
+        optimizer.grad_scale = 1.0 / self.world
+        optimizer._exchange_pending = True
+
+    def note(self, wparam, bparam=None, stream=None):
+        """A backward kernel sequence that accumulates into `wparam.grad` (and `bparam.grad`) has been issued on `stream`."""
+        opt = self._armed
+        if opt is None:
+            return
+        pl = self._plans[id(opt)]
+        for prm in (wparam, bparam):             # the bias gradient comes out of the same call, and may sit in another bucket
+            if prm is None or not getattr(prm, "requires_grad", True):
+                continue
+            pid = id(prm)
+            if pid not in pl.bucket_of:
+                continue                         # a parameter of another optimizer (e.g. D's data-gradient-only pass)
+            if pl.expected is None:              # first backward: learn the counts, exchange everything at start()
+                pl.learning[pid] = pl.learning.get(pid, 0) + 1
+                continue
+            b = pl.bucket_of[pid]
+            if b in pl.launched or pl.left.get(pid, 0) <= 0:
+                raise RuntimeError("a weight gradient was accumulated into a bucket whose exchange is already in flight "
+                                   "(this backward uses a parameter more often than the first one did)")
+            pl.left[pid] -= 1
+            pl.remaining[b] -= 1
+            if pl.remaining[b] == 0:
+                self._launch(opt, pl, b, stream, "backward")
 
     def start(self, optimizer):
-        """Launch the asynchronous sum of this optimizer's flat gradient buffer."""
+        """After the backward: exchange every bucket that has not been launched from inside it."""
+        pl = self._plan(optimizer)
+        if id(optimizer) not in self._pending:   # begin() was not called (plain use): everything goes now
+            self._pending[id(optimizer)] = []
+            pl.launched = set()
+            optimizer.grad_scale = 1.0 / self.world
+            optimizer._exchange_pending = True
+        if self._armed is optimizer:
+            self._armed = None
+            if pl.expected is None and pl.learning:
+                pl.expected = dict(pl.learning)
+        for b in range(len(pl.buckets)):
+            if b not in pl.launched:
+                self._launch(optimizer, pl, b, None, "start")
+
+    def _launch(self, optimizer, pl, b, stream, where):
+        lo, hi = pl.buckets[b]
         flat = optimizer.flat_grad
-        works = []
-        for lo in range(0, flat.numel(), self.bucket_elems):
-            hi = min(flat.numel(), lo + self.bucket_elems)
-            works.append(dist.all_reduce(flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
-        self._pending[id(optimizer)] = works
-        optimizer.grad_scale = 1.0 / self.world
+        if stream is not None and flat.is_cuda:
+            with torch.cuda.stream(stream):      # RCCL orders itself after the CURRENT stream: the one the weight gradients ran on
+                work = dist.all_reduce(flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        else:
+            if flat.is_cuda:
+                from . import ops
+                ops.join_side_streams()          # leftovers at start(): every producer stream first
+            work = dist.all_reduce(flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        pl.launched.add(b)
+        self._pending[id(optimizer)].append(work)
+        self.log.append((getattr(optimizer, "tag", ""), b, lo, hi, where))
+        self.stats["buckets_from_backward" if where == "backward" else "buckets_at_start"] += 1
 
     def finish(self, optimizer):
         """Make the compute stream wait for that exchange (before optimizer.step())."""
-        for w in self._pending.pop(id(optimizer), []):
+        works = self._pending.pop(id(optimizer), [])
+        timed = optimizer.flat_grad.is_cuda and works
+        if timed:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        for w in works:
             w.wait()
+        if timed:
+            e1.record()
+            self.stats["exposed_ms_events"].append((e0, e1))
+        optimizer._exchange_pending = False
 
+    def exposed_ms(self, reset=True):
+        """Milliseconds the compute stream spent waiting in finish() since the last call (synchronises)."""
+        if self.stats["exposed_ms_events"]:
+            torch.cuda.synchronize()
+        ms = sum(a.elapsed_time(b) for a, b in self.stats["exposed_ms_events"])
+        if reset:
+            self.stats["exposed_ms_events"] = []
+        return ms
+
+    # ---- small collectives -----------------------------------------------------------------------------------------
     def average_metrics(self, vec):
         """Logged metrics are means over the global batch: average the per-rank scalars."""
         dist.all_reduce(vec, op=dist.ReduceOp.SUM, group=self.group)
         vec.mul_(1.0 / self.world)          # 19 floats; bookkeeping, not on the step's critical path
         return vec
+
+    def any_rank(self, flag):
+        """True on every rank when `flag` is true on any: the decision to skip an update must be collective, or the ranks
+        that skipped never join the gradient exchange the others entered."""
+        t = torch.tensor([1.0 if flag else 0.0], dtype=torch.float32,
+                         device="cuda" if dist.get_backend(self.group) == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+        return bool(t.item() > 0)
 
 
 def broadcast_parameters(model, src=0, group=None):
@@ -68,8 +208,14 @@ def broadcast_parameters(model, src=0, group=None):
             ep[0] += 1
 
 
-def attach(model, group=None, bucket_bytes=128 << 20):
+def attach(model, group=None, bucket_bytes=64 << 20):
     """Give `model.training_step` a gradient exchange; returns the reducer."""
+    from . import ops
     red = GradReducer(group, bucket_bytes)
     model.grad_reducer = red
+    ops.GRAD_READY_HOOK[0] = red.note
+    for name in ("optimizer", "optimizer_G", "optimizer_D"):
+        opt = getattr(model, name, None)
+        if opt is not None:
+            opt.tag = name
     return red
