@@ -183,7 +183,8 @@ def read_kernel_profile(lib):
     out = {}
     for line in buf.value.decode().splitlines():
         name, cnt, ms, fl = line.split("\t")
-        out[name] = (int(cnt), float(ms) * 1e-3, float(fl))
+        c0, s0, f0 = out.get(name, (0, 0.0, 0.0))
+        out[name] = (c0 + int(cnt), s0 + float(ms) * 1e-3, f0 + float(fl))
     return out
 
 
@@ -194,7 +195,7 @@ def measure_roofline(pkg, model, pool, wl, B, S, latent, ms_per_step, rank=0):
     ops = pkg.ops
     lib = pkg._native.lib()
     ops.PROFILE = []
-    lib.vcg_profile_read(None, 0)                                 # drop anything recorded earlier
+    read_kernel_profile(lib)                                      # drop anything recorded earlier
     lib.vcg_profile_enable(1)
     overlap, ops.OVERLAP_ENABLED = ops.OVERLAP_ENABLED, False     # kernel rates are measured one family at a time:
     nsteps = 2

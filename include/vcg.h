@@ -56,7 +56,8 @@ const char* vcg_last_error(void);
 /* Diagnostic (bench.py's `roofline` object; the training path never enables it): while enabled, every MFMA kernel launch
    is bracketed by HIP events on its launch stream.  vcg_profile_read WAITS for those events (the one call of this library
    that synchronises) and writes one line per device kernel: name \t launches \t total ms \t executed FLOPs
-   (fp32-equivalent: 2*M*N*K of the GEMM the launch ran); returns the bytes written (or needed, when buf is NULL). */
+   (fp32-equivalent: 2*M*N*K of the GEMM the launch ran); returns the bytes written — or, with buf NULL, the bytes a
+   following call will need (the table is kept until it has been copied out). */
 int vcg_profile_enable(int on);
 long vcg_profile_read(char* buf, size_t cap);
 
@@ -157,6 +158,16 @@ int vcg_fullmap_dgrad(const float* g, const float* wsn_k, float* dx, int N, size
 int vcg_fullmap_wgrad(const float* g, const float* x, const float* wsn_k, const float* sigma,
                       const float* u, const float* v, float* gw_orig_oihw, float* gbias,
                       int N, int C, int KH, int KW, void* ws, size_t ws_bytes, void* stream);
+
+/* Input transforms on the device — the torchvision pipelines of train.py:184-190, 248-262, 309-319 ------------------------- */
+/* RandomHorizontal/VerticalFlip -> RandomResizedCrop(S, BICUBIC) | Resize((S,S)) -> ToTensor for N decoded uint8 HWC images
+   packed in `arena`.  params[n][16] (device, int32): arena byte offset lo, hi; source H, W; crop box y0, x0, h, w in
+   FLIPPED-image coordinates; flip_h; flip_v; filter (0 bicubic, 1 bilinear).  Pillow's antialiased convolution resize in
+   floating point.  out: (N, S, S, 4) fp32, channel 3 = 0 — the layout every network entry point takes.                        */
+int vcg_input_resample(const unsigned char* arena, const int32_t* params, float* out, int N, int S, void* stream);
+/* torchvision ColorJitter (tensor-path formulas) in place on (N, S, S, 4).  jitter[n][8] (device, fp32): enabled, brightness,
+   contrast, saturation, hue factors, order code o0 + 4 o1 + 16 o2 + 64 o3 (0 brightness, 1 contrast, 2 saturation, 3 hue). */
+int vcg_input_color_jitter(float* img, const float* jitter, int N, int S, void* stream);
 
 /* torch.optim.Adam.step — call sites Networks.py:312,894,1928-1935 ---------- */
 /* single-tensor torch formula on one flat buffer:

@@ -1,0 +1,178 @@
+"""Device-side input pipeline: the torchvision transforms of /root/reference/train.py:184-190, 248-262,
+309-319 as HIP kernels, against their numpy restatement (oracle/input_oracle.py), which is itself anchored on Pillow —
+the library those transforms call for PIL inputs (torchvision is absent from this image)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import input_oracle as io  # noqa: E402
+
+
+def _smooth_image(rng, h, w):
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float64)
+    img = np.stack([127.5 + 100 * np.sin(rng.uniform(0.01, 0.06) * xx + rng.uniform(0.01, 0.06) * yy + rng.uniform(0, 6)) for _ in range(3)], -1)
+    return np.clip(img, 0, 255).astype(np.uint8)
+
+
+CASES = [  # H, W, S, box (y0, x0, h, w) in flipped coordinates, flip_h, flip_v, filter
+    (300, 400, 64, (10, 20, 250, 250), False, False, 0),      # 3.9x shrink: antialiased bicubic, 17 taps per axis
+    (300, 400, 64, (0, 100, 300, 300), True, False, 0),
+    (120, 90, 64, (30, 10, 40, 40), False, True, 0),          # upsampling: plain bicubic, 4 taps
+    (200, 260, 96, (0, 0, 200, 260), False, False, 1),        # the test transform: Resize((S, S)) bilinear, anisotropic
+    (600, 600, 256, (100, 50, 345, 345), True, True, 0),      # the headline size
+    (64, 64, 64, (0, 0, 64, 64), True, False, 0),             # identity scale: resampling must reproduce the (flipped) image
+]
+
+
+# --------------------------------------------------------------------------------------------- CPU: the oracle itself
+@pytest.mark.parametrize("case", CASES, ids=[str(c[:3]) + ("b" if c[6] else "c") for c in CASES])
+def test_oracle_resample_matches_pillow(case):
+    """Pillow rounds to uint8 after its horizontal and after its vertical pass: agreement to ~1.5/255 on smooth images."""
+    from PIL import Image
+    H, W, S, box, fh, fv, filt = case
+    src = _smooth_image(np.random.RandomState(1), H, W)
+    mine = np.clip(io.resample(src, box, S, fh, fv, filt), 0, 1)
+    img = Image.fromarray(src)
+    if fh:
+        img = img.transpose(Image.FLIP_LEFT_RIGHT)
+    if fv:
+        img = img.transpose(Image.FLIP_TOP_BOTTOM)
+    y0, x0, h, w = box
+    pil = img.crop((x0, y0, x0 + w, y0 + h)).resize((S, S), Image.BICUBIC if filt == 0 else Image.BILINEAR)
+    ref = np.asarray(pil).astype(np.float64) / 255
+    assert np.abs(mine - ref).max() <= 1.6 / 255, np.abs(mine - ref).max() * 255
+    assert np.abs(mine - ref).mean() <= 0.5 / 255
+
+
+def test_oracle_identity_and_jitter_identities():
+    src = _smooth_image(np.random.RandomState(2), 64, 64)
+    out = io.resample(src, (0, 0, 64, 64), 64, True, False, 0)
+    assert np.abs(out - src[:, ::-1] / 255.0).max() < 1e-12           # scale 1: the bicubic kernel is interpolating
+    img = np.random.RandomState(3).rand(16, 16, 3)
+    assert np.abs(io.color_jitter(img, 1.0, 1.0, 1.0, 0.0, (0, 1, 2, 3)) - img).max() < 1e-12     # unit factors: identity
+    grey = io.color_jitter(img, 1.0, 1.0, 0.0, 0.0, (2, 0, 1, 3))
+    assert np.abs(grey[..., 0] - grey[..., 1]).max() < 1e-12          # saturation 0: grey image
+    rot = io.color_jitter(io.color_jitter(img, 1, 1, 1, 0.25, (3, 0, 1, 2)), 1, 1, 1, -0.25, (3, 0, 1, 2))
+    assert np.abs(rot - img).max() < 1e-9                             # a hue rotation and its inverse
+
+
+def test_draws_follow_torchvision_get_params(pkg):
+    ip = pkg.input_pipeline
+    rng = np.random.RandomState(5)
+    areas, flips = [], 0
+    for _ in range(2000):
+        g, j = ip.draw_sample(rng, 300, 400, ip.RECIPES["summer2winter"])
+        y0, x0, h, w = g[4:8]
+        assert h == w and 0 < h <= 300 and 0 <= y0 <= 300 - h and 0 <= x0 <= 400 - w      # square (ratio (1, 1)), inside the image
+        areas.append(h * w / (300 * 400))
+        flips += g[8]
+        assert g[9] == 0 and g[10] == 0 and j[0] == 1.0
+        assert 0.8 <= j[1] <= 1.2 and 0.8 <= j[2] <= 1.2 and 0.8 <= j[3] <= 1.2 and -0.1 <= j[4] <= 0.1
+        assert sorted(((int(j[5]) >> (2 * k)) & 3) for k in range(4)) == [0, 1, 2, 3]
+    # area ~ U(0.33, 1) x image area, truncated where the square does not fit (side <= 300: area <= 0.75)
+    assert 0.33 - 0.01 <= min(areas) and max(areas) <= 0.75 + 0.01 and 900 < flips < 1100
+    g, j = ip.draw_sample(rng, 200, 260, ip.RECIPES["test"])
+    assert tuple(g[4:11]) == (0, 0, 200, 260, 0, 0, 1) and j[0] == 0.0
+    assert ip.draw_crop(np.random.RandomState(0), 100, 1000, (0.9, 1.0)) == (0, 450, 100, 100)    # never fits: centred square
+
+
+# --------------------------------------------------------------------------------------------- GPU: the kernels
+def _run_resample(pkg, device, srcs, geos, S):
+    import ctypes
+    lib = pkg._native.lib()
+    arena = np.concatenate([s.reshape(-1) for s in srcs])
+    g = np.zeros((len(srcs), 16), np.int32)
+    off = 0
+    for k, (s, geo) in enumerate(zip(srcs, geos)):
+        g[k, 0], g[k, 2], g[k, 3] = off, s.shape[0], s.shape[1]
+        g[k, 4:11] = geo
+        off += s.size
+    da, dg = torch.from_numpy(arena).to(device), torch.from_numpy(g).to(device)
+    out = torch.empty((len(srcs), S, S, 4), dtype=torch.float32, device=device)
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    pkg._native.check(lib.vcg_input_resample(ctypes.c_void_p(da.data_ptr()), ctypes.c_void_p(dg.data_ptr()), ctypes.c_void_p(out.data_ptr()),
+                                             len(srcs), S, st), "vcg_input_resample")
+    return out
+
+
+@pytest.mark.gpu
+def test_resample_kernel_matches_the_oracle(pkg, device):
+    rng = np.random.RandomState(7)
+    for S in (64, 96, 256):
+        cases = [c for c in CASES if c[2] == S]
+        srcs = [(rng.rand(c[0], c[1], 3) * 255).astype(np.uint8) for c in cases]          # white noise: the hardest input
+        geos = [(*c[3], int(c[4]), int(c[5]), c[6]) for c in cases]
+        out = _run_resample(pkg, device, srcs, geos, S).cpu().numpy()
+        for k, c in enumerate(cases):
+            ref = io.resample(srcs[k], c[3], S, c[4], c[5], c[6])
+            assert np.abs(out[k, ..., :3] - ref).max() <= 2e-5, (c, np.abs(out[k, ..., :3] - ref).max())
+            assert np.abs(out[k, ..., 3]).max() == 0.0                                    # the pad channel of the NHWC pitch
+
+
+@pytest.mark.gpu
+def test_color_jitter_kernel_matches_the_oracle(pkg, device):
+    import ctypes
+    import itertools
+    lib = pkg._native.lib()
+    rng = np.random.RandomState(11)
+    S = 32
+    perms = list(itertools.permutations(range(4)))
+    N = len(perms) + 1
+    img = rng.uniform(-0.05, 1.05, (N, S, S, 4)).astype(np.float32)                       # a little overshoot, as bicubic leaves
+    img[..., 3] = 0
+    jit = np.zeros((N, 8), np.float32)
+    for k, pm in enumerate(perms):
+        jit[k, :5] = (1.0, rng.uniform(0.7, 1.3), rng.uniform(0.7, 1.3), rng.uniform(0.7, 1.3), rng.uniform(-0.15, 0.15))
+        jit[k, 5] = pm[0] + 4 * pm[1] + 16 * pm[2] + 64 * pm[3]
+    d = torch.from_numpy(img.copy()).to(device)
+    dj = torch.from_numpy(jit).to(device)
+    pkg._native.check(lib.vcg_input_color_jitter(ctypes.c_void_p(d.data_ptr()), ctypes.c_void_p(dj.data_ptr()), N, S,
+                                                 ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "vcg_input_color_jitter")
+    got = d.cpu().numpy()
+    for k, pm in enumerate(perms):
+        ref = io.color_jitter(img[k, ..., :3], *jit[k, 1:5].astype(np.float64), pm)
+        err = np.abs(got[k, ..., :3] - ref)
+        # hue is discontinuous where two channels tie (the HSV sector changes): allow a handful of such pixels
+        assert np.quantile(err, 0.999) <= 2e-5 and (err > 1e-3).sum() <= 3, (pm, err.max())
+    assert np.array_equal(got[-1], img[-1])                                               # disabled: untouched (not even clamped)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("recipe", ["summer2winter", "maps", "test"])
+def test_pipeline_batches_equal_the_oracle_on_the_same_draws(recipe, pkg, device):
+    """End to end: decode (thread pool) -> pinned arena -> side-stream upload + kernels, double-buffered.  Every batch must
+    equal the oracle applied to the same images with the same draws, also while the NEXT batch is being staged."""
+    ip = pkg.input_pipeline
+    S, B = 64, 3
+    src = ip.SyntheticImages(10, min_side=80, max_side=160, seed=3, paired=recipe == "maps")
+    pipe = ip.DeviceInputPipeline(src, B, S, device, recipe=recipe, shuffle=True, seed=9, num_workers=2)
+    assert len(pipe) == 4
+    seen = 0
+    for batch in pipe:
+        geo, jit, imgs = pipe.last_draws
+        nb = batch["x"].shape[0]
+        assert tuple(batch["x"].shape) == (nb, 3, S, S) and pkg.ops.is_nhwc_view(batch["x"]) and batch["x"].is_cuda
+        xs = batch["x"].permute(0, 2, 3, 1).cpu().numpy()
+        ys = batch["y"].permute(0, 2, 3, 1).cpu().numpy()
+        for k in range(nb):
+            for got, r in ((xs[k], k), (ys[k], nb + k)):
+                g = geo[r]
+                ref = io.resample(imgs[r], tuple(g[4:8]), S, bool(g[8]), bool(g[9]), int(g[10]))
+                if jit[r, 0]:
+                    order = tuple((int(jit[r, 5]) >> (2 * q)) & 3 for q in range(4))
+                    ref = io.color_jitter(ref, *jit[r, 1:5].astype(np.float64), order)
+                err = np.abs(got - ref)
+                assert np.quantile(err, 0.999) <= 3e-5 and (err > 1e-3).sum() <= 3, (recipe, k, err.max())
+            if recipe == "maps":
+                assert np.array_equal(geo[k, 4:11], geo[nb + k, 4:11])                   # both halves share one draw
+        seen += nb
+    assert seen == 10
+    # the batches feed a model without any conversion: one AE forward on the last one
+    if recipe == "summer2winter":
+        model = pkg.Networks.Autoencoder().to(device)
+        assert tuple(model(batch["x"]).shape) == tuple(batch["x"].shape)

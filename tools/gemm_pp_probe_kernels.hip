@@ -1,3 +1,7 @@
+// EXPERIMENT (round 2), not part of libvcg.so: built only by tools/gemm_split_probe.hip.  Results and why it was not
+// kept: DESIGN.md §3 "ping-pong GEMM"; profiles/r02_gemm_pp_probe.txt.  k_gemm_pp (inline-asm loads, two-step prefetch)
+// still returns wrong tiles on one shape (rows 8712, K 256, N 512: 0.02 % of the outputs) in the build WITHOUT stamps.
+//
 // Batched split-operand GEMM, "ping-pong" form:   C[z][m][n] = sum_k A[z][m][k] * Bt[z][n][k]   (fp32 in memory, k contiguous)
 //
 // Same arithmetic as gemm_split.hip (three bf16 pieces per fp32 operand, six bf16 MFMAs per product, fp32 accumulation in two
@@ -13,7 +17,7 @@
 // Waves w and w+4 share a SIMD, so on every SIMD one wave is in its matrix phase while its partner stages — by
 // construction, not by luck.  LDS holds two images of the tile pair (2 x 72 KiB): tile kt+1 is written into the other
 // image while tile kt is read, and the one barrier per K-step publishes it.
-#include "vcg_common.h"
+#include "../vae-cyclegan-implementation_amd/csrc/vcg_common.h"
 
 typedef unsigned int u32x4p __attribute__((ext_vector_type(4)));
 
@@ -236,6 +240,169 @@ __global__ __launch_bounds__(512, 2) void k_gemm_pp(GemmPPParams p) {
         if (m < p.rows) dst[(size_t)m * p.N + n] = acc[i][j][e] + lo[i][j][e];
       }
   }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// The same GEMM on operands that were split by their PRODUCERS ("blocked planes"): for X[rows][K], K % 32 == 0,
+//     bp[(row * K/32 + kb) * 96 + piece * 32 + j]   (bf16; piece 0 / 1 / 2 = h / m / l of X[row][32 kb + j])
+// i.e. 192 contiguous bytes per (row, 32-wide K block).  The weights are split once per optimizer step when they are
+// packed, the activations by the Winograd input transform that writes them (an HBM-bound kernel with VALU to spare), so
+// this kernel's staging is a plain 16-byte copy global -> LDS: no conversion arithmetic in the K loop at all.  In-kernel
+// stamps had shown that arithmetic (about 130 VALU instructions per thread and K-step) to take as long as the 48 MFMAs of
+// the step, beside which it does not overlap well (profiles/r02_gemm_pp_stamps.txt).
+__global__ __launch_bounds__(512, 2) void k_gemm_pp_planes(GemmPPParams p) {
+  constexpr int BM = 256, BN = 128, MI = 2, NI = 2;
+  __shared__ __attribute__((aligned(16))) unsigned char As[2][3][BM * 64];
+  __shared__ __attribute__((aligned(16))) unsigned char Bs[2][3][BN * 64];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool late = wid >= 4;
+  const int wm = wid >> 1, wn = wid & 1, l31 = lane & 31, lh = lane >> 5;
+  int mt, nt, zb;
+  {
+    const uint32_t per = gridDim.x * gridDim.y, nwg = per * gridDim.z;
+    const uint32_t gid = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    const uint32_t q = nwg >> 3, r = nwg & 7, xcd = gid & 7;
+    const uint32_t swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (gid >> 3);
+    zb = (int)(swz / per);
+    const uint32_t l = swz - (uint32_t)zb * per;
+    mt = (int)(l / gridDim.y);
+    nt = (int)(l - (uint32_t)mt * gridDim.y);
+  }
+  const int m0 = mt * BM, n0 = nt * BN;
+  // a_bstride / b_bstride count bf16 elements here (rows * K * 3 per batch), a_bytes / b_bytes the bytes of one batch
+  const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)((const unsigned short*)p.a + (size_t)zb * p.a_bstride), 0, (int)p.a_bytes, 0x00020000),
+                               rb = __builtin_amdgcn_make_buffer_rsrc((void*)((const unsigned short*)p.bt + (size_t)zb * p.b_bstride), 0, (int)p.b_bytes, 0x00020000);
+  const int KB = p.K / 32;
+  const int sq = tid & 3, sr = tid >> 2;                        // staging: 16-byte chunk of a 64-byte piece row, row (0..127)
+  const uint32_t aoff0 = (uint32_t)((size_t)(m0 + sr) * KB * 192 + sq * 16), boff0 = (uint32_t)((size_t)(n0 + sr) * KB * 192 + sq * 16);
+  const uint32_t ahalf = (uint32_t)KB * (128u * 192u);          // + 128 rows
+  const uint32_t soff0 = (uint32_t)(sr * 64 + ((sq ^ ((sr >> 2) & 3)) << 4));
+
+  f32x16 acc[MI][NI], lo[MI][NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = lo[i][j][e] = 0.f;
+
+  u32x4p va[6], vb[3];
+  auto load_tiles = [&](int kt) {                               // past the last K block every offset is out of bounds only for
+    const uint32_t ko = (uint32_t)kt * 192u;                    // the last rows; callers never load kt >= KB
+#pragma unroll
+    for (int j = 0; j < 6; ++j)
+      va[j] = __builtin_amdgcn_raw_buffer_load_b128(ra, (int)(aoff0 + (uint32_t)(j / 3) * ahalf + (uint32_t)(j % 3) * 64u + ko), 0, 0);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) vb[j] = __builtin_amdgcn_raw_buffer_load_b128(rb, (int)(boff0 + (uint32_t)j * 64u + ko), 0, 0);
+  };
+  auto store_tiles = [&](int buf) {
+#pragma unroll
+    for (int j = 0; j < 6; ++j) *reinterpret_cast<u32x4p*>(&As[buf][j % 3][soff0 + 8192 * (j / 3)]) = va[j];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) *reinterpret_cast<u32x4p*>(&Bs[buf][j][soff0]) = vb[j];
+  };
+  const uint32_t fa0 = (uint32_t)((wm * 64 + l31) * 64), fb0 = (uint32_t)((wn * 64 + l31) * 64);
+  const int sa0 = (l31 >> 2) & 3;
+  auto mma = [&](int buf) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      bf16x8 a[3][MI], b[3][NI];
+#pragma unroll
+      for (int pc = 0; pc < 3; ++pc) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i) a[pc][i] = *reinterpret_cast<const bf16x8*>(&As[buf][pc][fa0 + 2048 * i + (((2 * s + lh) ^ sa0) << 4)]);
+#pragma unroll
+        for (int j = 0; j < NI; ++j) b[pc][j] = *reinterpret_cast<const bf16x8*>(&Bs[buf][pc][fb0 + 2048 * j + (((2 * s + lh) ^ sa0) << 4)]);
+      }
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+          f32x16 c = lo[i][j];
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][i], b[1][j], c, 0, 0, 0);     // smallest contributions first
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2][i], b[0][j], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[2][j], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][i], b[0][j], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[1][j], c, 0, 0, 0);
+          lo[i][j] = c;
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[0][j], acc[i][j], 0, 0, 0);
+        }
+    }
+  };
+
+  load_tiles(0);
+  store_tiles(0);
+  if (KB > 1) load_tiles(1);
+  __syncthreads();
+  for (int kt = 0; kt < KB; ++kt) {
+    const int cur = kt & 1;
+    if (late) {
+      if (kt + 1 < KB) store_tiles(cur ^ 1);
+      if (kt + 2 < KB) load_tiles(kt + 2);
+    }
+    mma(cur);
+    if (!late) {
+      if (kt + 1 < KB) store_tiles(cur ^ 1);
+      if (kt + 2 < KB) load_tiles(kt + 2);
+    }
+    __syncthreads();
+  }
+  float* const dst = p.c + (size_t)zb * p.c_bstride;
+#pragma unroll
+  for (int j = 0; j < NI; ++j) {
+    const int n = n0 + wn * 64 + j * 32 + l31;
+    if (n >= p.N) continue;
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = (e & 3) + 8 * (e >> 2) + 4 * lh;
+        const int m = m0 + wm * 64 + i * 32 + row;
+        if (m < p.rows) dst[(size_t)m * p.N + n] = acc[i][j][e] + lo[i][j][e];
+      }
+  }
+}
+
+// X[rows][K] fp32 -> blocked planes (see k_gemm_pp_planes); one thread per 4 consecutive k.  K % 32 == 0.
+__global__ __launch_bounds__(256) void k_split_planes(const float* __restrict__ x, unsigned short* __restrict__ bp, size_t quads, int K) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < quads; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t e = i * 4, row = e / K;
+    const int k = (int)(e - row * K);
+    uint2 h, m, l;
+    split4(*reinterpret_cast<const float4*>(x + e), h, m, l);
+    unsigned short* o = bp + (row * (K / 32) + k / 32) * 96 + (k & 31);
+    *reinterpret_cast<uint2*>(o) = h;
+    *reinterpret_cast<uint2*>(o + 32) = m;
+    *reinterpret_cast<uint2*>(o + 64) = l;
+  }
+}
+int vcg_split_planes(const float* x, void* bp, size_t rows, int K, hipStream_t st) {
+  VCG_CHECK_ARG(K % 32 == 0, "vcg_split_planes: K must be a multiple of 32");
+  const size_t quads = rows * K / 4;
+  size_t blocks = (quads + 255) / 256; if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(k_split_planes, dim3((unsigned)blocks), dim3(256), 0, st, x, (unsigned short*)bp, quads, K);
+  VCG_LAUNCH_CHECK("vcg_split_planes");
+  return 0;
+}
+// A, Bt: blocked planes of rows x K and N x K per batch; K % 32 == 0, N % 128 == 0
+int vcg_gemm_pp_planes_batched(const void* Ap, const void* Btp, float* C, int rows, int K, int N, int batches, hipStream_t st) {
+  VCG_CHECK_ARG(K % 32 == 0 && N % 128 == 0 && rows > 0, "vcg_gemm_pp_planes_batched: bad shape rows=%d K=%d N=%d", rows, K, N);
+  VCG_CHECK_ARG((unsigned long long)rows * K * 6 < (1ull << 31) && (unsigned long long)N * K * 6 < (1ull << 31),
+                "vcg_gemm_pp_planes_batched: operand extents must stay below 2 GiB per batch");
+  VCG_CHECK_ARG((unsigned long long)rows * K * 3 * (unsigned long long)batches < (1ull << 32) &&
+                    (unsigned long long)N * K * 3 * (unsigned long long)batches < (1ull << 32),
+                "vcg_gemm_pp_planes_batched: batch stride overflow");
+  GemmPPParams p;
+  p.a = (const float*)Ap; p.bt = (const float*)Btp; p.c = C; p.rows = rows; p.K = K; p.N = N;
+  p.a_bytes = (uint32_t)((size_t)rows * K * 6); p.b_bytes = (uint32_t)((size_t)N * K * 6);
+  p.a_bstride = (uint32_t)((size_t)rows * K * 3); p.b_bstride = (uint32_t)((size_t)N * K * 3);
+  p.c_bstride = (size_t)rows * N;
+  dim3 grid((rows + 255) / 256, N / 128, batches);
+  VcgProfScope prof("k_gemm_pp_planes", 2.0 * rows * (double)K * N * batches, st);
+  hipLaunchKernelGGL(k_gemm_pp_planes, grid, dim3(512), 0, st, p);
+  VCG_LAUNCH_CHECK("vcg_gemm_pp_planes_batched");
+  return 0;
 }
 
 // rows x K times (N x K)^T per batch; K % 4 == 0, N % 128 == 0

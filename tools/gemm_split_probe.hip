@@ -1,6 +1,6 @@
 // Diagnostic: accuracy (against float64) and speed of the split-operand bf16 GEMM next to the fp32-MFMA GEMM the
 // Winograd layers use.  Build: C=vae-cyclegan-implementation_amd/csrc; hipcc --offload-arch=gfx950 -O3 -std=c++17 -DVCG_PP_STAMP \
-//   -o tools/_build/gemm_split_probe tools/gemm_split_probe.hip $C/conv_igemm.hip $C/conv_thin.hip $C/conv_wino.hip $C/gemm_split.hip $C/gemm_pp.hip $C/norm.hip $C/misc.hip
+//   -o tools/_build/gemm_split_probe tools/gemm_split_probe.hip $C/conv_igemm.hip $C/conv_thin.hip $C/conv_wino.hip $C/gemm_split.hip tools/gemm_pp_probe_kernels.hip $C/norm.hip $C/misc.hip
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdio.h>
@@ -12,8 +12,16 @@ int vcg_gemm_batched(const float* A, const float* B, float* C, int rows, int K, 
 int vcg_gemm_pp_batched(const float* A, const float* Bt, float* C, int rows, int K, int N, int batches, hipStream_t st);
 extern "C" const char* vcg_last_error();
 
+#ifdef VCG_PP_STAMP
 int vcg_pp_set_stamp(void* buf);
+#endif
+int vcg_split_planes(const float* x, void* bp, size_t rows, int K, hipStream_t st);
+int vcg_gemm_pp_planes_batched(const void* Ap, const void* Btp, float* C, int rows, int K, int N, int batches, hipStream_t st);
+
 static void stamps(const float* A, const float* Bt, float* C3, int rows, int K, int N, int batches) {
+#ifndef VCG_PP_STAMP
+  return;
+#else
   const int wgs = ((rows + 255) / 256) * (N / 128) * batches;
   unsigned long long* d; hipMalloc(&d, (size_t)wgs * 8 * 8 * 8); hipMemset(d, 0, (size_t)wgs * 8 * 8 * 8);
   vcg_pp_set_stamp(d);
@@ -29,6 +37,7 @@ static void stamps(const float* A, const float* Bt, float* C3, int rows, int K, 
     printf("   stamps %s waves: per K-step  matrix %6.0f  vmcnt wait %6.0f  split+store %6.0f  load issue %6.0f  barrier %6.0f | kernel %8.0f clocks (%d K-steps)\n",
            g ? "late (4-7) " : "early (0-3)", s[g][0] / cnt / nk, s[g][4] / cnt / nk, s[g][1] / cnt / nk, s[g][5] / cnt / nk, s[g][2] / cnt / nk, s[g][3] / cnt, (int)nk);
   hipFree(d);
+#endif
 }
 
 static void run(int rows, int K, int N, int batches) {
@@ -78,6 +87,31 @@ static void run(int rows, int K, int N, int batches) {
     }
   }
   if (pp) stamps(A, Bt, C3, rows, K, N, batches);
+  if (pp && K % 32 == 0) {                     // operands pre-split into blocked planes by their producers
+    void *Ap, *Bp; float* C4;
+    hipMalloc(&Ap, na * 6); hipMalloc(&Bp, nb * 6); hipMalloc(&C4, nc * 4); hipMemset(C4, 0, nc * 4);
+    vcg_split_planes(A, Ap, (size_t)batches * rows, K, 0);
+    vcg_split_planes(Bt, Bp, (size_t)batches * N, K, 0);
+    for (int w = 0; w < 2; ++w) if (vcg_gemm_pp_planes_batched(Ap, Bp, C4, rows, K, N, batches, 0)) { printf("planes failed: %s\n", vcg_last_error()); return; }
+    hipDeviceSynchronize();
+    float tg = 0, ts = 0;
+    for (int round = 0; round < 3; ++round) {
+      hipEventRecord(e0, 0);
+      for (int r = 0; r < reps; ++r) vcg_gemm_pp_planes_batched(Ap, Bp, C4, rows, K, N, batches, 0);
+      hipEventRecord(e1, 0); hipEventSynchronize(e1); hipEventElapsedTime(&tg, e0, e1);
+      hipEventRecord(e0, 0);
+      for (int r = 0; r < reps; ++r) vcg_split_planes(A, Ap, (size_t)batches * rows, K, 0);
+      hipEventRecord(e1, 0); hipEventSynchronize(e1); hipEventElapsedTime(&ts, e0, e1);
+      printf("   round %d: planes GEMM %8.1f us (%6.1f TF)   + splitting A as its own pass %8.1f us\n", round, tg * 1e3 / reps,
+             2.0 * batches * rows * N * (double)K / (tg * 1e-3 / reps) * 1e-12, ts * 1e3 / reps);
+    }
+    std::vector<float> h4(nc), h3(nc);
+    hipMemcpy(h4.data(), C4, nc * 4, hipMemcpyDeviceToHost); hipMemcpy(h3.data(), C3, nc * 4, hipMemcpyDeviceToHost);
+    double md = 0; size_t bad = 0;
+    for (size_t i = 0; i < nc; ++i) { const double d = fabs((double)h4[i] - h3[i]); if (d > md) md = d; if (!(d <= 1e-3)) ++bad; }
+    printf("   planes vs ping-pong over ALL outputs: max |diff| %.3e (%zu beyond 1e-3)\n", md, bad);
+    hipFree(Ap); hipFree(Bp); hipFree(C4);
+  }
   std::vector<float> hc(nc), hc2(nc), hc3(nc);
   hipMemcpy(hc3.data(), C3, nc * 4, hipMemcpyDeviceToHost);
   double e_pp = 0, maxdiff = 0;
@@ -107,12 +141,11 @@ static void run(int rows, int K, int N, int batches) {
 }
 
 int main() {
-  run(512, 1024, 1024, 16);    // R forward: row pitch 4096 B
-  run(512, 1056, 1024, 16);    // same with a row pitch of 4224 B (33 K-steps): L2 / memory channel camping?
-  run(512, 1088, 1024, 16);    // 4352 B (34 K-steps)
-  run(8192, 512, 256, 16);     // D2 forward: 2048 B
-  run(8192, 544, 256, 16);     // 2176 B (17 K-steps)
+  run(32768, 256, 128, 16);    // D1 forward
+  run(512, 1024, 1024, 16);    // R forward
+  run(8192, 512, 256, 16);     // D2 forward
   run(2048, 1024, 512, 16);    // D3 forward
-  run(2048, 1056, 512, 16);
+  run(8712, 256, 512, 16);     // D2 data gradient
+  run(300, 100, 128, 3);       // ragged: row and K tails
   return 0;
 }

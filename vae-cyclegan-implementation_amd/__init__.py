@@ -4,6 +4,6 @@ Losses.py / train.py surface).  The directory name is not a Python identifier; i
 `vcg_amd`.
 """
 from . import _native, ops, optim, synth  # noqa: F401
-from . import Losses, Networks, parallel, utils  # noqa: F401
+from . import Losses, Networks, input_pipeline, parallel, utils  # noqa: F401
 
-__all__ = ["_native", "ops", "optim", "synth", "Losses", "Networks", "parallel", "utils"]
+__all__ = ["_native", "ops", "optim", "synth", "Losses", "Networks", "input_pipeline", "parallel", "utils"]

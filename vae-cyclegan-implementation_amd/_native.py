@@ -10,7 +10,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(_HERE, "libvcg.so")
-SOURCES = ["conv_igemm.hip", "conv_thin.hip", "conv_wino.hip", "gemm_split.hip", "gemm_pp.hip", "norm.hip", "misc.hip"]
+SOURCES = ["conv_igemm.hip", "conv_thin.hip", "conv_wino.hip", "gemm_split.hip", "norm.hip", "misc.hip", "input.hip"]
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "vcg.h")
 
 _c = ctypes
@@ -60,6 +60,8 @@ SIGNATURES = {
     "vcg_fullmap_fwd": (_I, [_P, _P, _P, _P, _I, _Z, _P]),
     "vcg_fullmap_dgrad": (_I, [_P, _P, _P, _I, _Z, _P]),
     "vcg_fullmap_wgrad": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _Z, _P]),
+    "vcg_input_resample": (_I, [_P, _P, _P, _I, _I, _P]),
+    "vcg_input_color_jitter": (_I, [_P, _P, _I, _I, _P]),
     "vcg_adam_step": (_I, [_P, _P, _P, _P, _Z, _F, _F, _F, _F, _F, _F, _F, _F, _P]),
 }
 

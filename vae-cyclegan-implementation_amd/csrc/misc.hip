@@ -43,28 +43,32 @@ extern "C" int vcg_profile_enable(int on) {
   g_vcg_prof_on = on != 0;
   return 0;
 }
+static std::string g_prof_text;
 extern "C" long vcg_profile_read(char* buf, size_t cap) {
   struct Agg { double ms = 0, flops = 0; long n = 0; };
-  std::map<std::string, Agg> agg;
-  for (auto& r : g_prof) {
-    float ms = 0.f;
-    if (hipEventSynchronize(r.e1) == hipSuccess && hipEventElapsedTime(&ms, r.e0, r.e1) == hipSuccess) {
-      Agg& a = agg[r.name];
-      a.ms += ms; a.flops += r.flops; a.n += 1;
+  if (!g_prof.empty()) {                       // fold what has been recorded since the last call into the pending text
+    std::map<std::string, Agg> agg;
+    for (auto& r : g_prof) {
+      float ms = 0.f;
+      if (hipEventSynchronize(r.e1) == hipSuccess && hipEventElapsedTime(&ms, r.e0, r.e1) == hipSuccess) {
+        Agg& a = agg[r.name];
+        a.ms += ms; a.flops += r.flops; a.n += 1;
+      }
+      hipEventDestroy(r.e0); hipEventDestroy(r.e1);
     }
-    hipEventDestroy(r.e0); hipEventDestroy(r.e1);
+    g_prof.clear();
+    char line[256];
+    for (auto& kv : agg) {
+      snprintf(line, sizeof line, "%s\t%ld\t%.6f\t%.6e\n", kv.first.c_str(), kv.second.n, kv.second.ms, kv.second.flops);
+      g_prof_text += line;
+    }
   }
-  g_prof.clear();
-  std::string out;
-  char line[256];
-  for (auto& kv : agg) {
-    snprintf(line, sizeof line, "%s\t%ld\t%.6f\t%.6e\n", kv.first.c_str(), kv.second.n, kv.second.ms, kv.second.flops);
-    out += line;
-  }
+  std::string& out = g_prof_text;
   if (!buf || cap == 0) return (long)out.size() + 1;
   const size_t n = out.size() < cap - 1 ? out.size() : cap - 1;
   memcpy(buf, out.data(), n);
   buf[n] = 0;
+  out.clear();
   return (long)n;
 }
 
