@@ -128,15 +128,24 @@ def main():
     gc.collect()
     gc.freeze()
     barrier()
+    if red is not None:
+        red.exposed_ms()                       # drop the warm-up's events
+        red.stats["buckets_from_backward"] = red.stats["buckets_at_start"] = 0
     t0 = time.perf_counter()
     for i in range(args.steps):
         last = model.training_step(pool[i % len(pool)])
     barrier()
     elapsed = time.perf_counter() - t0
+    exposed_ms = None
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = tt.item()
+        # what the compute stream still waited for in GradReducer.finish() (HIP events around the waits), per step, and where
+        # the buckets were launched from; the max over ranks, like the time
+        ex = torch.tensor([red.exposed_ms() / args.steps], dtype=torch.float64, device=dev)
+        dist.all_reduce(ex, op=dist.ReduceOp.MAX)
+        exposed_ms = ex.item()
     bad = [k for k, v in last.items() if v != v or abs(v) == float("inf")]
     if bad:
         raise SystemExit(f"non-finite metrics after the timed steps: {bad}")
@@ -154,6 +163,13 @@ def main():
                    "image_size": S, "latent_dim": latent, "parallelism": f"dp{world}", "init": "random (reference init statistics)"},
     }
 
+    if world > 1:
+        st = red.stats
+        out["exchange_exposed_ms"] = round(exposed_ms, 3)
+        out["exchange"] = {"buckets_launched_from_inside_backward": st["buckets_from_backward"], "buckets_launched_after_backward": st["buckets_at_start"],
+                           "bucket_bytes": red.bucket_elems * 4, "is": "sum-all-reduce (RCCL) of contiguous slices of each optimizer's flat "
+                           "gradient buffer, launched as their last weight gradient is issued; exchange_exposed_ms = time the compute stream "
+                           "spent waiting for them before the optimizer steps, per step, max over ranks"}
     if not args.no_roofline:
         # every rank runs the two extra (untimed) steps: with N > 1 they contain the gradient exchange, which all
         # ranks must enter; rank 0 reports its own kernels

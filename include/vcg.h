@@ -72,9 +72,11 @@ int vcg_fill(float* dst, float value, size_t n, void* stream);
      Wf[K][Cout]          K ordered (kh,kw,i,j,c), so PixelUnshuffle (Networks.py:86) needs no data movement;
                           the B operand of the data-gradient and weight-gradient GEMMs
      U, Ud[16][..]        3x3 / stride-1 layers: the Winograd F(2x2,3x3) transforms G g G^T of the kernel (forward,
-                          [xi][Cout][K]) and of the flipped kernel (data gradient, [xi][K][Cout])
+                          [xi][Cout][K]) and of the flipped kernel (data gradient, [xi][K][Cout]), ALREADY SPLIT into the
+                          three bf16 pieces the GEMMs multiply with ("blocked planes": 192 bytes per row and 32-wide block)
      Wk, Wkd              7x7 layers with <= 4 channels on one side: kw folded into the GEMM's N (forward / data gradient)
-     WfT[Cout][K]         the transpose of Wf: B^T operand of the split-operand forward kernel
+     WFT, WFD planes      other layers with >= 64 output channels: the transpose of Wf (forward) and its rows per tap (data
+                          gradient), pre-split the same way for the direct split-operand kernels
    vcg_pack_weight_floats: floats the caller must provide for `wf` (spatial fields of cd are ignored). */
 size_t vcg_pack_weight_floats(const int32_t* cd);
 int vcg_pack_weight(const float* w_oihw, float* wf, const int32_t* cd, void* stream);

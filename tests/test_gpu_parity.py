@@ -525,23 +525,15 @@ def test_train_epoch_matches_the_reference_train_epoch(key, pkg, device, train_e
     assert not pkg.ops._EPS_QUEUE, "train_epoch consumed fewer eps draws than the reference's"
     ref = meta[key]
     assert list(comps) == list(ref["components"])
-    gan_tol = {}
-    if key.startswith("cvg"):
-        # the GAN's second step amplifies rounding (see test_cyclevaegan_step_matches_reference_golden): per metric, what the
-        # reference's own fp32 run deviates from its float64 run at a second step, x 2.5 (the average halves it, and we may
-        # land on the other side of the truth)
-        import json
-        with open(os.path.join(os.path.dirname(__file__), "golden", "steps_fp64_meta.json")) as fh:
-            f64 = json.load(fh)["cvg256_unpaired"][1]
-        with open(os.path.join(os.path.dirname(__file__), "golden", "steps_meta.json")) as fh:
-            f32 = json.load(fh)["cvg256_unpaired"][1]
-        gan_tol = {k: 2.5 * abs(f32[k] - f64[k]) / max(abs(f64[k]), 1e-6) for k in f64}
-
-    def tol(k):
-        return max(2e-2, gan_tol.get(k, 0.0)) if key.startswith("cvg") else 1e-3
-    assert abs(avg - ref["avg_loss"]) <= tol("G_loss") * abs(ref["avg_loss"])
-    for k, v in ref["components"].items():
-        assert abs(comps[k] - v) <= tol(k) * max(abs(v), 1e-6), f"{key}: averaged {k} = {comps[k]!r}, reference {v!r}"
+    # calibrated like the gradients: the fixture also holds the reference's own float64 epoch; ours must be within
+    # max(tol, 4 x |reference fp32 - reference fp64|) of that truth (tol 1e-3; 2e-2 for the GAN, whose second step amplifies
+    # rounding: Adam's first update is lr * sign(g), see test_cyclevaegan_step_matches_reference_golden)
+    base = 2e-2 if key.startswith("cvg") else 1e-3
+    for k, v in [("avg_loss", ref["avg_loss"])] + list(ref["components"].items()):
+        got = avg if k == "avg_loss" else comps[k]
+        truth = ref["avg_loss64"] if k == "avg_loss" else ref["components64"][k]
+        bound = max(base * abs(truth), 4 * abs(v - truth))
+        assert abs(got - truth) <= bound, f"{key}: averaged {k} = {got!r}, reference fp64 {truth!r} (its fp32 run {v!r}); bound {bound:.3e}"
     assert list(last_output.shape) == ref["last_output_shape"]          # Autoencoder: model(x)[0] is ONE image (:114)
     lo = nchw(last_output if last_output.dim() == 4 else last_output[None])
     st = 16 if S == 256 else 4
@@ -576,7 +568,9 @@ def test_train_epoch_matches_the_reference_train_epoch(key, pkg, device, train_e
         _, comps2, out2, _, _ = train.train_epoch(model2, batches, device, type("A", (), {"reference_viz_forward": False})())
         pkg.ops.inject_eps([])
         assert out2 is None
-        assert abs(comps2["loss_kl"] - ref["components"]["loss_kl"]) > 1e-3 * abs(ref["components"]["loss_kl"])
+        # (KL does not depend on eps; the reconstruction term does, through z = mu + eps * sigma)
+        k2 = "loss_trans" if "loss_trans" in comps2 else "loss_cycle"
+        assert abs(comps2[k2] - ref["components"][k2]) > 2e-3 * abs(ref["components"][k2]), (comps2[k2], ref["components"][k2])
 
 
 def test_cyclevaegan_unconfigured_raises_like_the_reference(pkg, device):

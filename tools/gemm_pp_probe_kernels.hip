@@ -364,27 +364,6 @@ __global__ __launch_bounds__(512, 2) void k_gemm_pp_planes(GemmPPParams p) {
   }
 }
 
-// X[rows][K] fp32 -> blocked planes (see k_gemm_pp_planes); one thread per 4 consecutive k.  K % 32 == 0.
-__global__ __launch_bounds__(256) void k_split_planes(const float* __restrict__ x, unsigned short* __restrict__ bp, size_t quads, int K) {
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < quads; i += (size_t)gridDim.x * blockDim.x) {
-    const size_t e = i * 4, row = e / K;
-    const int k = (int)(e - row * K);
-    uint2 h, m, l;
-    split4(*reinterpret_cast<const float4*>(x + e), h, m, l);
-    unsigned short* o = bp + (row * (K / 32) + k / 32) * 96 + (k & 31);
-    *reinterpret_cast<uint2*>(o) = h;
-    *reinterpret_cast<uint2*>(o + 32) = m;
-    *reinterpret_cast<uint2*>(o + 64) = l;
-  }
-}
-int vcg_split_planes(const float* x, void* bp, size_t rows, int K, hipStream_t st) {
-  VCG_CHECK_ARG(K % 32 == 0, "vcg_split_planes: K must be a multiple of 32");
-  const size_t quads = rows * K / 4;
-  size_t blocks = (quads + 255) / 256; if (blocks > 8192) blocks = 8192;
-  hipLaunchKernelGGL(k_split_planes, dim3((unsigned)blocks), dim3(256), 0, st, x, (unsigned short*)bp, quads, K);
-  VCG_LAUNCH_CHECK("vcg_split_planes");
-  return 0;
-}
 // A, Bt: blocked planes of rows x K and N x K per batch; K % 32 == 0, N % 128 == 0
 int vcg_gemm_pp_planes_batched(const void* Ap, const void* Btp, float* C, int rows, int K, int N, int batches, hipStream_t st) {
   VCG_CHECK_ARG(K % 32 == 0 && N % 128 == 0 && rows > 0, "vcg_gemm_pp_planes_batched: bad shape rows=%d K=%d N=%d", rows, K, N);

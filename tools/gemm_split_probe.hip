@@ -7,7 +7,7 @@
 #include <stdint.h>
 #include <vector>
 
-int vcg_gemm_split_batched(const float* A, const float* Bt, float* C, int rows, int K, int N, int batches, hipStream_t st);
+int vcg_gemm_split_batched(const float* A, const void* BtPlanes, float* C, int rows, int K, int N, int batches, hipStream_t st);
 int vcg_gemm_batched(const float* A, const float* B, float* C, int rows, int K, int Ncols, int batches, hipStream_t st);
 int vcg_gemm_pp_batched(const float* A, const float* Bt, float* C, int rows, int K, int N, int batches, hipStream_t st);
 extern "C" const char* vcg_last_error();
@@ -57,14 +57,17 @@ static void run(int rows, int K, int N, int batches) {
   hipMemcpy(B, hb.data(), nb * 4, hipMemcpyHostToDevice);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   float ms_split = 0, ms_f32 = 0;
+  if (K % 32) { printf("rows %d K %d N %d: K %% 32 != 0, skipped (the weight operand comes as blocked planes)\n", rows, K, N); return; }
+  void* BtP; hipMalloc(&BtP, nb * 6);
+  vcg_split_planes(Bt, BtP, (size_t)batches * N, K, 0);
   for (int w = 0; w < 2; ++w) {
-    if (vcg_gemm_split_batched(A, Bt, C, rows, K, N, batches, 0)) { printf("split failed: %s\n", vcg_last_error()); return; }
+    if (vcg_gemm_split_batched(A, BtP, C, rows, K, N, batches, 0)) { printf("split failed: %s\n", vcg_last_error()); return; }
     if (vcg_gemm_batched(A, B, C2, rows, K, N, batches, 0)) { printf("f32 failed: %s\n", vcg_last_error()); return; }
   }
   hipDeviceSynchronize();
   const int reps = 5;
   hipEventRecord(e0, 0);
-  for (int r = 0; r < reps; ++r) vcg_gemm_split_batched(A, Bt, C, rows, K, N, batches, 0);
+  for (int r = 0; r < reps; ++r) vcg_gemm_split_batched(A, BtP, C, rows, K, N, batches, 0);
   hipEventRecord(e1, 0); hipEventSynchronize(e1); hipEventElapsedTime(&ms_split, e0, e1);
   hipEventRecord(e0, 0);
   for (int r = 0; r < reps; ++r) vcg_gemm_batched(A, B, C2, rows, K, N, batches, 0);
@@ -77,7 +80,7 @@ static void run(int rows, int K, int N, int batches) {
     for (int round = 0; round < 3; ++round) {          // interleaved rounds: split, pp, split, pp ...
       float a = 0, b = 0;
       hipEventRecord(e0, 0);
-      for (int r = 0; r < reps; ++r) vcg_gemm_split_batched(A, Bt, C, rows, K, N, batches, 0);
+      for (int r = 0; r < reps; ++r) vcg_gemm_split_batched(A, BtP, C, rows, K, N, batches, 0);
       hipEventRecord(e1, 0); hipEventSynchronize(e1); hipEventElapsedTime(&a, e0, e1);
       hipEventRecord(e0, 0);
       for (int r = 0; r < reps; ++r) vcg_gemm_pp_batched(A, Bt, C3, rows, K, N, batches, 0);

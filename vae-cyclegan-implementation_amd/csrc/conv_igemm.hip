@@ -444,7 +444,7 @@ template <int BN>
 __global__ __launch_bounds__(256, 2) void k_conv_fwd_split(ConvP p) {
   VCG_STAMP_AT(0);
   constexpr int BM = 128, WN = 2, WM = 2;
-  constexpr int MI = BM / (32 * WM), NI = BN / (32 * WN), AR = BM / 32, BE = BN / 32;
+  constexpr int MI = BM / (32 * WM), NI = BN / (32 * WN), AR = BM / 32;
   __shared__ __attribute__((aligned(16))) unsigned char As[3][BM * 64];
   __shared__ __attribute__((aligned(16))) unsigned char Bs[3][BN * 64];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -491,7 +491,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_fwd_split(ConvP p) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = lo[i][j][e] = 0.f;
 
-  float4 va[AR], vb[BE];
+  float4 va[AR];
   int nkt = (p.K + BK - 1) / BK;
   int kt0 = 0;
   if (p.ksplit > 1) {
@@ -504,17 +504,20 @@ __global__ __launch_bounds__(256, 2) void k_conv_fwd_split(ConvP p) {
   // Cin/32 K-steps), so a steady-state K-step costs one add per row instead of the reflect arithmetic
   uint32_t rowoff[AR];
   int tap_cur = -1;
-  // weight tile from WfT[Cout][K]: row co = n0 + a_row + 32 e, this thread's k quad a_u of the K-step
-  uint32_t boff[BE];
-#pragma unroll
-  for (int e = 0; e < BE; ++e) {
-    const int co = n0 + a_row + 32 * e;
-    boff[e] = co < p.Cout ? (uint32_t)(((size_t)co * p.K + a_u * 4) * 4) : VCG_OOB;
-  }
+  // weight tile from the WfT PLANES (the transposed pack, split into bf16 pieces when it was packed: [Cout][K/32][3][32],
+  // K zero-padded to 32): thread (row b_r = tid >> 2, 16-byte chunk b_q = tid & 3 of a 64-byte piece row); pass j =
+  // (64-row half, piece).  Rows past Cout fall off the end of the buffer and read as zeros.
+  constexpr int BP = 3 * BN / 64;
+  const int b_q = tid & 3, b_r = tid >> 2;
+  const int KB = (p.K + 31) / 32;
+  const uint32_t boff0 = (uint32_t)(((size_t)(n0 + b_r) * KB) * 192 + b_q * 16);
+  const uint32_t bhalf = (uint32_t)KB * (64u * 192u);
+  const uint32_t bsoff0 = (uint32_t)(b_r * 64 + ((b_q ^ ((b_r >> 2) & 3)) << 4));
+  u32x4 vbp[BP];
   // LDS byte offset of this thread's quad in a piece image (row r, chunk a_u >> 1 swizzled by (r >> 2) & 3, half a_u & 1)
-  uint32_t soff[AR > BE ? AR : BE];
+  uint32_t soff[AR];
 #pragma unroll
-  for (int i = 0; i < (AR > BE ? AR : BE); ++i) {
+  for (int i = 0; i < AR; ++i) {
     const int r = a_row + 32 * i;
     soff[i] = (uint32_t)(r * 64 + (((a_u >> 1) ^ ((r >> 2) & 3)) << 4) + ((a_u & 1) << 3));
   }
@@ -549,7 +552,8 @@ __global__ __launch_bounds__(256, 2) void k_conv_fwd_split(ConvP p) {
       va[r] = bload4(ra, off);
     }
 #pragma unroll
-    for (int e = 0; e < BE; ++e) vb[e] = bload4(rb, (kv && boff[e] != VCG_OOB) ? boff[e] + (uint32_t)kt * 128u : VCG_OOB);
+    for (int j = 0; j < BP; ++j)
+      vbp[j] = __builtin_amdgcn_raw_buffer_load_b128(rb, (int)(boff0 + (uint32_t)(j / 3) * bhalf + (uint32_t)(j % 3) * 64u + (uint32_t)kt * 192u), 0, 0);
   };
   auto store_tiles = [&]() {
 #pragma unroll
@@ -561,13 +565,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_fwd_split(ConvP p) {
       *reinterpret_cast<uint2*>(&As[2][soff[r]]) = l;
     }
 #pragma unroll
-    for (int e = 0; e < BE; ++e) {
-      uint2 h, m, l;
-      split4(vb[e], h, m, l);
-      *reinterpret_cast<uint2*>(&Bs[0][soff[e]]) = h;
-      *reinterpret_cast<uint2*>(&Bs[1][soff[e]]) = m;
-      *reinterpret_cast<uint2*>(&Bs[2][soff[e]]) = l;
-    }
+    for (int j = 0; j < BP; ++j) *reinterpret_cast<u32x4*>(&Bs[j % 3][bsoff0 + 4096 * (j / 3)]) = vbp[j];
   };
   uint32_t fa[MI], fb[NI];
   int sa[MI], sb[NI];
@@ -836,7 +834,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_dgrad(ConvP p) {
 // The data gradient on the split-operand bf16 path (see k_conv_fwd_split / gemm_split.hip).  Same gather as
 // k_conv_dgrad — including the fold of the reflect halo, summed in fp32 BEFORE the split — and the same weight rows
 // (Wf viewed as [tap][J][co] is already k-contiguous per output column J).
-template <int BN, int WN>
+template <int BN, int WN, bool BPL = (BN >= 64)>
 __global__ __launch_bounds__(256, 2) void k_conv_dgrad_split(ConvP p) {
   VCG_STAMP_AT(0);
   constexpr int BM = 128, WM = 4 / WN;
@@ -877,7 +875,14 @@ __global__ __launch_bounds__(256, 2) void k_conv_dgrad_split(ConvP p) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = lo[i][j][e] = 0.f;
 
-  float4 va[AR], ve[AR], vb[BR];
+  float4 va[AR], ve[AR], vb[BPL ? 1 : BR];
+  // BPL: the weight rows come pre-split from the pack's dgrad planes [(tap, J)][Cout/32][3][32] (Cout % 32 == 0): thread
+  // (row b_r = tid >> 2, 16-byte chunk b_q = tid & 3 of a 64-byte piece row), pass j = (64-row half, piece)
+  constexpr int BP = BPL ? 3 * BN / 64 : 1;
+  const int b_q = tid & 3, b_r = tid >> 2;
+  const int CB = p.Cout / 32;
+  const uint32_t bsoff0 = (uint32_t)(b_r * 64 + ((b_q ^ ((b_r >> 2) & 3)) << 4));
+  u32x4 vbp[BP];
   int nkt = (Kc + BK - 1) / BK;
   int kt0 = 0;
   if (p.ksplit > 1) {                      // stride 1 only: blockIdx.z is the K slice, not a parity class
@@ -931,10 +936,12 @@ __global__ __launch_bounds__(256, 2) void k_conv_dgrad_split(ConvP p) {
         }
       }
       const int tapfull = kh * p.KW + kw;
+      if constexpr (!BPL) {
 #pragma unroll
-      for (int r = 0; r < BR; ++r) {
-        const int J = n0 + a_row + 32 * r;
-        wbase[r] = J < p.NB ? (uint32_t)((tapfull * p.NB + J) * p.Cout) * 4u : VCG_OOB;
+        for (int r = 0; r < BR; ++r) {
+          const int J = n0 + a_row + 32 * r;
+          wbase[r] = J < p.NB ? (uint32_t)((tapfull * p.NB + J) * p.Cout) * 4u : VCG_OOB;
+        }
       }
     }
     const uint32_t cb4 = (uint32_t)co * 4u;
@@ -957,8 +964,21 @@ __global__ __launch_bounds__(256, 2) void k_conv_dgrad_split(ConvP p) {
         ve[r] = e;
       }
     }
+    if constexpr (BPL) {
+      // the K-step's 32 reduction indices are 32 consecutive co of ONE tap (Cout % 32 == 0): wave-uniform
+      const int tk = (kt * 32) / p.Cout, cob = (kt * 32 - tk * p.Cout) >> 5;
+      const int tf = (kh0 + (tk / nKW) * s) * p.KW + (kw0 + (tk % nKW) * s);
+      const bool kvt = kt * 32 < Kc;
 #pragma unroll
-    for (int r = 0; r < BR; ++r) vb[r] = bload4(rb, (kv && wbase[r] != VCG_OOB) ? wbase[r] + cb4 : VCG_OOB);
+      for (int j = 0; j < BP; ++j) {
+        const int J = n0 + b_r + 64 * (j / 3);
+        const uint32_t off = (kvt && J < p.NB) ? (uint32_t)((((size_t)tf * p.NB + J) * CB + cob) * 192 + (j % 3) * 64 + b_q * 16) : VCG_OOB;
+        vbp[j] = __builtin_amdgcn_raw_buffer_load_b128(rb, (int)off, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < BR; ++r) vb[r] = bload4(rb, (kv && wbase[r] != VCG_OOB) ? wbase[r] + cb4 : VCG_OOB);
+    }
   };
   uint32_t soff[AR > BR ? AR : BR];
 #pragma unroll
@@ -976,13 +996,18 @@ __global__ __launch_bounds__(256, 2) void k_conv_dgrad_split(ConvP p) {
       *reinterpret_cast<uint2*>(&As[1][soff[r]]) = m;
       *reinterpret_cast<uint2*>(&As[2][soff[r]]) = l;
     }
+    if constexpr (BPL) {
 #pragma unroll
-    for (int r = 0; r < BR; ++r) {
-      uint2 h, m, l;
-      split4(vb[r], h, m, l);
-      *reinterpret_cast<uint2*>(&Bs[0][soff[r]]) = h;
-      *reinterpret_cast<uint2*>(&Bs[1][soff[r]]) = m;
-      *reinterpret_cast<uint2*>(&Bs[2][soff[r]]) = l;
+      for (int j = 0; j < BP; ++j) *reinterpret_cast<u32x4*>(&Bs[j % 3][bsoff0 + 4096 * (j / 3)]) = vbp[j];
+    } else {
+#pragma unroll
+      for (int r = 0; r < BR; ++r) {
+        uint2 h, m, l;
+        split4(vb[r], h, m, l);
+        *reinterpret_cast<uint2*>(&Bs[0][soff[r]]) = h;
+        *reinterpret_cast<uint2*>(&Bs[1][soff[r]]) = m;
+        *reinterpret_cast<uint2*>(&Bs[2][soff[r]]) = l;
+      }
     }
   };
   uint32_t fa[MI], fb[NI];
@@ -1708,25 +1733,57 @@ __global__ __launch_bounds__(256) void k_pack_weight_t(const float* __restrict__
     for (int t = 0; t < T; ++t) wf[((size_t)t * p.Cin + c) * p.Cout + co] = tile[(t * 8 + cl_) * 33 + col];
 }
 
-// OIHW -> WfT[Cout][K] (the transpose of Wf; the B^T operand of k_conv_fwd_split): one thread per (co, k), k fastest
-__global__ __launch_bounds__(256) void k_pack_weight_wft(const float* __restrict__ w, float* __restrict__ wft, ConvP p, int cin_log,
-                                                         int cout_log) {
-  const size_t total = (size_t)p.K * p.Cout;
+// OIHW -> the pre-split ("blocked planes", gemm_split.hip) weight operands of the direct split-operand kernels:
+//   WFT planes  [Cout][KB][3][32], KB = ceil(K / 32), zero padded: the transpose of Wf, B^T of k_conv_fwd_split;
+//               one thread per (co, 4 consecutive k = one tap, 4 channels)
+//   WFD planes  [(kh, kw)][J][Cout / 32][3][32], J = (phase, c): the rows of Wf as k_conv_dgrad_split reads them (reduction
+//               index co); one thread per ((tap, J), 4 consecutive co)
+template <bool DGRAD>
+__global__ __launch_bounds__(256) void k_pack_planes(const float* __restrict__ w, unsigned short* __restrict__ bp, ConvP p, int cin_log,
+                                                     int cout_log) {
+  const int U2 = p.ups * p.ups, KK = p.KH * p.KW;
+  const int cinL = cin_log * U2;
+  const int KB = (p.K + 31) / 32, CB = p.Cout / 32;
+  const size_t total = DGRAD ? (size_t)KK * U2 * p.Cin * (p.Cout / 4) : (size_t)p.Cout * KB * 8;
   for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
-    const int co = (int)(idx / p.K);
-    const uint32_t R = (uint32_t)(idx - (size_t)co * p.K);
-    uint32_t tap = R / (uint32_t)p.Cin;
-    const int c = (int)(R - tap * (uint32_t)p.Cin);
-    float v = 0.f;
-    if (co < cout_log && c < cin_log) {
-      int ii = 0, jj = 0;
-      if (p.ups == 2) { jj = tap & 1; ii = (tap >> 1) & 1; tap >>= 2; }
-      const int kh = (int)tap / p.KW, kw = (int)tap % p.KW;
-      const int cl = (p.ups == 2) ? (c * 4 + ii * 2 + jj) : c;
-      const int cinL = (p.ups == 2) ? cin_log * 4 : cin_log;
-      v = w[(((size_t)co * cinL + cl) * p.KH + kh) * p.KW + kw];
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    unsigned short* o;
+    if (DGRAD) {
+      const size_t row = idx / (p.Cout / 4);                     // (tapfull, J)
+      const int co0 = (int)(idx - row * (p.Cout / 4)) * 4;
+      const int NB = U2 * p.Cin;
+      const int tapfull = (int)(row / NB), J = (int)(row - (size_t)tapfull * NB);
+      const int q = J / p.Cin, c = J - q * p.Cin;
+      const int kh = tapfull / p.KW, kw = tapfull - kh * p.KW;
+      if (c < cin_log) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (co0 + e < cout_log) v[e] = w[(((size_t)(co0 + e) * cinL + (size_t)c * U2 + q) * p.KH + kh) * p.KW + kw];
+      }
+      o = bp + (row * CB + co0 / 32) * 96 + (co0 & 31);
+    } else {
+      const int co = (int)(idx / ((size_t)KB * 8));
+      const int k0 = (int)(idx - (size_t)co * KB * 8) * 4;       // 4 consecutive k: one tap, channels c .. c + 3
+      if (co < cout_log && k0 < p.K) {
+        uint32_t tap = (uint32_t)k0 / (uint32_t)p.Cin;
+        const int c = k0 - (int)tap * p.Cin;
+        int ii = 0, jj = 0;
+        if (p.ups == 2) { jj = tap & 1; ii = (tap >> 1) & 1; tap >>= 2; }
+        const int kh = (int)tap / p.KW, kw = (int)tap % p.KW;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (c + e < cin_log) {
+            const int cl = (p.ups == 2) ? ((c + e) * 4 + ii * 2 + jj) : c + e;
+            v[e] = w[(((size_t)co * cinL + cl) * p.KH + kh) * p.KW + kw];
+          }
+      }
+      o = bp + ((size_t)co * KB + k0 / 32) * 96 + (k0 & 31);
     }
-    wft[idx] = v;
+    uint2 h, m, l;
+    split4(make_float4(v[0], v[1], v[2], v[3]), h, m, l);
+    *reinterpret_cast<uint2*>(o) = h;
+    *reinterpret_cast<uint2*>(o + 32) = m;
+    *reinterpret_cast<uint2*>(o + 64) = l;
   }
 }
 
@@ -1927,14 +1984,23 @@ int vcg_gemm_batched(const float* A, const float* B, float* C, int rows, int K, 
 // floats of the packed-weight buffer: Wf[K][Cout], then (3x3 stride-1 layers) the Winograd-transformed U[16][Kc][Cout]
 static size_t wf_floats(const ConvGeom& g) { return (((size_t)g.K * g.Cout + 63) / 64) * 64; }
 // offset of Wkd (kw-folded thin data gradient) in the packed buffer: after Wf and, for a 4 -> 4 layer, after Wk
-// the direct forward on the split-operand kernel wants WfT; thin (Cout == 4) layers never take it
-static bool wft_wanted(const ConvGeom& g) { return g.Cout >= 64 && g.Cin % 4 == 0; }
+// The direct split-operand kernels take their weight operand pre-split (k_pack_planes): the forward the WFT planes, the data
+// gradient the WFD planes.  Layers that own Winograd copies (every D, R and U block from 128 reduction channels on) run
+// through those in all three directions and get neither; should one of them meet a map Winograd cannot take (odd sizes), it
+// runs on the fp32-MFMA kernels from Wf.  Thin (Cout == 4) layers and the kw-folded data gradient never take them either.
+static bool wft_wanted(const ConvGeom& g) { return g.Cout >= 64 && g.Cin % 4 == 0 && !vcg_wino_weight_ok(g); }
+static bool wfd_wanted(const ConvGeom& g) {
+  return g.Cout >= 64 && g.Cout % 32 == 0 && !vcg_wino_weight_ok(g) && !vcg_thin_fold_dgrad_ok(g) && !vcg_thin_dgrad_ok(g);
+}
+static size_t wft_floats(const ConvGeom& g) { return (size_t)g.Cout * ((g.K + 31) / 32) * 48; }               // 192 bytes per (co, K block)
+static size_t wfd_floats(const ConvGeom& g) { return (size_t)g.KH * g.KW * g.ups * g.ups * g.Cin * (g.Cout / 32) * 48; }
 static size_t wkd_offset(const ConvGeom& g) { return wf_floats(g) + (vcg_thin_fold_ok(g) ? vcg_thin_fold_weight_floats(g) : 0); }
 static size_t wft_offset(const ConvGeom& g) {
   return wf_floats(g) + (vcg_wino_weight_ok(g) ? 2 * vcg_wino_weight_floats(g) : 0) +
          (vcg_thin_fold_ok(g) ? vcg_thin_fold_weight_floats(g) : 0) +
          (vcg_thin_fold_dgrad_ok(g) ? vcg_thin_fold_dgrad_weight_floats(g) : 0);
 }
+static size_t wfd_offset(const ConvGeom& g) { return wft_offset(g) + (wft_wanted(g) ? wft_floats(g) : 0); }
 // the forward kernel on a caller-built geometry (no bias, no activation, no K slicing): conv_thin.hip's kw-folded path
 int vcg_fwd_launch(const ConvGeom& g, const float* x, const float* wf, float* y, hipStream_t st) {
   ConvP p; fill_params(g, p);
@@ -1959,7 +2025,8 @@ extern "C" size_t vcg_pack_weight_floats(const int32_t* cd) {
   return wf_floats(g) + (vcg_wino_weight_ok(g) ? 2 * vcg_wino_weight_floats(g) : 0)   // + U (forward) + Ud (data gradient)
          + (vcg_thin_fold_ok(g) ? vcg_thin_fold_weight_floats(g) : 0)                   // + Wk (kw-folded thin forward)
          + (vcg_thin_fold_dgrad_ok(g) ? vcg_thin_fold_dgrad_weight_floats(g) : 0)       // + Wkd (kw-folded thin data gradient)
-         + (wft_wanted(g) ? wf_floats(g) : 0);                                          // + WfT (split-operand direct forward)
+         + (wft_wanted(g) ? wft_floats(g) : 0)                                          // + WFT planes (split-operand direct forward)
+         + (wfd_wanted(g) ? wfd_floats(g) : 0);                                         // + WFD planes (split-operand direct data gradient)
 }
 
 extern "C" int vcg_pack_weight(const float* w_oihw, float* wf, const int32_t* cd, void* stream) {
@@ -1970,11 +2037,19 @@ extern "C" int vcg_pack_weight(const float* w_oihw, float* wf, const int32_t* cd
   if (vcg_thin_fold_dgrad_ok(g) && vcg_thin_fold_dgrad_pack(g, w_oihw, wf + wkd_offset(g), (hipStream_t)stream)) return -2;
   if (wft_wanted(g)) {
     ConvP q; fill_params(g, q);
-    const size_t tot = (size_t)g.K * g.Cout;
+    const size_t tot = (size_t)g.Cout * ((g.K + 31) / 32) * 8;
     int blocks = (int)((tot + 255) / 256); if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(k_pack_weight_wft, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w_oihw, wf + wft_offset(g), q,
+    hipLaunchKernelGGL(k_pack_planes<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w_oihw, (unsigned short*)(wf + wft_offset(g)), q,
                        g.cin_log, g.cout_log);
-    VCG_LAUNCH_CHECK("vcg_pack_weight(WfT)");
+    VCG_LAUNCH_CHECK("vcg_pack_weight(WFT planes)");
+  }
+  if (wfd_wanted(g)) {
+    ConvP q; fill_params(g, q);
+    const size_t tot = (size_t)g.KH * g.KW * g.ups * g.ups * g.Cin * (g.Cout / 4);
+    int blocks = (int)((tot + 255) / 256); if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(k_pack_planes<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w_oihw, (unsigned short*)(wf + wfd_offset(g)), q,
+                       g.cin_log, g.cout_log);
+    VCG_LAUNCH_CHECK("vcg_pack_weight(WFD planes)");
   }
   if (vcg_wino_weight_ok(g)) {
     if (vcg_wino_weight(g, w_oihw, wf + wf_floats(g), (hipStream_t)stream)) return -2;
@@ -2040,8 +2115,9 @@ extern "C" int vcg_conv_fwd(const float* x, const float* wf, const float* bias, 
   dim3 grid((g.M + bm - 1) / bm, (g.Cout + bn - 1) / bn, nsplit);
   hipStream_t st = (hipStream_t)stream;
   const double gemm_flops = 2.0 * g.M * (double)g.K * g.Cout;
-  if (bm == 128 && bn >= 64 && wft_wanted(g)) {          // split-operand bf16 kernel, B^T from the WfT region of the pack
+  if (bm == 128 && bn >= 64 && wft_wanted(g)) {          // split-operand bf16 kernel, B^T from the pre-split WFT planes of the pack
     p.b = wf + wft_offset(g);
+    p.b_bytes = (uint32_t)(wft_floats(g) * 4);
     VcgProfScope prof(bn == 128 ? "k_conv_fwd_split<128>" : "k_conv_fwd_split<64>", gemm_flops, st);
     if (bn == 128) hipLaunchKernelGGL((k_conv_fwd_split<128>), grid, dim3(256), 0, st, p);
     else hipLaunchKernelGGL((k_conv_fwd_split<64>), grid, dim3(256), 0, st, p);
@@ -2112,11 +2188,13 @@ extern "C" int vcg_conv_dgrad(const float* dy, const float* wf, float* dx, const
   hipStream_t st = (hipStream_t)stream;
   {
     const double gemm_flops = 2.0 * g.M * (double)g.K * g.Cout;   // stride 2: the parity classes together visit every tap once
-    const bool split = (bm == 128 && bn >= 64) || bn == 32;
+    const bool planes = bm == 128 && bn >= 64 && wfd_wanted(g);       // weight rows from the pre-split WFD planes of the pack
+    if (planes) { p.b = wf + wfd_offset(g); p.b_bytes = (uint32_t)(wfd_floats(g) * 4); }
+    const bool split = planes || bn == 32;
     VcgProfScope prof(!split ? "k_conv_dgrad<fp32 MFMA>" : bn == 128 ? "k_conv_dgrad_split<128, 2>" : bn == 64 ? "k_conv_dgrad_split<64, 2>"
                                                                                                              : "k_conv_dgrad_split<32, 1>",
                       gemm_flops, st);
-    if (bm == 128 && bn >= 64) {                            // split-operand bf16 kernel
+    if (planes) {                                           // split-operand bf16 kernel
       if (bn == 128) hipLaunchKernelGGL((k_conv_dgrad_split<128, 2>), grid, dim3(256), 0, st, p);
       else hipLaunchKernelGGL((k_conv_dgrad_split<64, 2>), grid, dim3(256), 0, st, p);
     } else if (bn == 32) hipLaunchKernelGGL((k_conv_dgrad_split<32, 1>), grid, dim3(256), 0, st, p);

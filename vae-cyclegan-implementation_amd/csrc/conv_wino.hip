@@ -13,7 +13,7 @@
 #include "vcg_common.h"
 #include <stdlib.h>
 
-int vcg_gemm_split_batched(const float* A, const float* Bt, float* C, int rows, int K, int N, int batches, hipStream_t st);
+int vcg_gemm_split_batched(const float* A, const void* BtPlanes, float* C, int rows, int K, int N, int batches, hipStream_t st);
 
 struct WinoP {
   const float* x;
@@ -133,72 +133,57 @@ __global__ __launch_bounds__(256) void k_wino_out(WinoP p) {
   }
 }
 
-// U[xi][k][co] = (G g G^T)[xi], G = [[1, 0, 0], [.5, .5, .5], [.5, -.5, .5], [0, 0, 1]]; k = (phase, c) as in Wf.
-// One thread per (k, co), co fastest: coalesced stores into the 16 planes, 36-byte OIHW reads.
-__global__ __launch_bounds__(256) void k_wino_weight(const float* __restrict__ w, float* __restrict__ u, int Cin, int Cout,
-                                                     int ups, int cin_log, int cout_log, int flip) {
+// The transformed kernels (G g G^T)[xi], G = [[1, 0, 0], [.5, .5, .5], [.5, -.5, .5], [0, 0, 1]], written as the B^T operand of
+// the batched GEMM, already split into bf16 "blocked planes" (gemm_split.hip): for GEMM row n and reduction index kk,
+//     up[((xi * NR + n) * KD/32 + kk/32) * 96 + piece * 32 + kk % 32]
+// DGRAD = false: the forward GEMM M = V . U^T — n = co (NR = Cout), kk = k = (phase, c) (KD = Kc);
+// DGRAD = true:  the data-gradient GEMM over the padded domain — n = k (NR = Kc), kk = co (KD = Cout), kernel flipped:
+//                Ud = transform of w[co][k][2 - a][2 - b].
+// One thread per (n, 4 consecutive kk): 36-byte OIHW reads, 8-byte stores per piece and transform point.
+template <bool DGRAD>
+__global__ __launch_bounds__(256) void k_wino_weight_planes(const float* __restrict__ w, unsigned short* __restrict__ up, int Cin,
+                                                            int Cout, int ups, int cin_log, int cout_log) {
   const int U2 = ups * ups, Kc = U2 * Cin;
-  const size_t total = (size_t)Kc * Cout;
+  const int NR = DGRAD ? Kc : Cout, KD = DGRAD ? Cout : Kc;
+  const size_t total = (size_t)NR * (KD / 4);
   for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
-    const int k = (int)(idx / Cout), co = (int)(idx - (size_t)k * Cout);
-    const int ph = k / Cin, c = k - ph * Cin;
-    float g[3][3];
-    const bool ok = co < cout_log && c < cin_log;
-    const float* wp = w + ((size_t)co * (cin_log * U2) + (size_t)c * U2 + ph) * 9;
+    const int n = (int)(idx / (KD / 4)), kk = (int)(idx - (size_t)n * (KD / 4)) * 4;
+    float t[16][4];
 #pragma unroll
-    for (int a = 0; a < 3; ++a)
+    for (int e = 0; e < 4; ++e) {
+      const int co = DGRAD ? kk + e : n, k = DGRAD ? n : kk + e;
+      const int ph = k / Cin, c = k - ph * Cin;
+      const bool ok = co < cout_log && c < cin_log;
+      const float* wp = w + ((size_t)co * (cin_log * U2) + (size_t)c * U2 + ph) * 9;
+      float g[3][3];
 #pragma unroll
-      for (int b = 0; b < 3; ++b) g[a][b] = ok ? (flip ? wp[(2 - a) * 3 + (2 - b)] : wp[a * 3 + b]) : 0.f;
-    float h[4][3];
+      for (int a = 0; a < 3; ++a)
 #pragma unroll
-    for (int b = 0; b < 3; ++b) {
-      h[0][b] = g[0][b];
-      h[1][b] = 0.5f * (g[0][b] + g[1][b] + g[2][b]);
-      h[2][b] = 0.5f * (g[0][b] - g[1][b] + g[2][b]);
-      h[3][b] = g[2][b];
+        for (int b = 0; b < 3; ++b) g[a][b] = ok ? (DGRAD ? wp[(2 - a) * 3 + (2 - b)] : wp[a * 3 + b]) : 0.f;
+      float h[4][3];
+#pragma unroll
+      for (int b = 0; b < 3; ++b) {
+        h[0][b] = g[0][b];
+        h[1][b] = 0.5f * (g[0][b] + g[1][b] + g[2][b]);
+        h[2][b] = 0.5f * (g[0][b] - g[1][b] + g[2][b]);
+        h[3][b] = g[2][b];
+      }
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        t[a * 4 + 0][e] = h[a][0];
+        t[a * 4 + 1][e] = 0.5f * (h[a][0] + h[a][1] + h[a][2]);
+        t[a * 4 + 2][e] = 0.5f * (h[a][0] - h[a][1] + h[a][2]);
+        t[a * 4 + 3][e] = h[a][2];
+      }
     }
 #pragma unroll
-    for (int a = 0; a < 4; ++a) {
-      u[(size_t)(a * 4 + 0) * total + idx] = h[a][0];
-      u[(size_t)(a * 4 + 1) * total + idx] = 0.5f * (h[a][0] + h[a][1] + h[a][2]);
-      u[(size_t)(a * 4 + 2) * total + idx] = 0.5f * (h[a][0] - h[a][1] + h[a][2]);
-      u[(size_t)(a * 4 + 3) * total + idx] = h[a][2];
-    }
-  }
-}
-
-// Data gradient.  dxp = correlation of the zero-extended dy with the flipped kernel over the PADDED domain
-// (Hl + 2) x (Wl + 2); dx then folds the halo back (adjoint of the reflect padding; a plain crop for zero padding) and
-// scatters the unshuffle phases.  Ud[xi][co][k] = (G g' G^T)[xi] with g'[a][b] = w[co][k][2 - a][2 - b].
-// One thread per (co, k), k fastest: coalesced stores, 36-byte OIHW reads that are contiguous along k for ups == 1.
-__global__ __launch_bounds__(256) void k_wino_weight_dgrad(const float* __restrict__ w, float* __restrict__ u, int Cin, int Cout,
-                                                           int ups, int cin_log, int cout_log, int flip) {
-  const int U2 = ups * ups, Kc = U2 * Cin;
-  const size_t total = (size_t)Kc * Cout;
-  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
-    const int co = (int)(idx / Kc), k = (int)(idx - (size_t)co * Kc);
-    const int ph = k / Cin, c = k - ph * Cin;
-    float g[3][3];
-    const bool ok = co < cout_log && c < cin_log;
-    const float* wp = w + ((size_t)co * (cin_log * U2) + (size_t)c * U2 + ph) * 9;
-#pragma unroll
-    for (int a = 0; a < 3; ++a)
-#pragma unroll
-      for (int b = 0; b < 3; ++b) g[a][b] = ok ? (flip ? wp[(2 - a) * 3 + (2 - b)] : wp[a * 3 + b]) : 0.f;
-    float h[4][3];
-#pragma unroll
-    for (int b = 0; b < 3; ++b) {
-      h[0][b] = g[0][b];
-      h[1][b] = 0.5f * (g[0][b] + g[1][b] + g[2][b]);
-      h[2][b] = 0.5f * (g[0][b] - g[1][b] + g[2][b]);
-      h[3][b] = g[2][b];
-    }
-#pragma unroll
-    for (int a = 0; a < 4; ++a) {
-      u[(size_t)(a * 4 + 0) * total + idx] = h[a][0];
-      u[(size_t)(a * 4 + 1) * total + idx] = 0.5f * (h[a][0] + h[a][1] + h[a][2]);
-      u[(size_t)(a * 4 + 2) * total + idx] = 0.5f * (h[a][0] - h[a][1] + h[a][2]);
-      u[(size_t)(a * 4 + 3) * total + idx] = h[a][2];
+    for (int xi = 0; xi < 16; ++xi) {
+      uint2 hh, mm, ll;
+      split4(make_float4(t[xi][0], t[xi][1], t[xi][2], t[xi][3]), hh, mm, ll);
+      unsigned short* o = up + (((size_t)xi * NR + n) * (KD / 32) + kk / 32) * 96 + (kk & 31);
+      *reinterpret_cast<uint2*>(o) = hh;
+      *reinterpret_cast<uint2*>(o + 32) = mm;
+      *reinterpret_cast<uint2*>(o + 64) = ll;
     }
   }
 }
@@ -327,16 +312,17 @@ bool vcg_wino_fwd_ok(const ConvGeom& g) {
   if (Kc * g.Cout < 64ull * (Kc + g.Cout)) return false;
   return T * Kc * 4 < (1ull << 31) && T * g.Cout * 4 < (1ull << 31) && T * Kc * 16 < (1ull << 32);
 }
-size_t vcg_wino_weight_floats(const ConvGeom& g) { return (size_t)16 * g.ups * g.ups * g.Cin * g.Cout; }
+// one transformed copy of the kernel as bf16 blocked planes: 3 pieces x 2 bytes per value = 1.5 floats
+size_t vcg_wino_weight_floats(const ConvGeom& g) { return (size_t)16 * g.ups * g.ups * g.Cin * g.Cout * 3 / 2; }
 size_t vcg_wino_fwd_workspace(const ConvGeom& g) {
   const size_t T = (size_t)g.N * (g.Ho / 2) * (g.Wo / 2);
   return (size_t)16 * T * ((size_t)g.ups * g.ups * g.Cin + g.Cout) * sizeof(float) + 512;
 }
 int vcg_wino_weight(const ConvGeom& g, const float* w_oihw, float* u, hipStream_t st) {
-  const size_t total = (size_t)g.ups * g.ups * g.Cin * g.Cout;
-  // Bt operand of the forward GEMM M = V . U: [xi][co][k], k contiguous
-  hipLaunchKernelGGL(k_wino_weight_dgrad, dim3(wino_blocks(total)), dim3(256), 0, st, w_oihw, u, g.Cin, g.Cout, g.ups,
-                     g.cin_log, g.cout_log, 0);
+  const size_t total = (size_t)g.ups * g.ups * g.Cin * g.Cout / 4;
+  // Bt operand of the forward GEMM M = V . U: [xi][co][k], k contiguous, pre-split
+  hipLaunchKernelGGL(k_wino_weight_planes<false>, dim3(wino_blocks(total)), dim3(256), 0, st, w_oihw, (unsigned short*)u, g.Cin, g.Cout,
+                     g.ups, g.cin_log, g.cout_log);
   VCG_LAUNCH_CHECK("vcg_wino_weight");
   return 0;
 }
@@ -393,10 +379,10 @@ size_t vcg_wino_dgrad_workspace(const ConvGeom& g) {
   return ((size_t)16 * Tp * (kc + g.Cout) + (size_t)g.N * (g.Ho + 2) * (g.Wo + 2) * kc) * sizeof(float) + 1024;
 }
 int vcg_wino_weight_dgrad(const ConvGeom& g, const float* w_oihw, float* ud, hipStream_t st) {
-  const size_t total = (size_t)g.ups * g.ups * g.Cin * g.Cout;
-  // Bt operand of the data-gradient GEMM dXp = Vdy . Ud: [xi][k][co], co contiguous, kernel flipped
-  hipLaunchKernelGGL(k_wino_weight, dim3(wino_blocks(total)), dim3(256), 0, st, w_oihw, ud, g.Cin, g.Cout, g.ups, g.cin_log,
-                     g.cout_log, 1);
+  const size_t total = (size_t)g.ups * g.ups * g.Cin * g.Cout / 4;
+  // Bt operand of the data-gradient GEMM dXp = Vdy . Ud: [xi][k][co], co contiguous, kernel flipped, pre-split
+  hipLaunchKernelGGL(k_wino_weight_planes<true>, dim3(wino_blocks(total)), dim3(256), 0, st, w_oihw, (unsigned short*)ud, g.Cin, g.Cout,
+                     g.ups, g.cin_log, g.cout_log);
   VCG_LAUNCH_CHECK("vcg_wino_weight_dgrad");
   return 0;
 }

@@ -9,6 +9,13 @@
 // 6 bf16 MFMAs of 32 cycles replace 8 fp32 MFMAs of 64: 2.7x less matrix-pipe time; the kernel then runs at what its
 // staging (global -> split -> LDS) and its epilogue allow.
 //
+// The B operand of every call site is a WEIGHT (the Winograd-transformed kernels U / Ud): it is split once per optimizer
+// step, when it is packed ("blocked planes": for Bt[n][k], K % 32 == 0,  bp[(n * K/32 + kb) * 96 + piece * 32 + j]  as
+// bf16, piece 0 / 1 / 2 = h / m / l of Bt[n][32 kb + j] — 192 contiguous bytes per row and K block), so this kernel stages
+// B with plain 16-byte copies and only the activations (A) are split in the K loop: half of the loop's conversion
+// arithmetic gone for the 128-column tile (in-kernel stamps on a ping-pong variant showed that arithmetic to take as long
+// as the MFMAs it sits beside: profiles/r02_gemm_pp_stamps.txt).
+//
 // Tile 128 x BN (BN = 128 or 64), BK = 32, 256 threads = 2 x 2 waves, each wave (64 x BN/2) as 32x32 accumulators.
 // LDS images: per piece [rows][32] bf16, 64-byte rows, the four 16-byte chunks of a row XOR-swizzled by (row >> 2) & 3
 // so that the ds_read_b128 fragment reads (lane = row, 16 consecutive rows per LDS cycle) are conflict-free.
@@ -22,7 +29,7 @@ struct GemmSplitP {
   float* c;
   int rows, K, N;
   uint32_t a_bytes, b_bytes;          // per batch (buffer-load bounds)
-  uint32_t a_bstride, b_bstride;      // floats between batches
+  uint32_t a_bstride, b_bstride;      // floats (a) / bf16 elements (bt planes: 3 per value) between batches
   size_t c_bstride;
 };
 
@@ -34,7 +41,7 @@ __device__ __forceinline__ float4 gs_bload4(__amdgpu_buffer_rsrc_t r, uint32_t o
 
 template <int BN>
 __global__ __launch_bounds__(256, 2) void k_gemm_split(GemmSplitP p) {
-  constexpr int BM = 128, NI = BN / 64, MI = 2, AR = BM / 32, BR = BN / 32;
+  constexpr int BM = 128, NI = BN / 64, MI = 2, AR = BM / 32;
   // [piece][row][32 bf16] as raw bytes: 64 B per row
   __shared__ __attribute__((aligned(16))) unsigned char As[3][BM * 64];
   __shared__ __attribute__((aligned(16))) unsigned char Bs[3][BN * 64];
@@ -54,23 +61,25 @@ __global__ __launch_bounds__(256, 2) void k_gemm_split(GemmSplitP p) {
   }
   const int m0 = mt * BM, n0 = nt * BN;
   const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)(p.a + (size_t)zb * p.a_bstride), 0, (int)p.a_bytes, 0x00020000),
-                               rb = __builtin_amdgcn_make_buffer_rsrc((void*)(p.bt + (size_t)zb * p.b_bstride), 0, (int)p.b_bytes, 0x00020000);
+                               rb = __builtin_amdgcn_make_buffer_rsrc((void*)((const unsigned short*)p.bt + (size_t)zb * p.b_bstride), 0, (int)p.b_bytes, 0x00020000);
   const int s_row = tid >> 3, s_u = tid & 7;                    // staging: row (+32 i), k quad
-  uint32_t aoff[AR], boff[BR];
+  uint32_t aoff[AR];
 #pragma unroll
   for (int i = 0; i < AR; ++i) {
     const int r = m0 + s_row + 32 * i;
     aoff[i] = r < p.rows ? (uint32_t)(((size_t)r * p.K + s_u * 4) * 4) : GS_OOB;
   }
-#pragma unroll
-  for (int i = 0; i < BR; ++i) {
-    const int r = n0 + s_row + 32 * i;
-    boff[i] = r < p.N ? (uint32_t)(((size_t)r * p.K + s_u * 4) * 4) : GS_OOB;
-  }
+  // B planes: thread (row b_r = tid >> 2, 16-byte chunk b_q = tid & 3 of a 64-byte piece row); pass j = (row half, piece)
+  constexpr int BP = 3 * BN / 64;                                 // 16-byte copies per thread and K-step
+  const int b_q = tid & 3, b_r = tid >> 2;
+  const int KB = p.K / 32;
+  const uint32_t boff0 = (uint32_t)(((size_t)(n0 + b_r) * KB) * 192 + b_q * 16);      // N % BN == 0: every row is in range
+  const uint32_t bhalf = (uint32_t)KB * (64u * 192u);
+  const uint32_t bsoff0 = (uint32_t)(b_r * 64 + ((b_q ^ ((b_r >> 2) & 3)) << 4));     // row + 64 keeps the swizzle term
   // LDS byte offset of this thread's quad inside a piece image: row r, chunk (u >> 1) swizzled, half (u & 1)
-  uint32_t soff[AR > BR ? AR : BR];
+  uint32_t soff[AR];
 #pragma unroll
-  for (int i = 0; i < (AR > BR ? AR : BR); ++i) {
+  for (int i = 0; i < AR; ++i) {
     const int r = s_row + 32 * i;
     soff[i] = (uint32_t)(r * 64 + (((s_u >> 1) ^ ((r >> 2) & 3)) << 4) + ((s_u & 1) << 3));
   }
@@ -85,14 +94,15 @@ __global__ __launch_bounds__(256, 2) void k_gemm_split(GemmSplitP p) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = lo[i][j][e] = 0.f;
 
-  float4 va[AR], vb[BR];
-  const int nkt = (p.K + 31) / 32;
+  float4 va[AR];
+  u32x4g vb[BP];
+  const int nkt = KB;                                           // K % 32 == 0 (the planes' block size)
   auto load_tiles = [&](int kt) {
-    const bool kv = kt * 32 + s_u * 4 < p.K;                    // K is a multiple of 4
 #pragma unroll
-    for (int i = 0; i < AR; ++i) va[i] = gs_bload4(ra, (kv && aoff[i] != GS_OOB) ? aoff[i] + (uint32_t)kt * 128u : GS_OOB);
+    for (int i = 0; i < AR; ++i) va[i] = gs_bload4(ra, aoff[i] != GS_OOB ? aoff[i] + (uint32_t)kt * 128u : GS_OOB);
 #pragma unroll
-    for (int i = 0; i < BR; ++i) vb[i] = gs_bload4(rb, (kv && boff[i] != GS_OOB) ? boff[i] + (uint32_t)kt * 128u : GS_OOB);
+    for (int j = 0; j < BP; ++j)
+      vb[j] = __builtin_amdgcn_raw_buffer_load_b128(rb, (int)(boff0 + (uint32_t)(j / 3) * bhalf + (uint32_t)(j % 3) * 64u + (uint32_t)kt * 192u), 0, 0);
   };
   auto store_tiles = [&]() {
 #pragma unroll
@@ -104,13 +114,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_split(GemmSplitP p) {
       *reinterpret_cast<uint2*>(&As[2][soff[i]]) = l;
     }
 #pragma unroll
-    for (int i = 0; i < BR; ++i) {
-      uint2 h, m, l;
-      split4(vb[i], h, m, l);
-      *reinterpret_cast<uint2*>(&Bs[0][soff[i]]) = h;
-      *reinterpret_cast<uint2*>(&Bs[1][soff[i]]) = m;
-      *reinterpret_cast<uint2*>(&Bs[2][soff[i]]) = l;
-    }
+    for (int j = 0; j < BP; ++j) *reinterpret_cast<u32x4g*>(&Bs[j % 3][bsoff0 + 4096 * (j / 3)]) = vb[j];
   };
   // fragment byte offsets (per k slice s: chunk 2s + lh)
   uint32_t fa[MI], fb[NI];
@@ -174,18 +178,41 @@ __global__ __launch_bounds__(256, 2) void k_gemm_split(GemmSplitP p) {
   }
 }
 
-// rows x K times (N x K)^T per batch; K % 4 == 0, N % 64 == 0
-int vcg_gemm_split_batched(const float* A, const float* Bt, float* C, int rows, int K, int N, int batches, hipStream_t st) {
-  VCG_CHECK_ARG(K % 4 == 0 && N % 64 == 0 && rows > 0, "vcg_gemm_split_batched: bad shape rows=%d K=%d N=%d", rows, K, N);
-  VCG_CHECK_ARG((unsigned long long)rows * K * 4 < (1ull << 31) && (unsigned long long)N * K * 4 < (1ull << 31),
+// X[rows][K] fp32 -> blocked planes (see the top of this file); one thread per 4 consecutive k.  K % 32 == 0.
+__global__ __launch_bounds__(256) void k_split_planes(const float* __restrict__ x, unsigned short* __restrict__ bp, size_t quads, int K) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < quads; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t e = i * 4, row = e / K;
+    const int k = (int)(e - row * K);
+    uint2 h, m, l;
+    split4(*reinterpret_cast<const float4*>(x + e), h, m, l);
+    unsigned short* o = bp + (row * (K / 32) + k / 32) * 96 + (k & 31);
+    *reinterpret_cast<uint2*>(o) = h;
+    *reinterpret_cast<uint2*>(o + 32) = m;
+    *reinterpret_cast<uint2*>(o + 64) = l;
+  }
+}
+int vcg_split_planes(const float* x, void* bp, size_t rows, int K, hipStream_t st) {
+  VCG_CHECK_ARG(K % 32 == 0, "vcg_split_planes: K must be a multiple of 32");
+  const size_t quads = rows * K / 4;
+  size_t blocks = (quads + 255) / 256; if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(k_split_planes, dim3((unsigned)blocks), dim3(256), 0, st, x, (unsigned short*)bp, quads, K);
+  VCG_LAUNCH_CHECK("vcg_split_planes");
+  return 0;
+}
+
+// rows x K (fp32) times (N x K)^T (blocked planes) per batch; K % 32 == 0, N % 64 == 0
+int vcg_gemm_split_batched(const float* A, const void* BtPlanes, float* C, int rows, int K, int N, int batches, hipStream_t st) {
+  const float* Bt = (const float*)BtPlanes;
+  VCG_CHECK_ARG(K % 32 == 0 && N % 64 == 0 && rows > 0, "vcg_gemm_split_batched: bad shape rows=%d K=%d N=%d", rows, K, N);
+  VCG_CHECK_ARG((unsigned long long)rows * K * 4 < (1ull << 31) && (unsigned long long)N * K * 6 < (1ull << 31),
                 "vcg_gemm_split_batched: operand extents must stay below 2 GiB per batch");
   VCG_CHECK_ARG((unsigned long long)rows * K * (unsigned long long)batches < (1ull << 32) &&
-                    (unsigned long long)N * K * (unsigned long long)batches < (1ull << 32),
+                    (unsigned long long)N * K * 3 * (unsigned long long)batches < (1ull << 32),
                 "vcg_gemm_split_batched: batch stride overflow");
   GemmSplitP p;
   p.a = A; p.bt = Bt; p.c = C; p.rows = rows; p.K = K; p.N = N;
-  p.a_bytes = (uint32_t)((size_t)rows * K * 4); p.b_bytes = (uint32_t)((size_t)N * K * 4);
-  p.a_bstride = (uint32_t)((size_t)rows * K); p.b_bstride = (uint32_t)((size_t)N * K);
+  p.a_bytes = (uint32_t)((size_t)rows * K * 4); p.b_bytes = (uint32_t)((size_t)N * K * 6);
+  p.a_bstride = (uint32_t)((size_t)rows * K); p.b_bstride = (uint32_t)((size_t)N * K * 3);
   p.c_bstride = (size_t)rows * N;
   const int bn = (N % 128 == 0) ? 128 : 64;
   dim3 grid((rows + 127) / 128, N / bn, batches);

@@ -85,7 +85,8 @@ class SyntheticImages:
 
     def image(self, idx, which):
         rng = np.random.RandomState((self.seed * 1000003 + idx * 2 + which) % (2 ** 31 - 1))
-        h, w = (int(v) for v in rng.randint(self.min_side, self.max_side + 1, 2))
+        size_rng = np.random.RandomState((self.seed * 7919 + idx) % (2 ** 31 - 1)) if self.paired else rng
+        h, w = (int(v) for v in size_rng.randint(self.min_side, self.max_side + 1, 2))      # paired: both halves of one image
         yy, xx = np.mgrid[0:h, 0:w].astype(np.float32)
         img = np.empty((h, w, 3), np.float32)
         for c in range(3):

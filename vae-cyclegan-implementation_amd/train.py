@@ -30,9 +30,9 @@ if __package__ in (None, ""):
     import importlib
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     _pkg = importlib.import_module("vae-cyclegan-implementation_amd")
-    Networks, ops, parallel, utils = _pkg.Networks, _pkg.ops, _pkg.parallel, _pkg.utils
+    Networks, ops, parallel, utils, input_pipeline = _pkg.Networks, _pkg.ops, _pkg.parallel, _pkg.utils, _pkg.input_pipeline
 else:
-    from . import Networks, ops, parallel, utils
+    from . import Networks, input_pipeline, ops, parallel, utils
 
 ALIASES = {"ae": "autoencoder", "vae_cyclegan": "cyclevaegan"}
 REFERENCE_ARCHS = ["autoencoder", "doubleae", "doublevae", "vae", "aegan", "vaegan", "cycleae", "cyclevae",
@@ -198,11 +198,31 @@ def build_parser():
     return p
 
 
+def create_dataloaders(args, device, rank, world, epoch_seed):
+    """reference train.py:174-357 (create_dataloaders_hypersim / _maps / _summer2winter) on the device-side input pipeline:
+    PIL decodes, the MI355X flips, crops, resamples, jitters and converts (input_pipeline.py).  `summer2winter` and `maps` read
+    the reference's directory layouts; `hypersim`'s HDF5-derived tree (Data_Manager.py:18-326) is not rebuilt."""
+    if args.dataset == "hypersim":
+        raise NotImplementedError("--dataset hypersim: the Hypersim scene tree of Data_Manager.py:18-326 is not rebuilt; "
+                                  "use summer2winter, maps or synthetic")
+    root = os.path.join(args.data_dir, args.dataset)
+    same_xy = args.architecture in ("autoencoder", "vae")
+    test_split = "test" if args.dataset == "summer2winter" else "val"
+    train_src = input_pipeline.FolderPairs(root, args.dataset, "train")
+    test_src = input_pipeline.FolderPairs(root, args.dataset, test_split)
+    print(f"Training samples: {len(train_src)}\nTesting samples: {len(test_src)}")
+    kw = dict(num_workers=max(1, args.num_workers), same_xy=same_xy)
+    train = input_pipeline.DeviceInputPipeline(train_src, args.batch_size, args.image_size, device, recipe=args.dataset, shuffle=True,
+                                               seed=epoch_seed * 64 + rank, **kw)
+    test = input_pipeline.DeviceInputPipeline(test_src, args.batch_size, args.image_size, device, recipe="test", shuffle=False,
+                                              seed=epoch_seed * 64 + rank, **kw)
+    return train, test
+
+
 def main(args):
     args.architecture = ALIASES.get(args.architecture, args.architecture)
-    if args.dataset != "synthetic":
-        raise NotImplementedError("only --dataset synthetic is built: the image pipelines of Data_Manager.py "
-                                  "(PIL + torchvision) are outside the accelerated path (SURVEY.md §2)")
+    if args.dataset in ("summer2winter",):
+        args.paired = False                          # reference train.py:380-382: unpaired data forces the unpaired objectives
     if args.no_cuda or not torch.cuda.is_available():
         raise RuntimeError("this path has no CPU implementation: an MI355X is required (the reference's own "
                            "train.py is the CPU path)")
@@ -258,9 +278,10 @@ def main(args):
         # the same file; the broadcast also invalidates the weight packs of anything a load or a warm-up forward packed
         parallel.broadcast_parameters(model)
     best_test_loss = utils.LAST_EXTRAS.get("best_test_loss", float("inf")) if args.resume else float("inf")
+    image_loaders = create_dataloaders(args, device, rank, world, args.seed) if args.dataset != "synthetic" else None
     for epoch in range(start_epoch, args.epochs):
-        loader = SyntheticLoader(args.batch_size, args.image_size, args.steps_per_epoch, device, args.seed, rank,
-                                 same_xy, epoch)
+        loader = image_loaders[0] if image_loaders else SyntheticLoader(args.batch_size, args.image_size, args.steps_per_epoch, device,
+                                                                       args.seed, rank, same_xy, epoch)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         train_loss, comps, *_ = train_epoch(model, loader, device, args, epoch=epoch)
@@ -274,8 +295,8 @@ def main(args):
         # on the test set (reference train.py:533-537: every log_image_freq epochs); here a held-out synthetic stream.
         # validation_step has no exchange in it: every rank validates its own shard, rank 0 prints its numbers
         if args.log_image_freq > 0 and epoch % args.log_image_freq == 0:
-            test_loader = SyntheticLoader(args.batch_size, args.image_size, max(1, args.steps_per_epoch // 10), device,
-                                          args.seed + 1, rank, same_xy, epoch)
+            test_loader = image_loaders[1] if image_loaders else SyntheticLoader(
+                args.batch_size, args.image_size, max(1, args.steps_per_epoch // 10), device, args.seed + 1, rank, same_xy, epoch)
             test_loss, test_comps, *_ = validate(model, test_loader, device, args)
             if rank == 0:
                 print(f"Test Loss: {test_loss:.4f}")
