@@ -48,7 +48,7 @@ enum {
   VCG_CD_LEN = 16
 };
 
-enum { VCG_ACT_NONE = 0, VCG_ACT_RELU = 1, VCG_ACT_LEAKY02 = 2 };
+enum { VCG_ACT_NONE = 0, VCG_ACT_RELU = 1, VCG_ACT_LEAKY02 = 2, VCG_ACT_TANH = 3, VCG_ACT_SIGMOID = 4 };   /* CaSb's choices, Networks.py:62-73 */
 
 int vcg_abi_version(void);
 const char* vcg_last_error(void);
@@ -88,6 +88,15 @@ int vcg_pack_weight(const float* w_oihw, float* wf, const int32_t* cd, void* str
 size_t vcg_conv_fwd_workspace(const int32_t* cd);
 int vcg_conv_fwd(const float* x, const float* wf, const float* bias, float* y,
                  const int32_t* cd, void* ws, size_t ws_bytes, void* stream);
+
+/* The same convolution when an InstanceNorm follows it (CaSb with norm=True, /root/reference/Networks.py:93-95): y as
+   above AND mean / rstd (N x Cout each) of y over its pixels, biased variance, rstd = 1 / sqrt(var + eps) — what
+   vcg_in_stats(y) returns.  Where the conv's launch plan allows (Winograd output transform; direct split-operand tiles
+   with Ho*Wo % 128 == 0) the statistics' partial sums (in double) are written by the conv's own epilogue, so y is not
+   read again; otherwise the separate reduction pass runs.  `ws`: vcg_conv_fwd_in_workspace(cd) bytes. */
+size_t vcg_conv_fwd_in_workspace(const int32_t* cd);
+int vcg_conv_fwd_in(const float* x, const float* wf, const float* bias, float* y, float* mean, float* rstd, float eps,
+                    const int32_t* cd, void* ws, size_t ws_bytes, void* stream);
 /* dx = conv^T(dy) including the adjoint of the reflect padding.              */
 size_t vcg_conv_dgrad_workspace(const int32_t* cd);
 int vcg_conv_dgrad(const float* dy, const float* wf, float* dx, const int32_t* cd,

@@ -46,6 +46,10 @@ def _act(x, name):
         return F.leaky_relu(x, 0.2)
     if name == "Identity":
         return x
+    if name == "Tanh":
+        return torch.tanh(x)
+    if name == "Sigmoid":
+        return torch.sigmoid(x)
     raise NotImplementedError(name)
 
 

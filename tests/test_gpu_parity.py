@@ -225,6 +225,29 @@ def test_zero_padded_conv_matches_torch(shape, pkg, device):
     assert_close(bd.grad.cpu(), br.grad, "zero-pad db")
 
 
+@pytest.mark.parametrize("activation,use_norm", [("Tanh", True), ("Tanh", False), ("Sigmoid", True), ("Sigmoid", False)])
+def test_casb_tanh_and_sigmoid_match_the_oracle(activation, use_norm, pkg, oracle, device):
+    """The two CaSb activations no reference network uses (Networks.py:66-69): forward, data and weight gradients against
+    the oracle's torch.tanh / torch.sigmoid (after the InstanceNorm when there is one, in the conv epilogue when not)."""
+    name = f"casb_{activation}_{use_norm}"
+    shapes = {f"{name}.conv.weight": (8, 4, 3, 3), f"{name}.conv.bias": (8,)}
+    P = {k: torch.from_numpy(v) for k, v in pkg.synth.state_dict_like(shapes, SEED, bias_std=0.1).items()}
+    x_np = pkg.synth.normal((2, 4, 9, 7), SEED, name + "/x")
+    g_np = pkg.synth.normal((2, 8, 9, 7), SEED, name + "/g")
+    Q = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    xr = torch.from_numpy(x_np).requires_grad_(True)
+    yr = oracle.casb(xr, Q, name + ".", 1, 1, activation, use_norm)
+    yr.backward(torch.from_numpy(g_np))
+    mod = pkg.Networks.CaSb(4, 8, 3, stride=1, padding=1, activation=activation, use_norm=use_norm)
+    mod.load_state_dict({k[len(name) + 1:]: v for k, v in P.items()})
+    y, dx, grads = run_module(mod, x_np, g_np, device)
+    assert_close(y, yr.detach(), "y")
+    assert_close(dx, xr.grad, "dx")
+    assert_close(grads["conv.weight"], Q[name + ".conv.weight"].grad, "dw")
+    if not use_norm:
+        assert_close(grads["conv.bias"], Q[name + ".conv.bias"].grad, "db")
+
+
 def test_layout_round_trip_and_views(pkg, device):
     ops = pkg.ops
     for c in (3, 8):

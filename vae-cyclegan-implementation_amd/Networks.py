@@ -22,7 +22,7 @@ from .Losses import (CycleConsistencyLoss, GANLossDiscriminator, GANLossGenerato
                      KLDivergenceLoss, TranslationLoss)
 from .optim import FusedAdam
 
-_ACTS = {"ReLU": ops.ACT_RELU, "LeakyReLU": ops.ACT_LEAKY, "Identity": ops.ACT_NONE}
+_ACTS = {"ReLU": ops.ACT_RELU, "LeakyReLU": ops.ACT_LEAKY, "Identity": ops.ACT_NONE, "Tanh": ops.ACT_TANH, "Sigmoid": ops.ACT_SIGMOID}
 
 
 def _kaiming_relu_init(module):
@@ -55,8 +55,6 @@ class CaSb(nn.Module):
                                       act if act is not None else 0, False)
 
     def forward(self, x):
-        if self.activation_name not in _ACTS:
-            raise NotImplementedError(f"{self.activation_name} epilogue is not built: the training path uses ReLU/LeakyReLU/Identity only")
         return ops.conv_block(x, self.conv.weight, self.conv.bias, self._spec)
 
 

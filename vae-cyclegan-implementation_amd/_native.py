@@ -34,6 +34,8 @@ SIGNATURES = {
     "vcg_pack_weight": (_I, [_P, _P, _I32P, _P]),
     "vcg_conv_fwd_workspace": (_Z, [_I32P]),
     "vcg_conv_fwd": (_I, [_P, _P, _P, _P, _I32P, _P, _Z, _P]),
+    "vcg_conv_fwd_in_workspace": (_Z, [_I32P]),
+    "vcg_conv_fwd_in": (_I, [_P, _P, _P, _P, _P, _P, _F, _I32P, _P, _Z, _P]),
     "vcg_conv_dgrad_workspace": (_Z, [_I32P]),
     "vcg_conv_dgrad": (_I, [_P, _P, _P, _I32P, _P, _Z, _P]),
     "vcg_conv_wgrad_workspace": (_Z, [_I32P]),

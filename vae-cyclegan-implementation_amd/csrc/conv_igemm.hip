@@ -57,6 +57,10 @@ struct ConvP {
   int nbatch;
   uint32_t a_bstride, b_bstride;   // floats between consecutive batches of a / b
   size_t out_bstride;
+  // forward into an InstanceNorm (vcg_conv_fwd_in): the tile also leaves sum / sum of squares of its 128 output rows per
+  // channel, as chunk `(m0 % HoWo) / 128` of image `m0 / HoWo` in the [N][nchunk][Cout][2] double partials of norm.hip
+  double* in_part;
+  int in_nchunk;
 };
 
 #define BK 32
@@ -599,19 +603,43 @@ __global__ __launch_bounds__(256, 2) void k_conv_fwd_split(ConvP p) {
   // a K slice stores its raw partial tile instead (bias/activation happen in k_splitk_finish)
   float* const dst = p.ksplit > 1 ? p.slab + (size_t)blockIdx.z * p.M * p.Cout : p.out + (size_t)zb * p.out_bstride;
   const int act = p.ksplit > 1 ? VCG_ACT_NONE : p.act;
+  float* const red = reinterpret_cast<float*>(&As[0][0]);     // [wm][BN][2] floats; the K loop's last barrier freed As
 #pragma unroll
   for (int j = 0; j < NI; ++j) {
-    const int co = n0 + wn * (BN / WN) + j * 32 + l31;
-    if (co >= p.Cout) continue;
-    const float bv = (p.ksplit <= 1 && p.bias && co < p.cout_log) ? p.bias[co] : 0.f;
+    const int cl = wn * (BN / WN) + j * 32 + l31;
+    const int co = n0 + cl;
+    const bool cv = co < p.Cout;
+    const float bv = (cv && p.ksplit <= 1 && p.bias && co < p.cout_log) ? p.bias[co] : 0.f;
+    float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int row = (e & 3) + 8 * (e >> 2) + 4 * lh;
         const int m = m0 + wm * (BM / WM) + i * 32 + row;
-        if (m < p.M) dst[(size_t)m * p.Cout + co] = act_apply(acc[i][j][e] + bv, act);
+        const float v = act_apply(acc[i][j][e] + bv, act);
+        if (cv && m < p.M) dst[(size_t)m * p.Cout + co] = v;
+        s1 += v;
+        s2 += v * v;
       }
+    }
+    if (p.in_part) {                    // uniform; the host only sets it when every tile row is a valid pixel of ONE image
+      s1 += __shfl_xor(s1, 32);
+      s2 += __shfl_xor(s2, 32);
+      if (lh == 0) {
+        red[(wm * BN + cl) * 2] = s1;
+        red[(wm * BN + cl) * 2 + 1] = s2;
+      }
+    }
+  }
+  if (p.in_part) {
+    __syncthreads();
+    if (tid < BN && n0 + tid < p.Cout) {
+      const uint32_t n = fd_div((uint32_t)m0, p.fd_howo);
+      const uint32_t chunk = ((uint32_t)m0 - n * (uint32_t)(p.Ho * p.Wo)) / BM;
+      double* o = p.in_part + (((size_t)n * p.in_nchunk + chunk) * p.Cout + n0 + tid) * 2;
+      o[0] = (double)red[tid * 2] + (double)red[(BN + tid) * 2];
+      o[1] = (double)red[tid * 2 + 1] + (double)red[(BN + tid) * 2 + 1];
     }
   }
   VCG_STAMP_AT(3);
@@ -1861,7 +1889,7 @@ int vcg_conv_geom(const int32_t* cd, ConvGeom* g, const char* who) {
   VCG_CHECK_ARG(g->H % g->ups == 0 && g->W % g->ups == 0, "%s: H,W must be divisible by ups", who);
   VCG_CHECK_ARG(g->cin_log > 0 && g->cin_log <= g->Cin && g->cout_log > 0 && g->cout_log <= g->Cout,
                 "%s: logical channels out of range", who);
-  VCG_CHECK_ARG(g->act >= 0 && g->act <= 2, "%s: bad act", who);
+  VCG_CHECK_ARG(g->act >= 0 && g->act <= VCG_ACT_SIGMOID, "%s: bad act", who);
   g->Hl = g->H / g->ups; g->Wl = g->W / g->ups;
   VCG_CHECK_ARG(g->KH > 0 && g->KW > 0 && g->pad >= 0, "%s: bad kernel/pad", who);
   VCG_CHECK_ARG(g->Hl + 2 * g->pad >= g->KH && g->Wl + 2 * g->pad >= g->KW, "%s: kernel larger than padded input", who);
@@ -1900,6 +1928,7 @@ static void fill_params(const ConvGeom& g, ConvP& p) {
   p.ksplit = 1; p.kt_per = 0; p.slab = nullptr; p.adjoint = 0; p.src_pitch = g.Cout;
   p.a_bytes = p.b_bytes = 0; p.dbl_mirror = 0;
   p.bias = nullptr;
+  p.in_part = nullptr; p.in_nchunk = 0;
 }
 
 // Tile and K-slice choice.  The 256 CUs want >= 512 workgroups.  If the largest tile that reaches that
@@ -2091,15 +2120,30 @@ static int ew_grid(size_t work) {
   return b < 1 ? 1 : (int)b;
 }
 
-extern "C" int vcg_conv_fwd(const float* x, const float* wf, const float* bias, float* y,
-                            const int32_t* cd, void* ws, size_t ws_bytes, void* stream) {
+// does the direct split-operand forward leave the InstanceNorm partials itself?  (every 128-row tile inside one image)
+static bool fwd_tile_stats_ok(const ConvGeom& g) {
+  if (vcg_thin_fold_ok(g) || vcg_thin_fwd_ok(g) || vcg_wino_fwd_ok(g)) return false;
+  int bm, bn, nsplit, kt_per;
+  fwd_plan(g, bm, bn, nsplit, kt_per);
+  return bm == 128 && bn >= 64 && nsplit == 1 && wft_wanted(g) && (g.Ho * g.Wo) % 128 == 0;
+}
+
+// in_part != nullptr: also leave the InstanceNorm chunk partials of y there (the caller checked that this launch plan
+// can: Winograd, or fwd_tile_stats_ok) and report the chunk count per image.
+static int conv_fwd_impl(const float* x, const float* wf, const float* bias, float* y, const int32_t* cd, void* ws,
+                         size_t ws_bytes, void* stream, double* in_part, int* in_nchunk) {
   ConvGeom g;
   if (vcg_conv_geom(cd, &g, "vcg_conv_fwd")) return -1;
   VCG_CHECK_ARG(x && wf && y, "vcg_conv_fwd: null pointer");
   if (vcg_thin_fold_ok(g)) return vcg_thin_fold_fwd(g, x, wf + wf_floats(g), bias, y, ws, ws_bytes, (hipStream_t)stream);
   if (vcg_thin_fwd_ok(g)) return vcg_thin_fwd(g, x, wf, bias, y, (hipStream_t)stream);
-  if (vcg_wino_fwd_ok(g)) return vcg_wino_fwd(g, x, wf + wf_floats(g), bias, y, ws, ws_bytes, (hipStream_t)stream);
+  if (vcg_wino_fwd_ok(g))
+    return vcg_wino_fwd(g, x, wf + wf_floats(g), bias, y, ws, ws_bytes, (hipStream_t)stream, in_part, in_nchunk);
   ConvP p; fill_params(g, p);
+  if (in_part) {
+    p.in_part = in_part;
+    p.in_nchunk = *in_nchunk = g.Ho * g.Wo / 128;
+  }
   p.a = x; p.b = wf; p.bias = bias; p.out = y;
   {
     const unsigned long long ab = (unsigned long long)g.N * g.H * g.W * g.Cin * 4, bb = (unsigned long long)g.K * g.Cout * 4;
@@ -2131,6 +2175,42 @@ extern "C" int vcg_conv_fwd(const float* x, const float* wf, const float* bias, 
                        y, (size_t)g.M, g.Cout, nsplit, g.cout_log, g.act);
   VCG_LAUNCH_CHECK("vcg_conv_fwd");
   return 0;
+}
+
+extern "C" int vcg_conv_fwd(const float* x, const float* wf, const float* bias, float* y,
+                            const int32_t* cd, void* ws, size_t ws_bytes, void* stream) {
+  return conv_fwd_impl(x, wf, bias, y, cd, ws, ws_bytes, stream, nullptr, nullptr);
+}
+
+// ---- convolution + the statistics of the InstanceNorm that follows it (CaSb with norm=True, Networks.py:93-95) ----------
+// Workspace: [conv workspace, rounded to 256 B][statistics partials].  Where the conv's launch plan can, the partial sums
+// come out of the conv's own epilogue (Winograd output transform; the direct split-operand tiles) and only the tiny
+// finalize kernel follows; otherwise y is reduced by the same pass vcg_in_stats runs.
+static size_t fwd_in_conv_ws(const int32_t* cd) { return (vcg_conv_fwd_workspace(cd) + 255) / 256 * 256; }
+
+extern "C" size_t vcg_conv_fwd_in_workspace(const int32_t* cd) {
+  ConvGeom g;
+  if (vcg_conv_geom(cd, &g, "vcg_conv_fwd_in_workspace")) return 0;
+  size_t part;
+  if (vcg_wino_fwd_ok(g)) part = vcg_wino_fwd_stats_doubles(g) * sizeof(double);
+  else if (fwd_tile_stats_ok(g)) part = (size_t)g.N * (g.Ho * g.Wo / 128) * g.Cout * 2 * sizeof(double);
+  else part = vcg_in_workspace(g.N, g.Ho * g.Wo, g.Cout);
+  return fwd_in_conv_ws(cd) + part;
+}
+
+extern "C" int vcg_conv_fwd_in(const float* x, const float* wf, const float* bias, float* y, float* mean, float* rstd,
+                               float eps, const int32_t* cd, void* ws, size_t ws_bytes, void* stream) {
+  ConvGeom g;
+  if (vcg_conv_geom(cd, &g, "vcg_conv_fwd_in")) return -1;
+  VCG_CHECK_ARG(mean && rstd && ws, "vcg_conv_fwd_in: null pointer");
+  VCG_CHECK_ARG(ws_bytes >= vcg_conv_fwd_in_workspace(cd), "vcg_conv_fwd_in: workspace too small (%zu)", ws_bytes);
+  const size_t cws = fwd_in_conv_ws(cd);
+  double* part = reinterpret_cast<double*>(static_cast<char*>(ws) + cws);
+  const bool fused = vcg_wino_fwd_ok(g) || fwd_tile_stats_ok(g);
+  int nchunk = 0;
+  if (conv_fwd_impl(x, wf, bias, y, cd, ws, cws, stream, fused ? part : nullptr, &nchunk)) return -1;
+  if (fused) return vcg_in_finalize(part, mean, rstd, g.N, g.Ho * g.Wo, g.Cout, nchunk, eps, (hipStream_t)stream);
+  return vcg_in_stats_pass(y, mean, rstd, g.N, g.Ho * g.Wo, g.Cout, eps, part, ws_bytes - cws, (hipStream_t)stream);
 }
 
 static int dgrad_setup(const ConvGeom& g, ConvP& p, int& bm, int& bn, int& nsplit, int& kt_per) {

@@ -133,6 +133,87 @@ __global__ __launch_bounds__(256) void k_wino_out(WinoP p) {
   }
 }
 
+// The same output transform for a layer whose output goes into an InstanceNorm: it also leaves the statistics' chunk
+// partials (sum and sum of squares per (image, channel), in double: norm.hip) so that no extra pass has to re-read y.
+// Grid (chunk of tiles, image, channel-quad group); thread = (channel quad, tile lane), as in k_in_partial.
+__global__ __launch_bounds__(256) void k_wino_out_stats(WinoP p, double* __restrict__ part, NormPlan pl) {
+  __shared__ double r1[256 * 4];
+  __shared__ double r2[256 * 4];
+  const int tc = threadIdx.x % pl.TC, tp = threadIdx.x / pl.TC;
+  const int c4 = blockIdx.z * pl.TC + tc;
+  const int n = blockIdx.y;
+  const int tiles = p.th * p.tw;
+  const int pb = blockIdx.x * pl.chunk;
+  int pe = pb + pl.chunk;
+  if (pe > tiles) pe = tiles;
+  const size_t plane = (size_t)p.T * p.Cout;
+  double s1[4] = {0.0, 0.0, 0.0, 0.0}, s2[4] = {0.0, 0.0, 0.0, 0.0};
+  if (c4 * 4 < p.Cout) {
+    const int co = c4 * 4;
+    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p.bias) {
+      if (co + 0 < p.cout_log) bv.x = p.bias[co + 0];
+      if (co + 1 < p.cout_log) bv.y = p.bias[co + 1];
+      if (co + 2 < p.cout_log) bv.z = p.bias[co + 2];
+      if (co + 3 < p.cout_log) bv.w = p.bias[co + 3];
+    }
+    for (int tl = pb + tp; tl < pe; tl += pl.TP) {
+      const int ty = tl / p.tw, tx = tl - ty * p.tw;
+      const size_t t = (size_t)n * tiles + tl;
+      const float* mb = p.m + t * p.Cout + co;
+      float4 a0[4], a1[4];
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const float4 m0 = *reinterpret_cast<const float4*>(mb + (size_t)(0 + b) * plane);
+        const float4 m1 = *reinterpret_cast<const float4*>(mb + (size_t)(4 + b) * plane);
+        const float4 m2 = *reinterpret_cast<const float4*>(mb + (size_t)(8 + b) * plane);
+        const float4 m3 = *reinterpret_cast<const float4*>(mb + (size_t)(12 + b) * plane);
+        a0[b] = f4sum(f4sum(m0, m1), m2);
+        a1[b] = f4sub(f4sub(m1, m2), m3);
+      }
+      float4 y[2][2];
+      y[0][0] = f4sum(f4sum(a0[0], a0[1]), a0[2]);
+      y[0][1] = f4sub(f4sub(a0[1], a0[2]), a0[3]);
+      y[1][0] = f4sum(f4sum(a1[0], a1[1]), a1[2]);
+      y[1][1] = f4sub(f4sub(a1[1], a1[2]), a1[3]);
+#pragma unroll
+      for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          float4 o = y[r][q];
+          o.x = act_apply(o.x + bv.x, p.act); o.y = act_apply(o.y + bv.y, p.act);
+          o.z = act_apply(o.z + bv.z, p.act); o.w = act_apply(o.w + bv.w, p.act);
+          *reinterpret_cast<float4*>(p.y + (((size_t)n * p.Hl + 2 * ty + r) * p.Wl + 2 * tx + q) * p.Cout + co) = o;
+          s1[0] += (double)o.x; s2[0] += (double)o.x * (double)o.x;
+          s1[1] += (double)o.y; s2[1] += (double)o.y * (double)o.y;
+          s1[2] += (double)o.z; s2[2] += (double)o.z * (double)o.z;
+          s1[3] += (double)o.w; s2[3] += (double)o.w * (double)o.w;
+        }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    r1[threadIdx.x * 4 + e] = s1[e];
+    r2[threadIdx.x * 4 + e] = s2[e];
+  }
+  __syncthreads();
+  if (tp == 0 && c4 * 4 < p.Cout) {
+    for (int k = 1; k < pl.TP; ++k) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        s1[e] += r1[(k * pl.TC + tc) * 4 + e];
+        s2[e] += r2[(k * pl.TC + tc) * 4 + e];
+      }
+    }
+    double* o = part + (((size_t)n * pl.nchunk + blockIdx.x) * p.Cout + c4 * 4) * 2;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      o[2 * e] = s1[e];
+      o[2 * e + 1] = s2[e];
+    }
+  }
+}
+
 // The transformed kernels (G g G^T)[xi], G = [[1, 0, 0], [.5, .5, .5], [.5, -.5, .5], [0, 0, 1]], written as the B^T operand of
 // the batched GEMM, already split into bf16 "blocked planes" (gemm_split.hip): for GEMM row n and reduction index kk,
 //     up[((xi * NR + n) * KD/32 + kk/32) * 96 + piece * 32 + kk % 32]
@@ -414,8 +495,13 @@ int vcg_wino_dgrad(const ConvGeom& g, const float* dy, const float* ud, float* d
   return 0;
 }
 
+// doubles the Winograd forward writes when it also leaves InstanceNorm chunk partials (vcg_conv_fwd_in)
+size_t vcg_wino_fwd_stats_doubles(const ConvGeom& g) {
+  const NormPlan pl = vcg_norm_plan(g.N, (g.Ho / 2) * (g.Wo / 2), g.Cout);
+  return (size_t)g.N * pl.nchunk * g.Cout * 2;
+}
 int vcg_wino_fwd(const ConvGeom& g, const float* x, const float* u, const float* bias, float* y, void* ws, size_t ws_bytes,
-                 hipStream_t st) {
+                 hipStream_t st, double* in_part, int* in_nchunk) {
   VCG_CHECK_ARG(ws && ws_bytes >= vcg_wino_fwd_workspace(g), "vcg_conv_fwd: workspace too small for the Winograd path (%zu)",
                 ws_bytes);
   WinoP p = wino_params(g);
@@ -425,7 +511,13 @@ int vcg_wino_fwd(const ConvGeom& g, const float* x, const float* u, const float*
   hipLaunchKernelGGL(k_wino_in, dim3(wino_blocks((size_t)p.T * p.Kc / 4)), dim3(256), 0, st, p);
   VCG_LAUNCH_CHECK("vcg_conv_fwd(winograd input transform)");
   if (vcg_gemm_split_batched(V, u, M, p.T, p.Kc, g.Cout, 16, st)) return -2;
-  hipLaunchKernelGGL(k_wino_out, dim3(wino_blocks((size_t)p.T * g.Cout / 4)), dim3(256), 0, st, p);
+  if (in_part) {
+    const NormPlan pl = vcg_norm_plan(g.N, p.th * p.tw, g.Cout);
+    hipLaunchKernelGGL(k_wino_out_stats, dim3(pl.nchunk, g.N, pl.cgroups), dim3(256), 0, st, p, in_part, pl);
+    *in_nchunk = pl.nchunk;
+  } else {
+    hipLaunchKernelGGL(k_wino_out, dim3(wino_blocks((size_t)p.T * g.Cout / 4)), dim3(256), 0, st, p);
+  }
   VCG_LAUNCH_CHECK("vcg_conv_fwd(winograd output transform)");
   return 0;
 }

@@ -11,27 +11,7 @@
 // a single fp32 pass would have.
 #include "vcg_common.h"
 
-struct NormPlan {
-  int TC, TP, cgroups, nchunk, chunk;
-};
-
-static NormPlan make_plan(int N, int HW, int C) {
-  NormPlan pl;
-  int c4 = C / 4;
-  int tc = 1;
-  while (tc * 2 <= c4 && tc * 2 <= 256) tc *= 2;
-  pl.TC = tc;
-  pl.TP = 256 / tc;
-  pl.cgroups = (c4 + tc - 1) / tc;
-  long long target = 1024 / ((long long)N * pl.cgroups);
-  if (target < 1) target = 1;
-  long long maxc = (HW + pl.TP * 2 - 1) / (pl.TP * 2);
-  if (maxc < 1) maxc = 1;
-  if (target > maxc) target = maxc;
-  pl.chunk = (int)((HW + target - 1) / target);
-  pl.nchunk = (HW + pl.chunk - 1) / pl.chunk;
-  return pl;
-}
+static NormPlan make_plan(int N, int HW, int C) { return vcg_norm_plan(N, HW, C); }
 
 // ---- stage 1 of every per-(n,c) reduction -------------------------------------------
 // MODE 0: (sum t, sum t^2)
@@ -90,7 +70,7 @@ __global__ __launch_bounds__(256) void k_in_partial(const float* __restrict__ t,
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const float xh = (v[e] - mu[e]) * rs[e];
-          const float gg = gv[e] * act_grad_from_out(xh, post_act);
+          const float gg = gv[e] * act_grad_from_in(xh, post_act);
           s1[e] += (double)gg;
           s2[e] += (double)gg * (double)xh;
         }
@@ -224,13 +204,13 @@ __global__ __launch_bounds__(256) void k_in_bwd_apply(const float* __restrict__ 
     }
     float xh, gg;
     float4 o;
-    xh = (v.x - mu.x) * rs.x; gg = gv.x * act_grad_from_out(xh, post_act);
+    xh = (v.x - mu.x) * rs.x; gg = gv.x * act_grad_from_in(xh, post_act);
     o.x = act_grad_from_out(v.x, epi_act) * rs.x * (gg - sp[0] - xh * sp[1]);
-    xh = (v.y - mu.y) * rs.y; gg = gv.y * act_grad_from_out(xh, post_act);
+    xh = (v.y - mu.y) * rs.y; gg = gv.y * act_grad_from_in(xh, post_act);
     o.y = act_grad_from_out(v.y, epi_act) * rs.y * (gg - sp[2] - xh * sp[3]);
-    xh = (v.z - mu.z) * rs.z; gg = gv.z * act_grad_from_out(xh, post_act);
+    xh = (v.z - mu.z) * rs.z; gg = gv.z * act_grad_from_in(xh, post_act);
     o.z = act_grad_from_out(v.z, epi_act) * rs.z * (gg - sp[4] - xh * sp[5]);
-    xh = (v.w - mu.w) * rs.w; gg = gv.w * act_grad_from_out(xh, post_act);
+    xh = (v.w - mu.w) * rs.w; gg = gv.w * act_grad_from_in(xh, post_act);
     o.w = act_grad_from_out(v.w, epi_act) * rs.w * (gg - sp[6] - xh * sp[7]);
     *reinterpret_cast<float4*>(dt + pixg * C + c4 * 4) = o;
   }
@@ -263,20 +243,26 @@ extern "C" size_t vcg_in_workspace(int N, int HW, int C) {
   return (size_t)N * pl.nchunk * C * 2 * sizeof(double) + (size_t)N * C * 2 * sizeof(float) + 256;
 }
 
-extern "C" int vcg_in_stats(const float* t, float* mean, float* rstd, int N, int HW, int C, float eps,
-                            void* ws, size_t ws_bytes, void* stream) {
+// chunk partials [N][nchunk][C][2] (sum, sum of squares, in double) -> mean, rstd
+int vcg_in_finalize(const double* part, float* mean, float* rstd, int N, int HW, int C, int nchunk, float eps, hipStream_t st) {
+  hipLaunchKernelGGL(k_in_final<0>, dim3((N * C + 31) / 32), dim3(256), 0, st, part, mean, rstd, N, HW, C, nchunk, eps);
+  VCG_LAUNCH_CHECK("vcg_in_finalize");
+  return 0;
+}
+int vcg_in_stats_pass(const float* t, float* mean, float* rstd, int N, int HW, int C, float eps, void* ws, size_t ws_bytes, hipStream_t st) {
   VCG_CHECK_ARG(t && mean && rstd && ws, "vcg_in_stats: null pointer");
   VCG_CHECK_ARG(N > 0 && HW > 0 && C > 0 && C % 4 == 0, "vcg_in_stats: bad dims N=%d HW=%d C=%d", N, HW, C);
   VCG_CHECK_ARG(ws_bytes >= vcg_in_workspace(N, HW, C), "vcg_in_stats: workspace too small");
   NormPlan pl = make_plan(N, HW, C);
-  hipStream_t st = (hipStream_t)stream;
   double* part = (double*)ws;
   hipLaunchKernelGGL(k_in_partial<0>, dim3(pl.nchunk, N, pl.cgroups), dim3(256), 0, st, t, (const float*)nullptr,
                      (const float*)nullptr, (const float*)nullptr, part, HW, 1, C, pl, 0, 0);
-  hipLaunchKernelGGL(k_in_final<0>, dim3((N * C + 31) / 32), dim3(256), 0, st, (const double*)part, mean, rstd, N,
-                     HW, C, pl.nchunk, eps);
   VCG_LAUNCH_CHECK("vcg_in_stats");
-  return 0;
+  return vcg_in_finalize(part, mean, rstd, N, HW, C, pl.nchunk, eps, st);
+}
+extern "C" int vcg_in_stats(const float* t, float* mean, float* rstd, int N, int HW, int C, float eps,
+                            void* ws, size_t ws_bytes, void* stream) {
+  return vcg_in_stats_pass(t, mean, rstd, N, HW, C, eps, ws, ws_bytes, (hipStream_t)stream);
 }
 
 extern "C" int vcg_in_apply(const float* t, const float* mean, const float* rstd, const float* residual,

@@ -85,13 +85,22 @@ __host__ __device__ static inline int reflect_idx(int i, int L) {
 __device__ static inline float act_apply(float v, int act) {
   if (act == VCG_ACT_RELU) return v < 0.f ? 0.f : v;
   if (act == VCG_ACT_LEAKY02) return v > 0.f ? v : 0.2f * v;
+  if (act == VCG_ACT_TANH) return tanhf(v);
+  if (act == VCG_ACT_SIGMOID) return 1.f / (1.f + expf(-v));
   return v;
 }
-// derivative expressed on the activation OUTPUT (sign is preserved by both)
+// derivative expressed on the activation OUTPUT (ReLU / LeakyReLU preserve the sign; tanh' = 1 - out^2, sigmoid' = out (1 - out))
 __device__ static inline float act_grad_from_out(float out, int act) {
   if (act == VCG_ACT_RELU) return out > 0.f ? 1.f : 0.f;
   if (act == VCG_ACT_LEAKY02) return out > 0.f ? 1.f : 0.2f;
+  if (act == VCG_ACT_TANH) return 1.f - out * out;
+  if (act == VCG_ACT_SIGMOID) return out * (1.f - out);
   return 1.f;
+}
+// derivative expressed on the activation INPUT (the InstanceNorm backward holds xhat, not act(xhat))
+__device__ static inline float act_grad_from_in(float x, int act) {
+  if (act == VCG_ACT_TANH || act == VCG_ACT_SIGMOID) return act_grad_from_out(act_apply(x, act), act);
+  return act_grad_from_out(x, act);
 }
 
 __device__ static inline float wave_sum(float v) {
@@ -126,6 +135,32 @@ __device__ __forceinline__ void split4(const float4& v, uint2& h, uint2& m, uint
   l = make_uint2((uint32_t)ls[0] | ((uint32_t)ls[1] << 16), (uint32_t)ls[2] | ((uint32_t)ls[3] << 16));
 }
 
+// InstanceNorm reductions (norm.hip): a workgroup sums one chunk of pixels for TC channel quads x TP pixel lanes; the chunk
+// partials ([N][nchunk][C][2] doubles) are combined in double by k_in_final.  Shared with the conv epilogues that emit
+// those partials themselves (vcg_conv_fwd_in).
+struct NormPlan {
+  int TC, TP, cgroups, nchunk, chunk;
+};
+static inline NormPlan vcg_norm_plan(int N, int HW, int C) {
+  NormPlan pl;
+  int c4 = C / 4;
+  int tc = 1;
+  while (tc * 2 <= c4 && tc * 2 <= 256) tc *= 2;
+  pl.TC = tc;
+  pl.TP = 256 / tc;
+  pl.cgroups = (c4 + tc - 1) / tc;
+  long long target = 1024 / ((long long)N * pl.cgroups);
+  if (target < 1) target = 1;
+  long long maxc = (HW + pl.TP * 2 - 1) / (pl.TP * 2);
+  if (maxc < 1) maxc = 1;
+  if (target > maxc) target = maxc;
+  pl.chunk = (int)((HW + target - 1) / target);
+  pl.nchunk = (HW + pl.chunk - 1) / pl.chunk;
+  return pl;
+}
+int vcg_in_finalize(const double* part, float* mean, float* rstd, int N, int HW, int C, int nchunk, float eps, hipStream_t st);
+int vcg_in_stats_pass(const float* t, float* mean, float* rstd, int N, int HW, int C, float eps, void* ws, size_t ws_bytes, hipStream_t st);
+
 // geometry derived from the int32[16] conv descriptor
 struct ConvGeom {
   int N, H, W, Cin, Cout, KH, KW, stride, pad, reflect, ups, act, cin_log, cout_log;
@@ -149,7 +184,8 @@ size_t vcg_wino_weight_floats(const ConvGeom& g);
 size_t vcg_wino_fwd_workspace(const ConvGeom& g);
 int vcg_wino_weight(const ConvGeom& g, const float* w_oihw, float* u, hipStream_t st);
 int vcg_wino_fwd(const ConvGeom& g, const float* x, const float* u, const float* bias, float* y, void* ws, size_t ws_bytes,
-                 hipStream_t st);
+                 hipStream_t st, double* in_part = nullptr, int* in_nchunk = nullptr);
+size_t vcg_wino_fwd_stats_doubles(const ConvGeom& g);
 // Winograd weight gradient: transforms in conv_wino.hip, batched stream-K reduction + back-transform in conv_igemm.hip
 bool vcg_wino_wgrad_ok(const ConvGeom& g);
 size_t vcg_wino_wgrad_workspace(const ConvGeom& g);

@@ -15,8 +15,8 @@ import torch
 
 from . import _native
 
-ACT_NONE, ACT_RELU, ACT_LEAKY = 0, 1, 2
-_ACT = {"Identity": ACT_NONE, "ReLU": ACT_RELU, "LeakyReLU": ACT_LEAKY, None: ACT_NONE}
+ACT_NONE, ACT_RELU, ACT_LEAKY, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3, 4
+_ACT = {"Identity": ACT_NONE, "ReLU": ACT_RELU, "LeakyReLU": ACT_LEAKY, "Tanh": ACT_TANH, "Sigmoid": ACT_SIGMOID, None: ACT_NONE}
 
 IN_EPS = 1e-5  # nn.InstanceNorm2d default (Networks.py:61)
 
@@ -362,17 +362,17 @@ class _ConvBlockFn(torch.autograd.Function):
         t = torch.empty((n, ho, wo, spec.cout_pitch), dtype=torch.float32, device=dev)
         flops = 2.0 * n * ho * wo * spec.cout * spec.k * spec.k * spec.cin
         tag = f"{n}x{h}x{w}x{spec.cin_pitch}->{spec.cout_pitch} k{spec.k} s{spec.stride} u{spec.ups}"
-        with _timed("conv_fwd", flops, tag):
-            ws = workspace(lib.vcg_conv_fwd_workspace(cd), dev)
-            _native.check(lib.vcg_conv_fwd(_ptr(xp), _ptr(wf), _ptr(bias), _ptr(t), cd, _ptr(ws), ws.numel() * 4,
-                                           _stream()), "vcg_conv_fwd")
         mean = rstd = None
         if spec.norm:
+            # the conv and the statistics of the InstanceNorm that follows it in one call: the partial sums come out of
+            # the conv's own epilogue where its launch plan allows (csrc/conv_igemm.hip, vcg_conv_fwd_in)
             c = spec.cout_pitch
             mean = torch.empty((n, c), dtype=torch.float32, device=dev)
             rstd = torch.empty((n, c), dtype=torch.float32, device=dev)
-            wsb = lib.vcg_in_workspace(n, ho * wo, c)
-            ws = workspace(wsb, dev)
+            with _timed("conv_fwd", flops, tag):
+                ws = workspace(lib.vcg_conv_fwd_in_workspace(cd), dev)
+                _native.check(lib.vcg_conv_fwd_in(_ptr(xp), _ptr(wf), _ptr(bias), _ptr(t), _ptr(mean), _ptr(rstd), IN_EPS, cd,
+                                                  _ptr(ws), ws.numel() * 4, _stream()), "vcg_conv_fwd_in")
             resp = as_phys(residual) if residual is not None else None
             if spec.shuffle:
                 outp = torch.empty((n, 2 * ho, 2 * wo, c // 4), dtype=torch.float32, device=dev)
@@ -381,13 +381,15 @@ class _ConvBlockFn(torch.autograd.Function):
                 outp = torch.empty((n, ho, wo, c), dtype=torch.float32, device=dev)
                 cout_log = spec.cout
             with _timed("in_fwd"):
-                _native.check(lib.vcg_in_stats(_ptr(t), _ptr(mean), _ptr(rstd), n, ho * wo, c, IN_EPS, _ptr(ws),
-                                               ws.numel() * 4, _stream()), "vcg_in_stats")
                 _native.check(lib.vcg_in_apply(_ptr(t), _ptr(mean), _ptr(rstd), _ptr(resp), _ptr(outp), n, ho, wo, c,
                                                spec.post_act, int(spec.shuffle), _stream()), "vcg_in_apply")
         else:
             if residual is not None or spec.shuffle or spec.post_act:
                 raise RuntimeError("residual/shuffle/post_act need norm=True")
+            with _timed("conv_fwd", flops, tag):
+                ws = workspace(lib.vcg_conv_fwd_workspace(cd), dev)
+                _native.check(lib.vcg_conv_fwd(_ptr(xp), _ptr(wf), _ptr(bias), _ptr(t), cd, _ptr(ws), ws.numel() * 4,
+                                               _stream()), "vcg_conv_fwd")
             outp, cout_log = t, spec.cout
         ctx.spec, ctx.cd, ctx.dims, ctx.flops, ctx.tag = spec, cd, (n, h, w, ho, wo), flops, tag
         ctx.wparam, ctx.bparam = wparam, bparam
