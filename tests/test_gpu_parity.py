@@ -225,6 +225,64 @@ def test_zero_padded_conv_matches_torch(shape, pkg, device):
     assert_close(bd.grad.cpu(), br.grad, "zero-pad db")
 
 
+FWD_IN_CASES = [  # n, cin, cout, k, stride, pad, ups, h, w, activation code
+    (2, 64, 128, 3, 1, 1, 1, 32, 32, 1),      # Winograd: partials from the output transform
+    (3, 128, 128, 3, 1, 1, 1, 18, 14, 0),     # Winograd, ragged tile chunks (63 tiles per image)
+    (2, 64, 128, 3, 2, 1, 1, 64, 64, 1),      # D block
+    (2, 256, 128, 3, 1, 1, 2, 32, 32, 1),     # U block (the conv runs on the un-shuffled view)
+    (3, 64, 64, 7, 1, 3, 1, 32, 32, 1),       # direct split-operand tiles, Ho*Wo = 1024: partials from the tile epilogue
+    (4, 256, 256, 1, 1, 0, 1, 16, 16, 0),     # 1x1, Ho*Wo = 256
+    (2, 64, 64, 7, 1, 3, 1, 20, 20, 1),       # Ho*Wo = 400: tiles straddle images -> the separate pass
+    (1, 64, 8, 3, 1, 1, 1, 16, 16, 3),        # thin Cout
+]
+
+
+@pytest.mark.parametrize("case", FWD_IN_CASES, ids=[f"{c[1]}->{c[2]} k{c[3]} s{c[4]} u{c[6]} {c[0]}x{c[7]}x{c[8]}" for c in FWD_IN_CASES])
+def test_conv_fwd_in_equals_conv_then_statistics(case, pkg, device):
+    """vcg_conv_fwd_in (include/vcg.h): y bit-identical to vcg_conv_fwd's, mean / rstd those of that y (float64 reduction on
+    the host) whichever kernel produced the partial sums — and equal to the separate pass vcg_in_stats to fp32 rounding."""
+    import ctypes
+    n, cin, cout, k, stride, pad, ups, h, w, act = case
+    ops, lib, nat = pkg.ops, pkg._native.lib(), pkg._native
+    spec = ops.ConvSpec(cin, cout, k, stride, pad, True, ups, act)
+    key = f"fwdin{cin}x{cout}k{k}s{stride}u{ups}h{h}"
+    x = torch.from_numpy(pkg.synth.normal((n, spec.cin_phys_log, h, w), SEED + 5, key + "/x")).to(device)
+    wt = torch.nn.Parameter((torch.from_numpy(pkg.synth.normal((cout, cin, k, k), SEED + 5, key + "/w")) * (2.0 / (k * k * cin)) ** 0.5).to(device))
+    b = (torch.from_numpy(pkg.synth.normal((cout,), SEED + 5, key + "/b")) * 0.5).to(device)
+    xp = ops.as_phys(ops.to_nhwc(x))
+    cd = spec.desc(n, h, w)
+    ho, wo = spec.out_hw(h, w)
+    c = spec.cout_pitch
+    wf = spec.packed(wt)
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    P = lambda t: ctypes.c_void_p(t.data_ptr())
+    y0 = torch.empty((n, ho, wo, c), dtype=torch.float32, device=device)
+    ws = ops.workspace(lib.vcg_conv_fwd_workspace(cd), device)
+    nat.check(lib.vcg_conv_fwd(P(xp), P(wf), P(b), P(y0), cd, P(ws), ws.numel() * 4, st), "vcg_conv_fwd")
+    y0 = y0.clone()
+    m0 = torch.empty((n, c), dtype=torch.float32, device=device)
+    r0 = torch.empty_like(m0)
+    ws = ops.workspace(lib.vcg_in_workspace(n, ho * wo, c), device)
+    nat.check(lib.vcg_in_stats(P(y0), P(m0), P(r0), n, ho * wo, c, ops.IN_EPS, P(ws), ws.numel() * 4, st), "vcg_in_stats")
+    m0, r0 = m0.clone(), r0.clone()
+    y1 = torch.full((n, ho, wo, c), float("nan"), dtype=torch.float32, device=device)
+    m1 = torch.full((n, c), float("nan"), dtype=torch.float32, device=device)
+    r1 = torch.full((n, c), float("nan"), dtype=torch.float32, device=device)
+    ws = ops.workspace(lib.vcg_conv_fwd_in_workspace(cd), device)
+    ws.fill_(float("nan"))                                              # every partial the finalize reads must have been written
+    nat.check(lib.vcg_conv_fwd_in(P(xp), P(wf), P(b), P(y1), P(m1), P(r1), ops.IN_EPS, cd, P(ws), ws.numel() * 4, st), "vcg_conv_fwd_in")
+    torch.cuda.synchronize()
+    assert torch.equal(y1, y0)
+    yd = y0.double().reshape(n, ho * wo, c)
+    mean = yd.mean(1)
+    var = yd.var(1, unbiased=False)
+    rstd = 1.0 / torch.sqrt(var + ops.IN_EPS)
+    scale = var.sqrt() + mean.abs() + 1e-6
+    assert ((m1.double() - mean).abs() / scale).max().item() <= 2e-6
+    assert ((r1.double() - rstd).abs() / rstd).max().item() <= 5e-6
+    assert ((m1 - m0).abs().double() / scale).max().item() <= 2e-6 and ((r1 - r0).abs() / r0).max().item() <= 5e-6
+
+
 @pytest.mark.parametrize("activation,use_norm", [("Tanh", True), ("Tanh", False), ("Sigmoid", True), ("Sigmoid", False)])
 def test_casb_tanh_and_sigmoid_match_the_oracle(activation, use_norm, pkg, oracle, device):
     """The two CaSb activations no reference network uses (Networks.py:66-69): forward, data and weight gradients against
