@@ -165,6 +165,11 @@ ORACLE_CONV_CASES = [
     ("D", (64, 256), {}, (1, 64, 16, 16)),            # + folded PixelUnshuffle: Kc = 256
     ("R", (256,), {}, (1, 256, 6, 10)),               # non-square, two convs back to back, residual
     ("S", (256, 256), {}, (1, 256, 5, 7)),            # odd map: same channels fall back to the direct kernels
+    # the LDS-slab kernels (conv_slab.hip: 3x3, <= 128 channels, maps from 64 x 64): forward and data gradient
+    ("S", (32, 64), {}, (1, 32, 64, 64)),             # one chunk; data gradient on 16 x 16 blocks x 32 columns
+    ("S", (64, 128), {}, (1, 64, 64, 72)),            # two chunks, two column tiles, ragged pixel blocks (72 = 4.5 x 16)
+    ("U", (128, 64), {}, (1, 128, 32, 32)),           # U4's shape class: InstanceNorm partials from the slab epilogue
+    ("S", (32, 128), {}, (1, 32, 70, 64)),            # data gradient: four k chunks on the 16 x 16 blocks, ragged rows
 ]
 
 
@@ -198,11 +203,11 @@ def test_conv_blocks_match_oracle(case, pkg, oracle, device):
         assert_close(v, ref, f"{cls}{args} d{k}")
 
 
-@pytest.mark.parametrize("shape", [(2, 256, 256, 8, 8), (1, 128, 256, 6, 10), (1, 16, 16, 5, 7)])
+@pytest.mark.parametrize("shape", [(2, 256, 256, 8, 8), (1, 128, 256, 6, 10), (1, 16, 16, 5, 7), (1, 64, 64, 64, 80)])
 def test_zero_padded_conv_matches_torch(shape, pkg, device):
     """The C ABI also takes zero padding (reflect = 0), which no reference module uses: checked against plain PyTorch
-    fp32 on the CPU — first two shapes through the Winograd path (crop instead of fold in the data gradient), the last
-    one through the direct kernels."""
+    fp32 on the CPU — first two shapes through the Winograd path (crop instead of fold in the data gradient), the third
+    through the direct kernels, the last through the LDS-slab kernels (zero halo in the slab, crop after the data gradient)."""
     n, cin, cout, h, w = shape
     ops = pkg.ops
     key = f"zp{cin}x{cout}x{h}"
@@ -234,6 +239,8 @@ FWD_IN_CASES = [  # n, cin, cout, k, stride, pad, ups, h, w, activation code
     (4, 256, 256, 1, 1, 0, 1, 16, 16, 0),     # 1x1, Ho*Wo = 256
     (2, 64, 64, 7, 1, 3, 1, 20, 20, 1),       # Ho*Wo = 400: tiles straddle images -> the separate pass
     (1, 64, 8, 3, 1, 1, 1, 16, 16, 3),        # thin Cout
+    (2, 32, 64, 3, 1, 1, 1, 64, 64, 1),       # LDS-slab forward: partials per 8 x 16 pixel block
+    (1, 64, 128, 3, 1, 1, 1, 64, 72, 0),      # LDS-slab forward, ragged blocks -> the separate pass
 ]
 
 

@@ -2030,6 +2030,18 @@ static size_t wft_offset(const ConvGeom& g) {
          (vcg_thin_fold_dgrad_ok(g) ? vcg_thin_fold_dgrad_weight_floats(g) : 0);
 }
 static size_t wfd_offset(const ConvGeom& g) { return wft_offset(g) + (wft_wanted(g) ? wft_floats(g) : 0); }
+// VCG_SLAB=0 keeps the slab kernels (conv_slab.hip) out of the dispatch: A/B measurements only
+static bool slab_enabled() {
+  static const int on = [] { const char* e = getenv("VCG_SLAB"); return e ? atoi(e) : 1; }();
+  return on != 0;
+}
+static bool fwd_slab_ok(const ConvGeom& g) {
+  return slab_enabled() && !vcg_thin_fold_ok(g) && !vcg_thin_fwd_ok(g) && !vcg_wino_fwd_ok(g) && wft_wanted(g) && vcg_slab_fwd_ok(g);
+}
+static bool dgrad_slab_ok(const ConvGeom& g) {
+  return slab_enabled() && !vcg_thin_fold_dgrad_ok(g) && !vcg_thin_dgrad_ok(g) && !vcg_wino_dgrad_ok(g) && wfd_wanted(g) && vcg_slab_dgrad_ok(g);
+}
+
 // the forward kernel on a caller-built geometry (no bias, no activation, no K slicing): conv_thin.hip's kw-folded path
 int vcg_fwd_launch(const ConvGeom& g, const float* x, const float* wf, float* y, hipStream_t st) {
   ConvP p; fill_params(g, p);
@@ -2109,6 +2121,7 @@ extern "C" size_t vcg_conv_fwd_workspace(const int32_t* cd) {
   if (vcg_thin_fold_ok(g)) return vcg_thin_fold_workspace(g);
   if (vcg_thin_fwd_ok(g)) return 0;
   if (vcg_wino_fwd_ok(g)) return vcg_wino_fwd_workspace(g);
+  if (fwd_slab_ok(g)) return 0;
   int bm, bn, nsplit, kt_per;
   fwd_plan(g, bm, bn, nsplit, kt_per);
   return nsplit > 1 ? (size_t)nsplit * g.M * g.Cout * sizeof(float) + 256 : 0;
@@ -2122,7 +2135,7 @@ static int ew_grid(size_t work) {
 
 // does the direct split-operand forward leave the InstanceNorm partials itself?  (every 128-row tile inside one image)
 static bool fwd_tile_stats_ok(const ConvGeom& g) {
-  if (vcg_thin_fold_ok(g) || vcg_thin_fwd_ok(g) || vcg_wino_fwd_ok(g)) return false;
+  if (vcg_thin_fold_ok(g) || vcg_thin_fwd_ok(g) || vcg_wino_fwd_ok(g) || fwd_slab_ok(g)) return false;
   int bm, bn, nsplit, kt_per;
   fwd_plan(g, bm, bn, nsplit, kt_per);
   return bm == 128 && bn >= 64 && nsplit == 1 && wft_wanted(g) && (g.Ho * g.Wo) % 128 == 0;
@@ -2139,6 +2152,8 @@ static int conv_fwd_impl(const float* x, const float* wf, const float* bias, flo
   if (vcg_thin_fwd_ok(g)) return vcg_thin_fwd(g, x, wf, bias, y, (hipStream_t)stream);
   if (vcg_wino_fwd_ok(g))
     return vcg_wino_fwd(g, x, wf + wf_floats(g), bias, y, ws, ws_bytes, (hipStream_t)stream, in_part, in_nchunk);
+  if (fwd_slab_ok(g))
+    return vcg_slab_fwd(g, x, wf + wft_offset(g), wft_floats(g) * 4, bias, y, in_part, in_nchunk, (hipStream_t)stream);
   ConvP p; fill_params(g, p);
   if (in_part) {
     p.in_part = in_part;
@@ -2193,6 +2208,7 @@ extern "C" size_t vcg_conv_fwd_in_workspace(const int32_t* cd) {
   if (vcg_conv_geom(cd, &g, "vcg_conv_fwd_in_workspace")) return 0;
   size_t part;
   if (vcg_wino_fwd_ok(g)) part = vcg_wino_fwd_stats_doubles(g) * sizeof(double);
+  else if (fwd_slab_ok(g) && vcg_slab_fwd_stats_ok(g)) part = (size_t)g.N * vcg_slab_fwd_nchunk(g) * g.Cout * 2 * sizeof(double);
   else if (fwd_tile_stats_ok(g)) part = (size_t)g.N * (g.Ho * g.Wo / 128) * g.Cout * 2 * sizeof(double);
   else part = vcg_in_workspace(g.N, g.Ho * g.Wo, g.Cout);
   return fwd_in_conv_ws(cd) + part;
@@ -2206,7 +2222,7 @@ extern "C" int vcg_conv_fwd_in(const float* x, const float* wf, const float* bia
   VCG_CHECK_ARG(ws_bytes >= vcg_conv_fwd_in_workspace(cd), "vcg_conv_fwd_in: workspace too small (%zu)", ws_bytes);
   const size_t cws = fwd_in_conv_ws(cd);
   double* part = reinterpret_cast<double*>(static_cast<char*>(ws) + cws);
-  const bool fused = vcg_wino_fwd_ok(g) || fwd_tile_stats_ok(g);
+  const bool fused = vcg_wino_fwd_ok(g) || (fwd_slab_ok(g) && vcg_slab_fwd_stats_ok(g)) || fwd_tile_stats_ok(g);
   int nchunk = 0;
   if (conv_fwd_impl(x, wf, bias, y, cd, ws, cws, stream, fused ? part : nullptr, &nchunk)) return -1;
   if (fused) return vcg_in_finalize(part, mean, rstd, g.N, g.Ho * g.Wo, g.Cout, nchunk, eps, (hipStream_t)stream);
@@ -2230,6 +2246,7 @@ extern "C" size_t vcg_conv_dgrad_workspace(const int32_t* cd) {
   if (vcg_thin_fold_dgrad_ok(g)) return vcg_thin_fold_dgrad_workspace(g);
   if (vcg_thin_dgrad_ok(g)) return vcg_thin_dgrad_workspace(g);
   if (vcg_wino_dgrad_ok(g)) return vcg_wino_dgrad_workspace(g);
+  if (dgrad_slab_ok(g)) return vcg_slab_dgrad_workspace(g);
   ConvP p; fill_params(g, p);
   int bm, bn, nsplit, kt_per;
   dgrad_setup(g, p, bm, bn, nsplit, kt_per);
@@ -2247,6 +2264,8 @@ extern "C" int vcg_conv_dgrad(const float* dy, const float* wf, float* dx, const
   if (vcg_thin_dgrad_ok(g)) return vcg_thin_dgrad(g, dy, wf, dx, ws, ws_bytes, (hipStream_t)stream);
   if (vcg_wino_dgrad_ok(g))
     return vcg_wino_dgrad(g, dy, wf + wf_floats(g) + vcg_wino_weight_floats(g), dx, ws, ws_bytes, (hipStream_t)stream);
+  if (dgrad_slab_ok(g))
+    return vcg_slab_dgrad(g, dy, wf + wfd_offset(g), wfd_floats(g) * 4, dx, ws, ws_bytes, (hipStream_t)stream);
   ConvP p; fill_params(g, p);
   p.a = dy; p.b = wf; p.out = dx;
   {

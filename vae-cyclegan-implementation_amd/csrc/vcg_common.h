@@ -197,6 +197,16 @@ bool vcg_wino_dgrad_ok(const ConvGeom& g);
 size_t vcg_wino_dgrad_workspace(const ConvGeom& g);
 int vcg_wino_weight_dgrad(const ConvGeom& g, const float* w_oihw, float* ud, hipStream_t st);
 int vcg_wino_dgrad(const ConvGeom& g, const float* dy, const float* ud, float* dx, void* ws, size_t ws_bytes, hipStream_t st);
+// conv_slab.hip: 3x3 / stride-1 layers with few channels on large maps — the input staged once per workgroup as an LDS slab
+bool vcg_slab_fwd_ok(const ConvGeom& g);
+bool vcg_slab_fwd_stats_ok(const ConvGeom& g);
+int vcg_slab_fwd_nchunk(const ConvGeom& g);
+bool vcg_slab_dgrad_ok(const ConvGeom& g);
+size_t vcg_slab_dgrad_workspace(const ConvGeom& g);
+int vcg_slab_fwd(const ConvGeom& g, const float* x, const void* wft_planes, size_t planes_bytes, const float* bias, float* y,
+                 double* in_part, int* in_nchunk, hipStream_t st);
+int vcg_slab_dgrad(const ConvGeom& g, const float* dy, const void* wfd_planes, size_t planes_bytes, float* dx, void* ws,
+                   size_t ws_bytes, hipStream_t st);
 // conv_thin.hip: thin forward with kw folded into the GEMM's N (MFMA)
 bool vcg_thin_fold_ok(const ConvGeom& g);
 size_t vcg_thin_fold_weight_floats(const ConvGeom& g);
