@@ -95,13 +95,20 @@ def test_launch_plans_are_host_side_and_consistent(pkg):
     # [(tap, c)][Cout/32][3][32] (data gradient): 48 floats per (row, 32-wide block)
     assert lib.vcg_pack_weight_floats(u4) == 9 * 32 * 64 + 64 * 9 * 48 + 9 * 32 * 2 * 48
     assert lib.vcg_conv_fwd_workspace(u4) == 0
+    # ... and it runs on the LDS-slab kernels: the data gradient over the padded domain (H + 2) x (W + 2), folded afterwards
+    assert lib.vcg_conv_dgrad_workspace(u4) == 8 * 258 * 258 * 32 * f4 + 256
+    # the latent convs 1024 -> 64: Kc Cout / (Kc + Cout) = 60 is under every Winograd gate (forward 64, data gradient 80):
+    # no transformed copies, the planes of the direct split-operand kernels instead
+    mu = _desc(8, 16, 16, 1024, 64, 3)
+    assert lib.vcg_pack_weight_floats(mu) == 9 * 1024 * 64 + 64 * (9216 // 32) * 48 + 9 * 1024 * 2 * 48
     # decoder head 64 -> 3 (pitch 4), 7x7: Wf + the kw-folded copy [(kh, c)][32]; P buffer over the padded columns
     head = _desc(8, 256, 256, 64, 4, 7, pad=3, cout_log=3)
-    assert lib.vcg_pack_weight_floats(head) == ((49 * 64 * 4 + 63) // 64) * 64 + 7 * 64 * 32
+    # (+ that copy's pre-split planes [32][7 * 64 / 32][3][32] for the LDS-slab column kernel)
+    assert lib.vcg_pack_weight_floats(head) == ((49 * 64 * 4 + 63) // 64) * 64 + 7 * 64 * 32 + 7 * 64 * 48
     assert lib.vcg_conv_fwd_workspace(head) == 8 * 256 * (256 + 6) * 32 * f4 + 256
     # encoder stem 3 -> 64: the data gradient takes the folded path (padded-domain dxp + P), the forward does not
     stem = _desc(8, 256, 256, 4, 64, 7, pad=3, cin_log=3)
-    assert lib.vcg_pack_weight_floats(stem) == ((49 * 4 * 64 + 63) // 64) * 64 + 7 * 64 * 32 + 64 * 7 * 48     # K = 196 -> 7 blocks
+    assert lib.vcg_pack_weight_floats(stem) == ((49 * 4 * 64 + 63) // 64) * 64 + 7 * 64 * 32 + 7 * 64 * 48 + 64 * 7 * 48     # K = 196 -> 7 blocks
     assert lib.vcg_conv_dgrad_workspace(stem) >= 8 * 262 * 262 * 4 * f4 + 8 * 262 * (256 + 12) * 32 * f4
     # stride-2 discriminator conv: direct everywhere; the forward may slice K (whole output-sized slabs), the data
     # gradient cannot (its blockIdx.z enumerates the stride-parity classes)

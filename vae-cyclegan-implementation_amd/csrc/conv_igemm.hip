@@ -2017,15 +2017,30 @@ static size_t wf_floats(const ConvGeom& g) { return (((size_t)g.K * g.Cout + 63)
 // gradient the WFD planes.  Layers that own Winograd copies (every D, R and U block from 128 reduction channels on) run
 // through those in all three directions and get neither; should one of them meet a map Winograd cannot take (odd sizes), it
 // runs on the fp32-MFMA kernels from Wf.  Thin (Cout == 4) layers and the kw-folded data gradient never take them either.
-static bool wft_wanted(const ConvGeom& g) { return g.Cout >= 64 && g.Cin % 4 == 0 && !vcg_wino_weight_ok(g); }
+// (a layer with Winograd copies whose channel product is under a direction's gate — conv_wino.hip: forward from
+// Kc Cout / (Kc + Cout) = 64, data gradient from 80; the 1024 -> 64 latent convs sit at 60 — runs that direction direct, and
+// gets the planes for it)
+static bool wino_takes_fwd(const ConvGeom& g) {
+  const long long kc = (long long)g.ups * g.ups * g.Cin;
+  return vcg_wino_weight_ok(g) && kc * g.Cout >= 64 * (kc + g.Cout);
+}
+static bool wino_takes_dgrad(const ConvGeom& g) {
+  const long long kc = (long long)g.ups * g.ups * g.Cin;
+  return vcg_wino_weight_ok(g) && kc * g.Cout >= 80 * (kc + g.Cout);
+}
+// floats of the Winograd copies a layer keeps: U if some map can take the forward (and with it the weight gradient), Ud if
+// some map can take the data gradient
+static size_t wino_u_floats(const ConvGeom& g) { return wino_takes_fwd(g) ? vcg_wino_weight_floats(g) : 0; }
+static size_t wino_ud_floats(const ConvGeom& g) { return wino_takes_dgrad(g) ? vcg_wino_weight_floats(g) : 0; }
+static bool wft_wanted(const ConvGeom& g) { return g.Cout >= 64 && g.Cin % 4 == 0 && !wino_takes_fwd(g); }
 static bool wfd_wanted(const ConvGeom& g) {
-  return g.Cout >= 64 && g.Cout % 32 == 0 && !vcg_wino_weight_ok(g) && !vcg_thin_fold_dgrad_ok(g) && !vcg_thin_dgrad_ok(g);
+  return g.Cout >= 64 && g.Cout % 32 == 0 && !wino_takes_dgrad(g) && !vcg_thin_fold_dgrad_ok(g) && !vcg_thin_dgrad_ok(g);
 }
 static size_t wft_floats(const ConvGeom& g) { return (size_t)g.Cout * ((g.K + 31) / 32) * 48; }               // 192 bytes per (co, K block)
 static size_t wfd_floats(const ConvGeom& g) { return (size_t)g.KH * g.KW * g.ups * g.ups * g.Cin * (g.Cout / 32) * 48; }
 static size_t wkd_offset(const ConvGeom& g) { return wf_floats(g) + (vcg_thin_fold_ok(g) ? vcg_thin_fold_weight_floats(g) : 0); }
 static size_t wft_offset(const ConvGeom& g) {
-  return wf_floats(g) + (vcg_wino_weight_ok(g) ? 2 * vcg_wino_weight_floats(g) : 0) +
+  return wf_floats(g) + wino_u_floats(g) + wino_ud_floats(g) +
          (vcg_thin_fold_ok(g) ? vcg_thin_fold_weight_floats(g) : 0) +
          (vcg_thin_fold_dgrad_ok(g) ? vcg_thin_fold_dgrad_weight_floats(g) : 0);
 }
@@ -2063,7 +2078,7 @@ int vcg_fwd_launch(const ConvGeom& g, const float* x, const float* wf, float* y,
 extern "C" size_t vcg_pack_weight_floats(const int32_t* cd) {
   ConvGeom g;
   if (vcg_conv_geom(cd, &g, "vcg_pack_weight_floats")) return 0;
-  return wf_floats(g) + (vcg_wino_weight_ok(g) ? 2 * vcg_wino_weight_floats(g) : 0)   // + U (forward) + Ud (data gradient)
+  return wf_floats(g) + wino_u_floats(g) + wino_ud_floats(g)                           // + U (forward) + Ud (data gradient)
          + (vcg_thin_fold_ok(g) ? vcg_thin_fold_weight_floats(g) : 0)                   // + Wk (kw-folded thin forward)
          + (vcg_thin_fold_dgrad_ok(g) ? vcg_thin_fold_dgrad_weight_floats(g) : 0)       // + Wkd (kw-folded thin data gradient)
          + (wft_wanted(g) ? wft_floats(g) : 0)                                          // + WFT planes (split-operand direct forward)
@@ -2092,10 +2107,8 @@ extern "C" int vcg_pack_weight(const float* w_oihw, float* wf, const int32_t* cd
                        g.cin_log, g.cout_log);
     VCG_LAUNCH_CHECK("vcg_pack_weight(WFD planes)");
   }
-  if (vcg_wino_weight_ok(g)) {
-    if (vcg_wino_weight(g, w_oihw, wf + wf_floats(g), (hipStream_t)stream)) return -2;
-    if (vcg_wino_weight_dgrad(g, w_oihw, wf + wf_floats(g) + vcg_wino_weight_floats(g), (hipStream_t)stream)) return -2;
-  }
+  if (wino_takes_fwd(g) && vcg_wino_weight(g, w_oihw, wf + wf_floats(g), (hipStream_t)stream)) return -2;
+  if (wino_takes_dgrad(g) && vcg_wino_weight_dgrad(g, w_oihw, wf + wf_floats(g) + wino_u_floats(g), (hipStream_t)stream)) return -2;
   ConvP p; fill_params(g, p);
   size_t total = (size_t)g.K * g.Cout;
   const int T = g.KH * g.KW * g.ups * g.ups;
@@ -2263,7 +2276,7 @@ extern "C" int vcg_conv_dgrad(const float* dy, const float* wf, float* dx, const
   if (vcg_thin_fold_dgrad_ok(g)) return vcg_thin_fold_dgrad(g, dy, wf + wkd_offset(g), dx, ws, ws_bytes, (hipStream_t)stream);
   if (vcg_thin_dgrad_ok(g)) return vcg_thin_dgrad(g, dy, wf, dx, ws, ws_bytes, (hipStream_t)stream);
   if (vcg_wino_dgrad_ok(g))
-    return vcg_wino_dgrad(g, dy, wf + wf_floats(g) + vcg_wino_weight_floats(g), dx, ws, ws_bytes, (hipStream_t)stream);
+    return vcg_wino_dgrad(g, dy, wf + wf_floats(g) + wino_u_floats(g), dx, ws, ws_bytes, (hipStream_t)stream);
   if (dgrad_slab_ok(g))
     return vcg_slab_dgrad(g, dy, wf + wfd_offset(g), wfd_floats(g) * 4, dx, ws, ws_bytes, (hipStream_t)stream);
   ConvP p; fill_params(g, p);

@@ -35,11 +35,12 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t sl_srd(const void* ptr, uint32
   return __builtin_amdgcn_make_buffer_rsrc((void*)ptr, 0, (int)bytes, 0x00020000);
 }
 
-// WM x WN waves of 64 x 32 outputs: BM = 64 WM pixels (PR = 4 WM rows of 16), BN = 32 WN output channels
-template <int WM, int WN>
+// WM x WN waves of 64 x 32 outputs: BM = 64 WM pixels (PR = 4 WM rows of 16), BN = 32 WN output channels; KH x KW taps
+// (3 x 3; 7 x 1 for the kw-folded thin layers of conv_thin.hip, whose column taps live in the GEMM's N)
+template <int WM, int WN, int KH, int KW>
 __global__ __launch_bounds__(256, 2) void k_conv_slab(SlabP p) {
   static_assert(WM * WN == 4, "four waves");
-  constexpr int BM = 64 * WM, BN = 32 * WN, PR = BM / 16, SH = PR + 2, SW = 18, SPX = SH * SW;
+  constexpr int BM = 64 * WM, BN = 32 * WN, PR = BM / 16, SH = PR + KH - 1, SW = 16 + KW - 1, SPX = SH * SW, NTAP = KH * KW;
   constexpr int AQ = (SPX * 8 + 255) / 256;                  // slab quads per thread
   constexpr int BQ = (BN * 12 + 255) / 256;                  // 16-byte weight chunks per thread and tap
   __shared__ __attribute__((aligned(16))) unsigned char As[3][SPX * 64];
@@ -107,7 +108,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_slab(SlabP p) {
 
   sl_u32x4 vb[BQ];
   auto load_b = [&](int chunk, int tap) {
-    const uint32_t t = (uint32_t)(p.tap_flip ? 8 - tap : tap);
+    const uint32_t t = (uint32_t)(p.tap_flip ? NTAP - 1 - tap : tap);
     const uint32_t o = t * p.tap_stride + (uint32_t)chunk * 192u;
 #pragma unroll
     for (int j = 0; j < BQ; ++j) vb[j] = __builtin_amdgcn_raw_buffer_load_b128(rb, (int)(boff[j] != SL_OOB ? boff[j] + o : SL_OOB), 0, 0);
@@ -142,11 +143,11 @@ __global__ __launch_bounds__(256, 2) void k_conv_slab(SlabP p) {
       if (chunk == 0) store_b(0);
       __syncthreads();
     }
-    for (int tap = 0; tap < 9; ++tap, ++s) {
+    for (int tap = 0; tap < NTAP; ++tap, ++s) {
       const int buf = s & 1;
-      const bool more = tap < 8 || chunk + 1 < p.nchunks;
-      if (more) load_b(tap < 8 ? chunk : chunk + 1, tap < 8 ? tap + 1 : 0);
-      const int kh = tap / 3, kw = tap - kh * 3;
+      const bool more = tap < NTAP - 1 || chunk + 1 < p.nchunks;
+      if (more) load_b(tap < NTAP - 1 ? chunk : chunk + 1, tap < NTAP - 1 ? tap + 1 : 0);
+      const int kh = tap / KW, kw = tap - kh * KW;
       uint32_t fa[2];
       int sa[2];
 #pragma unroll
@@ -284,8 +285,8 @@ int vcg_slab_fwd(const ConvGeom& g, const float* x, const void* wft_planes, size
   p.in_bytes = (uint32_t)ab; p.b_bytes = (uint32_t)planes_bytes;
   p.row_stride = (uint32_t)(9 * (g.Cin / 32) * 192); p.tap_stride = (uint32_t)((g.Cin / 32) * 192);
   {
-    VcgProfScope prof("k_conv_slab<2, 2>", 2.0 * g.M * (double)g.K * g.Cout, st);
-    hipLaunchKernelGGL((k_conv_slab<2, 2>), dim3(g.N * p.nbx * p.nby, g.Cout / 64), dim3(256), 0, st, p);
+    VcgProfScope prof("k_conv_slab<2, 2, 3, 3>", 2.0 * g.M * (double)g.K * g.Cout, st);
+    hipLaunchKernelGGL((k_conv_slab<2, 2, 3, 3>), dim3(g.N * p.nbx * p.nby, g.Cout / 64), dim3(256), 0, st, p);
   }
   VCG_LAUNCH_CHECK("vcg_conv_fwd(slab)");
   return 0;
@@ -306,9 +307,9 @@ int vcg_slab_dgrad(const ConvGeom& g, const float* dy, const void* wfd_planes, s
   p.row_stride = (uint32_t)((g.Cout / 32) * 192); p.tap_stride = (uint32_t)(g.Cin * (g.Cout / 32) * 192);
   {
     const double flops = 2.0 * g.N * (double)p.Ho * p.Wo * 9.0 * g.Cout * g.Cin;
-    VcgProfScope prof(wide ? "k_conv_slab<4, 1>" : "k_conv_slab<2, 2>", flops, st);
-    if (wide) hipLaunchKernelGGL((k_conv_slab<4, 1>), dim3(g.N * p.nbx * p.nby, 1), dim3(256), 0, st, p);
-    else hipLaunchKernelGGL((k_conv_slab<2, 2>), dim3(g.N * p.nbx * p.nby, g.Cin / 64), dim3(256), 0, st, p);
+    VcgProfScope prof(wide ? "k_conv_slab<4, 1, 3, 3>" : "k_conv_slab<2, 2, 3, 3>", flops, st);
+    if (wide) hipLaunchKernelGGL((k_conv_slab<4, 1, 3, 3>), dim3(g.N * p.nbx * p.nby, 1), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((k_conv_slab<2, 2, 3, 3>), dim3(g.N * p.nbx * p.nby, g.Cin / 64), dim3(256), 0, st, p);
   }
   VCG_LAUNCH_CHECK("vcg_conv_dgrad(slab)");
   const size_t total = (size_t)g.N * g.H * g.W * (g.Cin / 4);
@@ -316,5 +317,29 @@ int vcg_slab_dgrad(const ConvGeom& g, const float* dy, const void* wfd_planes, s
   if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(k_fold_pad_c, dim3(blocks), dim3(256), 0, st, (const float4*)ws, (float4*)dx, g.N, g.H, g.W, g.Cin / 4, g.reflect);
   VCG_LAUNCH_CHECK("vcg_conv_dgrad(slab fold)");
+  return 0;
+}
+
+// ---- the (KH x 1) convolution of the kw-folded thin layers (conv_thin.hip): P[n][oh][pc][32] over the padded columns --------
+// planes: [32 rows = (kw, co)][KH * C / 32 blocks][3][32], k = (kh, c).  Reflect or zero padding `pad` on both axes (the
+// column taps being part of N, a padded column pc simply reads input column reflect(pc - pad)).
+bool vcg_slab_col_ok(int KH, int C) { return KH == 7 && C % 32 == 0 && C <= 128; }
+int vcg_slab_col(const float* x, const void* planes, size_t planes_bytes, float* P, int N, int H, int W, int C, int Ho, int Wo,
+                 int KH, int pad, int reflect, hipStream_t st) {
+  VCG_CHECK_ARG(vcg_slab_col_ok(KH, C), "vcg_conv(kw-fold slab): unsupported KH=%d C=%d", KH, C);
+  SlabP p = {};
+  p.in = x; p.planes = planes; p.bias = nullptr; p.out = P; p.in_part = nullptr;
+  p.N = N; p.H = H; p.W = W; p.C = C; p.Ho = Ho; p.Wo = Wo; p.Cout = 32; p.cout_log = 32;
+  p.pad = pad; p.reflect = reflect; p.act = VCG_ACT_NONE; p.tap_flip = 0; p.nchunks = C / 32;
+  p.nbx = (Wo + 15) / 16; p.nby = (Ho + 15) / 16;
+  const unsigned long long ab = (unsigned long long)N * H * W * C * 4;
+  VCG_CHECK_ARG(ab < (1ull << 31) && planes_bytes < (1ull << 31), "vcg_conv(kw-fold slab): tensor extents must stay below 2 GiB");
+  p.in_bytes = (uint32_t)ab; p.b_bytes = (uint32_t)planes_bytes;
+  p.row_stride = (uint32_t)(KH * (C / 32) * 192); p.tap_stride = (uint32_t)((C / 32) * 192);
+  {
+    VcgProfScope prof("k_conv_slab<4, 1, 7, 1>", 2.0 * N * (double)Ho * Wo * KH * C * 32, st);
+    hipLaunchKernelGGL((k_conv_slab<4, 1, 7, 1>), dim3(N * p.nbx * p.nby, 1), dim3(256), 0, st, p);
+  }
+  VCG_LAUNCH_CHECK("vcg_conv(kw-fold slab)");
   return 0;
 }

@@ -424,6 +424,11 @@ class _ConvBlockFn(torch.autograd.Function):
         if wparam is not None and wparam.requires_grad and id(wparam) not in _NO_WGRAD:
             gw = _grad_buffer(wparam)
             gb = _grad_buffer(bparam) if (bparam is not None and bparam.requires_grad) else None
+            if spec.norm and spec.epi_act == ACT_NONE:
+                # InstanceNorm directly on conv + bias (CaSb, R.conv2): the mean subtraction cancels the bias, its gradient
+                # is identically zero (the reference's autograd returns rounding noise of ~1e-9 there: the column sums of
+                # a dt whose columns sum to zero) — the buffer stays at its zeros and the column-sum kernels are not run
+                gb = None
             wsb = lib.vcg_conv_wgrad_workspace(cd)
 
             def run_wgrad():
