@@ -92,11 +92,15 @@ int vcg_conv_fwd(const float* x, const float* wf, const float* bias, float* y,
 /* The same convolution when an InstanceNorm follows it (CaSb with norm=True, /root/reference/Networks.py:93-95): y as
    above AND mean / rstd (N x Cout each) of y over its pixels, biased variance, rstd = 1 / sqrt(var + eps) — what
    vcg_in_stats(y) returns.  Where the conv's launch plan allows (Winograd output transform; direct split-operand tiles
-   with Ho*Wo % 128 == 0) the statistics' partial sums (in double) are written by the conv's own epilogue, so y is not
-   read again; otherwise the separate reduction pass runs.  `ws`: vcg_conv_fwd_in_workspace(cd) bytes. */
+   with Ho*Wo % 128 == 0; the LDS-slab pixel blocks) the statistics' partial sums (in double) are written by the conv's own
+   epilogue, so y is not read again; otherwise the separate reduction pass runs.  mean == rstd == NULL: no statistics,
+   the plain forward.  `ws`: vcg_conv_fwd_in_workspace(cd) bytes (vcg_conv_fwd_workspace when mean is NULL).
+   `saved` (may be NULL): vcg_conv_saved_floats(cd) floats in which the call leaves forward state that the weight gradient
+   of the same (x, cd) can reuse instead of recomputing it — vcg_conv_wgrad_saved below; 0 floats: nothing to keep. */
 size_t vcg_conv_fwd_in_workspace(const int32_t* cd);
+size_t vcg_conv_saved_floats(const int32_t* cd);
 int vcg_conv_fwd_in(const float* x, const float* wf, const float* bias, float* y, float* mean, float* rstd, float eps,
-                    const int32_t* cd, void* ws, size_t ws_bytes, void* stream);
+                    float* saved, const int32_t* cd, void* ws, size_t ws_bytes, void* stream);
 /* dx = conv^T(dy) including the adjoint of the reflect padding.              */
 size_t vcg_conv_dgrad_workspace(const int32_t* cd);
 int vcg_conv_dgrad(const float* dy, const float* wf, float* dx, const int32_t* cd,
@@ -106,6 +110,9 @@ int vcg_conv_dgrad(const float* dy, const float* wf, float* dx, const int32_t* c
 size_t vcg_conv_wgrad_workspace(const int32_t* cd);
 int vcg_conv_wgrad(const float* x, const float* dy, float* gw_oihw, float* gbias,
                    const int32_t* cd, void* ws, size_t ws_bytes, void* stream);
+/* vcg_conv_wgrad with the forward state vcg_conv_fwd_in kept in `saved` (NULL: identical to vcg_conv_wgrad). */
+int vcg_conv_wgrad_saved(const float* x, const float* dy, float* gw_oihw, float* gbias, const float* saved,
+                         const int32_t* cd, void* ws, size_t ws_bytes, void* stream);
 
 /* nn.InstanceNorm2d(eps=1e-5, affine=False) — Networks.py:61,88,102,105,123 -- */
 size_t vcg_in_workspace(int N, int HW, int C);

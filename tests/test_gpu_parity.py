@@ -231,7 +231,8 @@ def test_zero_padded_conv_matches_torch(shape, pkg, device):
 
 
 FWD_IN_CASES = [  # n, cin, cout, k, stride, pad, ups, h, w, activation code
-    (2, 64, 128, 3, 1, 1, 1, 32, 32, 1),      # Winograd: partials from the output transform
+    (2, 64, 128, 3, 1, 1, 1, 32, 32, 1),      # Winograd forward: partials from the output transform
+    (2, 256, 256, 3, 1, 1, 1, 16, 16, 1),     # Winograd in every direction: the forward keeps V for the weight gradient
     (3, 128, 128, 3, 1, 1, 1, 18, 14, 0),     # Winograd, ragged tile chunks (63 tiles per image)
     (2, 64, 128, 3, 2, 1, 1, 64, 64, 1),      # D block
     (2, 256, 128, 3, 1, 1, 2, 32, 32, 1),     # U block (the conv runs on the un-shuffled view)
@@ -277,7 +278,10 @@ def test_conv_fwd_in_equals_conv_then_statistics(case, pkg, device):
     r1 = torch.full((n, c), float("nan"), dtype=torch.float32, device=device)
     ws = ops.workspace(lib.vcg_conv_fwd_in_workspace(cd), device)
     ws.fill_(float("nan"))                                              # every partial the finalize reads must have been written
-    nat.check(lib.vcg_conv_fwd_in(P(xp), P(wf), P(b), P(y1), P(m1), P(r1), ops.IN_EPS, cd, P(ws), ws.numel() * 4, st), "vcg_conv_fwd_in")
+    nsv = int(lib.vcg_conv_saved_floats(cd))
+    saved = torch.full((max(nsv, 1),), float("nan"), dtype=torch.float32, device=device)
+    nat.check(lib.vcg_conv_fwd_in(P(xp), P(wf), P(b), P(y1), P(m1), P(r1), ops.IN_EPS, P(saved) if nsv else None, cd, P(ws), ws.numel() * 4, st),
+              "vcg_conv_fwd_in")
     torch.cuda.synchronize()
     assert torch.equal(y1, y0)
     yd = y0.double().reshape(n, ho * wo, c)
@@ -288,6 +292,19 @@ def test_conv_fwd_in_equals_conv_then_statistics(case, pkg, device):
     assert ((m1.double() - mean).abs() / scale).max().item() <= 2e-6
     assert ((r1.double() - rstd).abs() / rstd).max().item() <= 5e-6
     assert ((m1 - m0).abs().double() / scale).max().item() <= 2e-6 and ((r1 - r0).abs() / r0).max().item() <= 5e-6
+    # the forward state kept for the weight gradient: the gradient computed from it is bit-identical to the recomputing path
+    g = torch.from_numpy(pkg.synth.normal((n, ho, wo, c), SEED + 5, key + "/g")).to(device)
+    grads = []
+    for sv in ([None, saved] if nsv else [None]):
+        gw = torch.zeros((cout, cin, k, k), dtype=torch.float32, device=device)
+        gb = torch.zeros((cout,), dtype=torch.float32, device=device)
+        ws = ops.workspace(lib.vcg_conv_wgrad_workspace(cd), device)
+        nat.check(lib.vcg_conv_wgrad_saved(P(xp), P(g), P(gw), P(gb), P(sv) if sv is not None else None, cd, P(ws), ws.numel() * 4, st),
+                  "vcg_conv_wgrad_saved")
+        grads.append((gw.clone(), gb.clone()))
+    if nsv:
+        assert torch.isfinite(saved).all()
+        assert torch.equal(grads[0][0], grads[1][0]) and torch.equal(grads[0][1], grads[1][1])
 
 
 @pytest.mark.parametrize("activation,use_norm", [("Tanh", True), ("Tanh", False), ("Sigmoid", True), ("Sigmoid", False)])

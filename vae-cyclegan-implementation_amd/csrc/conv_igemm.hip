@@ -2157,14 +2157,14 @@ static bool fwd_tile_stats_ok(const ConvGeom& g) {
 // in_part != nullptr: also leave the InstanceNorm chunk partials of y there (the caller checked that this launch plan
 // can: Winograd, or fwd_tile_stats_ok) and report the chunk count per image.
 static int conv_fwd_impl(const float* x, const float* wf, const float* bias, float* y, const int32_t* cd, void* ws,
-                         size_t ws_bytes, void* stream, double* in_part, int* in_nchunk) {
+                         size_t ws_bytes, void* stream, double* in_part, int* in_nchunk, float* saved = nullptr) {
   ConvGeom g;
   if (vcg_conv_geom(cd, &g, "vcg_conv_fwd")) return -1;
   VCG_CHECK_ARG(x && wf && y, "vcg_conv_fwd: null pointer");
   if (vcg_thin_fold_ok(g)) return vcg_thin_fold_fwd(g, x, wf + wf_floats(g), bias, y, ws, ws_bytes, (hipStream_t)stream);
   if (vcg_thin_fwd_ok(g)) return vcg_thin_fwd(g, x, wf, bias, y, (hipStream_t)stream);
   if (vcg_wino_fwd_ok(g))
-    return vcg_wino_fwd(g, x, wf + wf_floats(g), bias, y, ws, ws_bytes, (hipStream_t)stream, in_part, in_nchunk);
+    return vcg_wino_fwd(g, x, wf + wf_floats(g), bias, y, ws, ws_bytes, (hipStream_t)stream, in_part, in_nchunk, saved);
   if (fwd_slab_ok(g))
     return vcg_slab_fwd(g, x, wf + wft_offset(g), wft_floats(g) * 4, bias, y, in_part, in_nchunk, (hipStream_t)stream);
   ConvP p; fill_params(g, p);
@@ -2227,17 +2227,31 @@ extern "C" size_t vcg_conv_fwd_in_workspace(const int32_t* cd) {
   return fwd_in_conv_ws(cd) + part;
 }
 
+// floats of forward state worth keeping for the weight gradient of this layer (0: nothing) — today the Winograd-transformed
+// input V of the layers whose weight gradient runs through Winograd as well
+extern "C" size_t vcg_conv_saved_floats(const int32_t* cd) {
+  ConvGeom g;
+  if (vcg_conv_geom(cd, &g, "vcg_conv_saved_floats")) return 0;
+  return vcg_wino_fwd_ok(g) ? vcg_wino_saved_floats(g) : 0;
+}
+
 extern "C" int vcg_conv_fwd_in(const float* x, const float* wf, const float* bias, float* y, float* mean, float* rstd,
-                               float eps, const int32_t* cd, void* ws, size_t ws_bytes, void* stream) {
+                               float eps, float* saved, const int32_t* cd, void* ws, size_t ws_bytes, void* stream) {
   ConvGeom g;
   if (vcg_conv_geom(cd, &g, "vcg_conv_fwd_in")) return -1;
-  VCG_CHECK_ARG(mean && rstd && ws, "vcg_conv_fwd_in: null pointer");
+  VCG_CHECK_ARG((mean == nullptr) == (rstd == nullptr), "vcg_conv_fwd_in: mean and rstd go together");
+  if (saved && !vcg_conv_saved_floats(cd)) saved = nullptr;
+  if (!mean) {                                           // no statistics wanted: the plain forward (+ saved state)
+    VCG_CHECK_ARG(ws_bytes >= vcg_conv_fwd_workspace(cd), "vcg_conv_fwd_in: workspace too small (%zu)", ws_bytes);
+    return conv_fwd_impl(x, wf, bias, y, cd, ws, ws_bytes, stream, nullptr, nullptr, saved);
+  }
+  VCG_CHECK_ARG(ws, "vcg_conv_fwd_in: null pointer");
   VCG_CHECK_ARG(ws_bytes >= vcg_conv_fwd_in_workspace(cd), "vcg_conv_fwd_in: workspace too small (%zu)", ws_bytes);
   const size_t cws = fwd_in_conv_ws(cd);
   double* part = reinterpret_cast<double*>(static_cast<char*>(ws) + cws);
   const bool fused = vcg_wino_fwd_ok(g) || (fwd_slab_ok(g) && vcg_slab_fwd_stats_ok(g)) || fwd_tile_stats_ok(g);
   int nchunk = 0;
-  if (conv_fwd_impl(x, wf, bias, y, cd, ws, cws, stream, fused ? part : nullptr, &nchunk)) return -1;
+  if (conv_fwd_impl(x, wf, bias, y, cd, ws, cws, stream, fused ? part : nullptr, &nchunk, saved)) return -1;
   if (fused) return vcg_in_finalize(part, mean, rstd, g.N, g.Ho * g.Wo, g.Cout, nchunk, eps, (hipStream_t)stream);
   return vcg_in_stats_pass(y, mean, rstd, g.N, g.Ho * g.Wo, g.Cout, eps, part, ws_bytes - cws, (hipStream_t)stream);
 }
@@ -2469,8 +2483,15 @@ static int launch_colsum(const ConvGeom& gorig, const float* dy, float* gbias, f
   return 0;
 }
 
+extern "C" int vcg_conv_wgrad_saved(const float* x, const float* dy, float* gw_oihw, float* gbias, const float* saved,
+                                    const int32_t* cd, void* ws, size_t ws_bytes, void* stream);
 extern "C" int vcg_conv_wgrad(const float* x, const float* dy, float* gw_oihw, float* gbias,
                               const int32_t* cd, void* ws, size_t ws_bytes, void* stream) {
+  return vcg_conv_wgrad_saved(x, dy, gw_oihw, gbias, nullptr, cd, ws, ws_bytes, stream);
+}
+// `saved`: what vcg_conv_fwd_in left for this very (x, cd) in its `saved` buffer (vcg_conv_saved_floats), or null
+extern "C" int vcg_conv_wgrad_saved(const float* x, const float* dy, float* gw_oihw, float* gbias, const float* saved,
+                                    const int32_t* cd, void* ws, size_t ws_bytes, void* stream) {
   ConvGeom g;
   if (vcg_conv_geom(cd, &g, "vcg_conv_wgrad")) return -1;
   VCG_CHECK_ARG(x && dy && gw_oihw && ws, "vcg_conv_wgrad: null pointer");
@@ -2478,7 +2499,7 @@ extern "C" int vcg_conv_wgrad(const float* x, const float* dy, float* gw_oihw, f
   VCG_CHECK_ARG(ws_bytes >= need, "vcg_conv_wgrad: workspace %zu < %zu", ws_bytes, need);
   if (vcg_wino_wgrad_ok(g)) {
     const size_t wbytes = vcg_wino_wgrad_workspace(g);
-    if (vcg_wino_wgrad(g, x, dy, gw_oihw, ws, wbytes, (hipStream_t)stream)) return -2;
+    if (vcg_wino_wgrad(g, x, dy, gw_oihw, ws, wbytes, (hipStream_t)stream, saved)) return -2;
     if (gbias) return launch_colsum(g, dy, gbias, (float*)((char*)ws + ((wbytes + 255) / 256) * 256), (hipStream_t)stream);
     return 0;
   }

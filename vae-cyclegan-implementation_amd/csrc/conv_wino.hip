@@ -421,8 +421,9 @@ static WinoP wino_params(const ConvGeom& g) {
   return p;
 }
 
-// weight gradient: V = B^T x B (recomputed: keeping the forward's copy would hold 4x every activation), dM = A dy A^T,
-// then the batched reduction over tiles and the back-transform (conv_igemm.hip)
+// weight gradient: V = B^T x B — the forward's own copy when the caller kept it (vcg_conv_fwd_in's `saved`: 4x the
+// activation, 3.5 GB over a CycleVAEGAN step at batch 8, against 288 GB of HBM), recomputed otherwise — dM = A dy A^T, then
+// the batched reduction over tiles and the back-transform (conv_igemm.hip)
 bool vcg_wino_wgrad_ok(const ConvGeom& g) {
   // the transforms move 16 T (Kc + Cout) floats each way while the GEMMs save ~ T Kc Cout multiplications: it pays
   // from Kc Cout / (Kc + Cout) ~ 128 on (measured: 171 -> 1.46x, 85 -> 0.9x)
@@ -433,14 +434,19 @@ size_t vcg_wino_wgrad_workspace(const ConvGeom& g) {
   const int T = g.N * (g.Ho / 2) * (g.Wo / 2);
   return vcg_wino_fwd_workspace(g) + vcg_wino_wgrad_core_workspace(g, T);
 }
-int vcg_wino_wgrad(const ConvGeom& g, const float* x, const float* dy, float* gw_oihw, void* ws, size_t ws_bytes, hipStream_t st) {
+size_t vcg_wino_saved_floats(const ConvGeom& g) {
+  return vcg_wino_wgrad_ok(g) ? (size_t)16 * g.N * (g.Ho / 2) * (g.Wo / 2) * g.ups * g.ups * g.Cin : 0;
+}
+int vcg_wino_wgrad(const ConvGeom& g, const float* x, const float* dy, float* gw_oihw, void* ws, size_t ws_bytes, hipStream_t st,
+                   const float* v_saved) {
   VCG_CHECK_ARG(ws && ws_bytes >= vcg_wino_wgrad_workspace(g), "vcg_conv_wgrad: workspace too small for the Winograd path");
   WinoP p = wino_params(g);
   float* V = (float*)ws;
   float* dM = V + (((size_t)16 * p.T * p.Kc + 63) / 64) * 64;
   const size_t tbytes = vcg_wino_fwd_workspace(g);
   p.x = x; p.v = V;
-  hipLaunchKernelGGL(k_wino_in, dim3(wino_blocks((size_t)p.T * p.Kc / 4)), dim3(256), 0, st, p);
+  if (v_saved) V = const_cast<float*>(v_saved);
+  else hipLaunchKernelGGL(k_wino_in, dim3(wino_blocks((size_t)p.T * p.Kc / 4)), dim3(256), 0, st, p);
   hipLaunchKernelGGL(k_wino_dy, dim3(wino_blocks((size_t)p.T * g.Cout / 4)), dim3(256), 0, st, dy, dM, p);
   VCG_LAUNCH_CHECK("vcg_conv_wgrad(winograd transforms)");
   return vcg_wino_wgrad_core(g, V, dM, p.T, gw_oihw, (char*)ws + tbytes, ws_bytes - tbytes, st);
@@ -500,13 +506,14 @@ size_t vcg_wino_fwd_stats_doubles(const ConvGeom& g) {
   const NormPlan pl = vcg_norm_plan(g.N, (g.Ho / 2) * (g.Wo / 2), g.Cout);
   return (size_t)g.N * pl.nchunk * g.Cout * 2;
 }
+// v_keep: where to leave V = B^T x B for the weight gradient (vcg_wino_saved_floats), instead of the workspace
 int vcg_wino_fwd(const ConvGeom& g, const float* x, const float* u, const float* bias, float* y, void* ws, size_t ws_bytes,
-                 hipStream_t st, double* in_part, int* in_nchunk) {
+                 hipStream_t st, double* in_part, int* in_nchunk, float* v_keep) {
   VCG_CHECK_ARG(ws && ws_bytes >= vcg_wino_fwd_workspace(g), "vcg_conv_fwd: workspace too small for the Winograd path (%zu)",
                 ws_bytes);
   WinoP p = wino_params(g);
-  float* V = (float*)ws;
-  float* M = V + (((size_t)16 * p.T * p.Kc + 63) / 64) * 64;
+  float* V = v_keep ? v_keep : (float*)ws;
+  float* M = (float*)ws + (((size_t)16 * p.T * p.Kc + 63) / 64) * 64;
   p.x = x; p.v = V; p.m = M; p.bias = bias; p.y = y;
   hipLaunchKernelGGL(k_wino_in, dim3(wino_blocks((size_t)p.T * p.Kc / 4)), dim3(256), 0, st, p);
   VCG_LAUNCH_CHECK("vcg_conv_fwd(winograd input transform)");

@@ -184,12 +184,14 @@ size_t vcg_wino_weight_floats(const ConvGeom& g);
 size_t vcg_wino_fwd_workspace(const ConvGeom& g);
 int vcg_wino_weight(const ConvGeom& g, const float* w_oihw, float* u, hipStream_t st);
 int vcg_wino_fwd(const ConvGeom& g, const float* x, const float* u, const float* bias, float* y, void* ws, size_t ws_bytes,
-                 hipStream_t st, double* in_part = nullptr, int* in_nchunk = nullptr);
+                 hipStream_t st, double* in_part = nullptr, int* in_nchunk = nullptr, float* v_keep = nullptr);
+size_t vcg_wino_saved_floats(const ConvGeom& g);
 size_t vcg_wino_fwd_stats_doubles(const ConvGeom& g);
 // Winograd weight gradient: transforms in conv_wino.hip, batched stream-K reduction + back-transform in conv_igemm.hip
 bool vcg_wino_wgrad_ok(const ConvGeom& g);
 size_t vcg_wino_wgrad_workspace(const ConvGeom& g);
-int vcg_wino_wgrad(const ConvGeom& g, const float* x, const float* dy, float* gw_oihw, void* ws, size_t ws_bytes, hipStream_t st);
+int vcg_wino_wgrad(const ConvGeom& g, const float* x, const float* dy, float* gw_oihw, void* ws, size_t ws_bytes, hipStream_t st,
+                   const float* v_saved = nullptr);
 size_t vcg_wino_wgrad_core_workspace(const ConvGeom& g, int T);
 int vcg_wino_wgrad_core(const ConvGeom& g, const float* V, const float* dM, int T, float* gw_oihw, void* ws, size_t ws_bytes,
                         hipStream_t st);

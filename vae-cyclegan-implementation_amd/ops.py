@@ -293,6 +293,10 @@ def repack_async(params):
             sp.packed(w)
 
 
+# Keep the forward's Winograd-transformed input for the weight gradient (VCG_KEEP_FORWARD_STATE=0: recompute it, as round 1 did)
+KEEP_FORWARD_STATE = os.environ.get("VCG_KEEP_FORWARD_STATE", "1") != "0"
+
+
 # Data parallelism: parallel.GradReducer.note — told about every weight gradient the backward has issued (and on which
 # stream), so that a gradient bucket can be exchanged as soon as its last contribution is in flight.
 GRAD_READY_HOOK = [None]
@@ -362,7 +366,13 @@ class _ConvBlockFn(torch.autograd.Function):
         t = torch.empty((n, ho, wo, spec.cout_pitch), dtype=torch.float32, device=dev)
         flops = 2.0 * n * ho * wo * spec.cout * spec.k * spec.k * spec.cin
         tag = f"{n}x{h}x{w}x{spec.cin_pitch}->{spec.cout_pitch} k{spec.k} s{spec.stride} u{spec.ups}"
-        mean = rstd = None
+        mean = rstd = saved = None
+        # forward state the weight gradient can reuse (the Winograd-transformed input V: 4x the activation — HBM is 288 GB)
+        # (grad mode is off inside Function.forward: needs_input_grad[1] says whether a backward for the weight will come)
+        if wparam is not None and wparam.requires_grad and ctx.needs_input_grad[1] and KEEP_FORWARD_STATE:
+            nsv = int(lib.vcg_conv_saved_floats(cd))
+            if nsv:
+                saved = torch.empty(nsv, dtype=torch.float32, device=dev)
         if spec.norm:
             # the conv and the statistics of the InstanceNorm that follows it in one call: the partial sums come out of
             # the conv's own epilogue where its launch plan allows (csrc/conv_igemm.hip, vcg_conv_fwd_in)
@@ -371,8 +381,8 @@ class _ConvBlockFn(torch.autograd.Function):
             rstd = torch.empty((n, c), dtype=torch.float32, device=dev)
             with _timed("conv_fwd", flops, tag):
                 ws = workspace(lib.vcg_conv_fwd_in_workspace(cd), dev)
-                _native.check(lib.vcg_conv_fwd_in(_ptr(xp), _ptr(wf), _ptr(bias), _ptr(t), _ptr(mean), _ptr(rstd), IN_EPS, cd,
-                                                  _ptr(ws), ws.numel() * 4, _stream()), "vcg_conv_fwd_in")
+                _native.check(lib.vcg_conv_fwd_in(_ptr(xp), _ptr(wf), _ptr(bias), _ptr(t), _ptr(mean), _ptr(rstd), IN_EPS,
+                                                  _ptr(saved), cd, _ptr(ws), ws.numel() * 4, _stream()), "vcg_conv_fwd_in")
             resp = as_phys(residual) if residual is not None else None
             if spec.shuffle:
                 outp = torch.empty((n, 2 * ho, 2 * wo, c // 4), dtype=torch.float32, device=dev)
@@ -388,12 +398,13 @@ class _ConvBlockFn(torch.autograd.Function):
                 raise RuntimeError("residual/shuffle/post_act need norm=True")
             with _timed("conv_fwd", flops, tag):
                 ws = workspace(lib.vcg_conv_fwd_workspace(cd), dev)
-                _native.check(lib.vcg_conv_fwd(_ptr(xp), _ptr(wf), _ptr(bias), _ptr(t), cd, _ptr(ws), ws.numel() * 4,
-                                               _stream()), "vcg_conv_fwd")
+                _native.check(lib.vcg_conv_fwd_in(_ptr(xp), _ptr(wf), _ptr(bias), _ptr(t), None, None, IN_EPS, _ptr(saved), cd,
+                                                  _ptr(ws), ws.numel() * 4, _stream()), "vcg_conv_fwd_in")
             outp, cout_log = t, spec.cout
         ctx.spec, ctx.cd, ctx.dims, ctx.flops, ctx.tag = spec, cd, (n, h, w, ho, wo), flops, tag
         ctx.wparam, ctx.bparam = wparam, bparam
         ctx.has_res = residual is not None
+        ctx.saved_state = saved
         ctx.save_for_backward(xp, t, mean, rstd, wf)
         return logical_of(outp, cout_log)
 
@@ -421,6 +432,8 @@ class _ConvBlockFn(torch.autograd.Function):
         else:
             dt = gp
         wparam, bparam = ctx.wparam, ctx.bparam
+        saved = ctx.saved_state
+        ctx.saved_state = None                                        # one backward per forward: hand the 4x buffer back early
         if wparam is not None and wparam.requires_grad and id(wparam) not in _NO_WGRAD:
             gw = _grad_buffer(wparam)
             gb = _grad_buffer(bparam) if (bparam is not None and bparam.requires_grad) else None
@@ -434,8 +447,8 @@ class _ConvBlockFn(torch.autograd.Function):
             def run_wgrad():
                 ws = workspace(wsb, dev)
                 with _timed("conv_wgrad", ctx.flops, ctx.tag):
-                    _native.check(lib.vcg_conv_wgrad(_ptr(xp), _ptr(dt), _ptr(gw), _ptr(gb), cd, _ptr(ws), ws.numel() * 4,
-                                                     _stream()), "vcg_conv_wgrad")
+                    _native.check(lib.vcg_conv_wgrad_saved(_ptr(xp), _ptr(dt), _ptr(gw), _ptr(gb), _ptr(saved), cd, _ptr(ws),
+                                                           ws.numel() * 4, _stream()), "vcg_conv_wgrad")
             if _OVERLAP[0]:
                 side = _side_stream(dev)
                 side.wait_stream(torch.cuda.current_stream(dev))      # dt (and, the first time, x) are ready
@@ -443,6 +456,8 @@ class _ConvBlockFn(torch.autograd.Function):
                     run_wgrad()
                 xp.record_stream(side)                                # the allocator must not recycle them under the side stream
                 dt.record_stream(side)
+                if saved is not None:
+                    saved.record_stream(side)
                 wstream = side
             else:
                 run_wgrad()
