@@ -79,7 +79,7 @@ def test_launch_plans_are_host_side_and_consistent(pkg):
     # Wf (fp32) + U + Ud: the Winograd-transformed kernels as pre-split bf16 planes (3 pieces x 2 bytes = 1.5 floats per value)
     assert lib.vcg_pack_weight_floats(r) == 9 * kc * co + 2 * 16 * kc * co * 3 // 2
     assert lib.vcg_conv_fwd_workspace(r) == 16 * T * (kc + co) * f4 + 512
-    assert lib.vcg_conv_dgrad_workspace(r) == (16 * Tp * (kc + co) + 8 * 18 * 18 * kc) * f4 + 1024
+    assert lib.vcg_conv_dgrad_workspace(r) == 16 * Tp * (kc + co) * f4 + 1024       # V and M over the padded domain's 9 x 9 tiles
     assert lib.vcg_conv_wgrad_workspace(r) > 16 * T * (kc + co) * f4                  # transforms + stream-K slabs
     # same channels on an odd map: direct kernels, K-sliced forward (slabs) but no Winograd buffers
     odd = _desc(8, 15, 15, 1024, 1024, 3)

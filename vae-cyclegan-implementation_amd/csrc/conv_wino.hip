@@ -303,6 +303,87 @@ __global__ __launch_bounds__(256) void k_wino_out_pad(const float* __restrict__ 
 
 // dx[n][h*ups+i][w*ups+j][c] = sum over padded coordinates (qh, qw) that the padding maps onto (h, w) of dxp[n][qh][qw][(i,j,c)]
 // pad = 1: q = h + 1 always; with reflect padding the halo row q = 0 lands on h = 1 and q = Hl + 1 on h = Hl - 2.
+// k_wino_out_pad and k_wino_fold in one pass (the padded-domain image dxp never exists): a thread owns one padded-domain
+// tile x 4 columns, transforms it, and writes those of its 2 x 2 outputs that are image pixels straight to dx — adding,
+// for the pixels on rows / columns 1 and Hl - 2 (Wl - 2), the halo elements that reflect onto them.  A halo element belongs
+// to another tile; it is recomputed here from the 9 (of 16) transform points it depends on (Y[r][c] = sum A[i][r] M[i][j] A[j][c],
+// A's columns (1,1,1,0) and (0,1,-1,-1)): border threads read up to 2x (corners 3x) — a quarter of the tiles at 16 x 16 maps,
+// 6 % at 64 x 64 — against a write and a re-read of the whole padded image saved.
+__device__ __forceinline__ float4 wino_out_elem(const float* __restrict__ mb, size_t plane, int rr, int cc) {
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int xi_r = rr + i;                               // rows with a non-zero A entry: rr .. rr + 2
+    const float sr = (rr == 1 && i > 0) ? -1.f : 1.f;      // column 1 of A = (0, 1, -1, -1)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int xi_c = cc + j;
+      const float sc = (cc == 1 && j > 0) ? -1.f : 1.f;
+      const float4 v = *reinterpret_cast<const float4*>(mb + (size_t)(xi_r * 4 + xi_c) * plane);
+      const float sg = sr * sc;
+      acc.x += sg * v.x; acc.y += sg * v.y; acc.z += sg * v.z; acc.w += sg * v.w;
+    }
+  }
+  return acc;
+}
+__global__ __launch_bounds__(256) void k_wino_out_fold(const float* __restrict__ m, float* __restrict__ dx, WinoP p, int Hl, int Wl,
+                                                       int Cin, int ups, int reflect) {
+  const uint32_t k4n = (uint32_t)p.Kc / 4;
+  const size_t total = (size_t)p.T * k4n;
+  const size_t plane = (size_t)p.T * p.Kc;
+  const int W = Wl * ups;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    const uint32_t t = (uint32_t)(idx / k4n);
+    const int k = (int)(idx - (size_t)t * k4n) * 4;
+    const uint32_t n = fd_div(t, p.fd_thtw);
+    const uint32_t rem = t - n * (uint32_t)(p.th * p.tw);
+    const int ty = (int)fd_div(rem, p.fd_tw);
+    const int tx = (int)(rem - (uint32_t)ty * (uint32_t)p.tw);
+    const float* mb = m + (size_t)t * p.Kc + k;
+    float4 s0[4], s1[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const float4 m0 = *reinterpret_cast<const float4*>(mb + (size_t)(0 + b) * plane);
+      const float4 m1 = *reinterpret_cast<const float4*>(mb + (size_t)(4 + b) * plane);
+      const float4 m2 = *reinterpret_cast<const float4*>(mb + (size_t)(8 + b) * plane);
+      const float4 m3 = *reinterpret_cast<const float4*>(mb + (size_t)(12 + b) * plane);
+      s0[b] = f4sum(f4sum(m0, m1), m2);
+      s1[b] = f4sub(f4sub(m1, m2), m3);
+    }
+    float4 o[2][2];
+    o[0][0] = f4sum(f4sum(s0[0], s0[1]), s0[2]);
+    o[0][1] = f4sub(f4sub(s0[1], s0[2]), s0[3]);
+    o[1][0] = f4sum(f4sum(s1[0], s1[1]), s1[2]);
+    o[1][1] = f4sub(f4sub(s1[1], s1[2]), s1[3]);
+    const int ph = k / Cin, c = k - ph * Cin;
+    const int pi = ph >> 1, pj = ph & 1;
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int qy = 2 * ty + r, qx = 2 * tx + q;          // padded-domain coordinates
+        if (qy < 1 || qy > Hl || qx < 1 || qx > Wl) continue;  // a halo element: folded by the pixel it reflects onto
+        const int h = qy - 1, w = qx - 1;
+        float4 sum = o[r][q];
+        if (reflect) {
+          int qh[2], qw[2], nh = 1, nw = 1;
+          qh[0] = qy; qw[0] = qx;
+          if (h == 1) qh[nh++] = 0;
+          if (h == Hl - 2) qh[nh++] = Hl + 1;                // Hl >= 4: h == 1 and h == Hl - 2 are different rows
+          if (w == 1) qw[nw++] = 0;
+          if (w == Wl - 2) qw[nw++] = Wl + 1;
+          for (int a = 0; a < nh; ++a)
+            for (int b = 0; b < nw; ++b) {
+              if (a == 0 && b == 0) continue;
+              const size_t t2 = ((size_t)n * p.th + (qh[a] >> 1)) * p.tw + (qw[b] >> 1);
+              const float4 v = wino_out_elem(m + t2 * p.Kc + k, plane, qh[a] & 1, qw[b] & 1);
+              sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
+            }
+        }
+        *reinterpret_cast<float4*>(dx + (((size_t)n * Hl * ups + h * ups + pi) * W + (w * ups + pj)) * Cin + c) = sum;
+      }
+  }
+}
 __global__ __launch_bounds__(256) void k_wino_fold(const float* __restrict__ dxp, float* __restrict__ dx, int N, int Hl, int Wl,
                                                    int Cin, int ups, int reflect) {
   const int U2 = ups * ups, Kc = U2 * Cin, c4n = Cin / 4;
@@ -463,7 +544,7 @@ bool vcg_wino_dgrad_ok(const ConvGeom& g) {
 size_t vcg_wino_dgrad_workspace(const ConvGeom& g) {
   const size_t Tp = (size_t)g.N * (g.Ho / 2 + 1) * (g.Wo / 2 + 1);
   const size_t kc = (size_t)g.ups * g.ups * g.Cin;
-  return ((size_t)16 * Tp * (kc + g.Cout) + (size_t)g.N * (g.Ho + 2) * (g.Wo + 2) * kc) * sizeof(float) + 1024;
+  return (size_t)16 * Tp * (kc + g.Cout) * sizeof(float) + 1024;
 }
 int vcg_wino_weight_dgrad(const ConvGeom& g, const float* w_oihw, float* ud, hipStream_t st) {
   const size_t total = (size_t)g.ups * g.ups * g.Cin * g.Cout / 4;
@@ -487,16 +568,15 @@ int vcg_wino_dgrad(const ConvGeom& g, const float* dy, const float* ud, float* d
   p.fd_co4 = make_fastdiv((uint32_t)kc / 4);
   float* V = (float*)ws;
   float* M = V + (((size_t)16 * p.T * g.Cout + 63) / 64) * 64;
-  float* dxp = M + (((size_t)16 * p.T * kc + 63) / 64) * 64;
   p.v = V; p.m = M;
   hipLaunchKernelGGL(k_wino_in, dim3(wino_blocks((size_t)p.T * g.Cout / 4)), dim3(256), 0, st, p);
   VCG_LAUNCH_CHECK("vcg_conv_dgrad(winograd input transform)");
   if (vcg_gemm_split_batched(V, ud, M, p.T, g.Cout, kc, 16, st)) return -2;
   WinoP q = p;
   q.Kc = kc;                                      // the output side: k columns
-  hipLaunchKernelGGL(k_wino_out_pad, dim3(wino_blocks((size_t)p.T * kc / 4)), dim3(256), 0, st, (const float*)M, dxp, q);
-  hipLaunchKernelGGL(k_wino_fold, dim3(wino_blocks((size_t)g.N * g.Hl * g.Wl * kc / 4)), dim3(256), 0, st, (const float*)dxp, dx,
-                     g.N, g.Hl, g.Wl, g.Cin, g.ups, g.reflect);
+  // output transform and fold in one pass: the padded image is never written
+  hipLaunchKernelGGL(k_wino_out_fold, dim3(wino_blocks((size_t)p.T * kc / 4)), dim3(256), 0, st, (const float*)M, dx, q, g.Hl, g.Wl,
+                     g.Cin, g.ups, g.reflect);
   VCG_LAUNCH_CHECK("vcg_conv_dgrad(winograd output transform)");
   return 0;
 }
