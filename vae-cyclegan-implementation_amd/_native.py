@@ -10,7 +10,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(_HERE, "libvcg.so")
-SOURCES = ["conv_igemm.hip", "conv_thin.hip", "conv_wino.hip", "conv_slab.hip", "gemm_split.hip", "norm.hip", "misc.hip", "input.hip"]
+SOURCES = ["conv_igemm.hip", "conv_thin.hip", "conv_wino.hip", "conv_slab.hip", "conv_ring.hip", "gemm_split.hip", "norm.hip", "misc.hip", "input.hip"]
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "vcg.h")
 
 _c = ctypes

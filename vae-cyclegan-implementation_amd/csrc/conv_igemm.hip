@@ -2050,6 +2050,11 @@ static bool slab_enabled() {
   static const int on = [] { const char* e = getenv("VCG_SLAB"); return e ? atoi(e) : 1; }();
   return on != 0;
 }
+// VCG_RING=0: the row-ring weight gradients (conv_ring.hip) out of the dispatch
+static bool wgrad_ring_ok(const ConvGeom& g) {
+  static const int on = [] { const char* e = getenv("VCG_RING"); return e ? atoi(e) : 1; }();
+  return on != 0 && !vcg_wino_wgrad_ok(g) && vcg_ring_wgrad_ok(g);
+}
 static bool fwd_slab_ok(const ConvGeom& g) {
   return slab_enabled() && !vcg_thin_fold_ok(g) && !vcg_thin_fwd_ok(g) && !vcg_wino_fwd_ok(g) && wft_wanted(g) && vcg_slab_fwd_ok(g);
 }
@@ -2452,6 +2457,7 @@ extern "C" size_t vcg_conv_wgrad_workspace(const int32_t* cd) {
   colsum_plan(gorig, tc, cgroups, rows, nchunk);
   size_t cols = (size_t)nchunk * gorig.Cout * sizeof(float);
   if (vcg_wino_wgrad_ok(g)) return ((vcg_wino_wgrad_workspace(g) + 255) / 256) * 256 + cols + 1024;
+  if (wgrad_ring_ok(g)) return ((vcg_ring_wgrad_workspace(g) + 255) / 256) * 256 + cols + 1024;
   if (wgrad_swapped_ok(g)) g = swapped_geom(g);
   const WgradPlan wp = wgrad_plan(g);
   const int nsplit = wp.parts;
@@ -2501,6 +2507,12 @@ extern "C" int vcg_conv_wgrad_saved(const float* x, const float* dy, float* gw_o
     const size_t wbytes = vcg_wino_wgrad_workspace(g);
     if (vcg_wino_wgrad(g, x, dy, gw_oihw, ws, wbytes, (hipStream_t)stream, saved)) return -2;
     if (gbias) return launch_colsum(g, dy, gbias, (float*)((char*)ws + ((wbytes + 255) / 256) * 256), (hipStream_t)stream);
+    return 0;
+  }
+  if (wgrad_ring_ok(g)) {
+    const size_t rbytes = vcg_ring_wgrad_workspace(g);
+    if (vcg_ring_wgrad(g, x, dy, gw_oihw, ws, rbytes, (hipStream_t)stream)) return -2;
+    if (gbias) return launch_colsum(g, dy, gbias, (float*)((char*)ws + ((rbytes + 255) / 256) * 256), (hipStream_t)stream);
     return 0;
   }
   const bool swapped = wgrad_swapped_ok(g);

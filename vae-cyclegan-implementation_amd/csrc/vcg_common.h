@@ -209,6 +209,10 @@ int vcg_slab_fwd(const ConvGeom& g, const float* x, const void* wft_planes, size
                  double* in_part, int* in_nchunk, hipStream_t st);
 int vcg_slab_dgrad(const ConvGeom& g, const float* dy, const void* wfd_planes, size_t planes_bytes, float* dx, void* ws,
                    size_t ws_bytes, hipStream_t st);
+// conv_ring.hip: weight gradients of U4 / head / stem with row-ring staging (the taps are address offsets of the fragment reads)
+bool vcg_ring_wgrad_ok(const ConvGeom& g);
+size_t vcg_ring_wgrad_workspace(const ConvGeom& g);
+int vcg_ring_wgrad(const ConvGeom& g, const float* x, const float* dy, float* gw_oihw, void* ws, size_t ws_bytes, hipStream_t st);
 // conv_thin.hip: thin forward with kw folded into the GEMM's N (MFMA)
 bool vcg_thin_fold_ok(const ConvGeom& g);
 size_t vcg_thin_fold_weight_floats(const ConvGeom& g);
