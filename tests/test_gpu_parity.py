@@ -171,6 +171,7 @@ ORACLE_CONV_CASES = [
     ("U", (128, 64), {}, (1, 128, 32, 32)),           # U4's shape class: InstanceNorm partials from the slab epilogue
     ("S", (32, 128), {}, (1, 32, 70, 64)),            # data gradient: four k chunks on the 16 x 16 blocks, ragged rows
     # the row-ring weight gradients (conv_ring.hip; the four cases above take its 3x3 mode): the 7x7 thin layers on maps >= 64 x 64
+    ("D", (32, 64), {}, (1, 32, 128, 144)),           # 3x3 mode through a folded PixelUnshuffle: four channel groups = the four phases
     ("CaSb", (3, 64, 7), {}, (1, 3, 72, 64)),         # stem: x (3 channels) is the ring operand, read through the reflect padding
     ("CaSb", (64, 3, 7), {"activation": "Identity", "use_norm": False}, (2, 64, 64, 80)),   # head: dy is the ring, ragged segments (86 = 2.7 x 32)
 ]

@@ -33,7 +33,8 @@ struct RingP {
   int r_shift;
   int w_reflect, w_off;   // wide coordinate of K position (y, x) = (y - w_off, x - w_off), then reflect / zero outside
   int nseg, nrs, rows_per_band;
-  int cgroup;             // U mode: first ring channel of this launch's group = 32 * blockIdx.z; wide tile = blockIdx.y
+  int r_ups, r_gpp;       // U mode with a folded PixelUnshuffle: the ring tensor is (N, Hr * ups, Wr * ups, Cr), channel group z holds
+                          // phase z / r_gpp (i = phase >> 1, j = phase & 1), channels 32 * (z % r_gpp) .. + 31   (ups 1: r_gpp = Cr / 32)
   uint32_t ring_bytes, wide_bytes;
 };
 
@@ -80,7 +81,9 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_ring(RingP p) {
   const int y0 = rs * p.rows_per_band;
   int y1 = y0 + p.rows_per_band;
   if (y1 > p.Yd) y1 = p.Yd;
-  const int cg = THIN ? 0 : (int)blockIdx.z * 32;            // ring channel group (U mode)
+  const int rph = THIN ? 0 : (int)blockIdx.z / p.r_gpp;      // ring channel group (U mode): unshuffle phase and first channel
+  const int cg = THIN ? 0 : ((int)blockIdx.z - rph * p.r_gpp) * 32;
+  const int rpi = rph >> 1, rpj = rph & 1;
   const int wt = (int)blockIdx.y * 64;                       // wide channel tile
 
   const __amdgpu_buffer_rsrc_t rr = rg_srd(p.ring, p.ring_bytes), rw = rg_srd(p.wide, p.wide_bytes);
@@ -100,7 +103,7 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_ring(RingP p) {
     } else {
       ok = ok && xc >= 0 && xc < p.Wr;
     }
-    rcol[a] = ok ? (uint32_t)((xc * p.Cr + cg + q * 4) * 4) : RG_OOB;
+    rcol[a] = ok ? (uint32_t)(((xc * p.r_ups + rpj) * p.Cr + cg + q * 4) * 4) : RG_OOB;
     rlds[a] = idx < RQ ? (uint32_t)(px * RROW + q * 8) : RG_OOB;
   }
   // wide quads: 32 px x 16 quads = 512 -> 2 per thread
@@ -129,7 +132,7 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_ring(RingP p) {
     } else if (yr < 0 || yr >= p.Hr) {
       return RG_OOB;
     }
-    return (uint32_t)(((n * p.Hr + yr) * p.Wr) * p.Cr * 4);
+    return (uint32_t)((((n * p.Hr + yr) * p.r_ups + rpi) * p.Wr * p.r_ups) * p.Cr * 4);
   };
   auto wide_row = [&](int y) -> uint32_t {
     int yw = y - p.w_off;
@@ -283,19 +286,20 @@ __global__ __launch_bounds__(256) void k_ring_sum(const float4* __restrict__ sla
     out[((size_t)blockIdx.z * gridDim.y + g) * total4 + i] = s;
   }
 }
-// mode 0 (U): row (tap, c in group), column co      -> gw[co][cg + c][tap]
+// mode 0 (U): row (tap, c in group), column co      -> gw[co][(cg + c) * U2 + phase][tap]   (U2 = ups^2 phases of a folded PixelUnshuffle)
 // mode 1 (stem): row (kh, j, c), column co          -> gw[co][c][kh * 7 + j]            (j < 7, c < cin_log)
 // mode 2 (head): row (kh', j, co), column c          -> gw[co][c][(6 - kh') * 7 + 6 - j]  (j < 7, co < cout_log)
 __global__ __launch_bounds__(256) void k_ring_scatter(const float* __restrict__ grp, float* __restrict__ gw, int G, int NR, int mode,
-                                                      int cin_log, int cout_log, int ngroups, int ntiles) {
+                                                      int cin_log, int cout_log, int ngroups, int ntiles, int U2, int gpp) {
   const int total = NR * 64;
   const int sub = blockIdx.y;                                // = wide tile + ntiles * channel group (the launch's (y, z) order)
   const int wtile = sub % ntiles, cgrp = sub / ntiles;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
     const int row = i >> 6, col = i & 63;
-    int co, c, tap, KK;
+    int co, c, tap, KK, ph = 0;
     if (mode == 0) {
-      tap = row >> 5; c = cgrp * 32 + (row & 31); co = wtile * 64 + col; KK = 9;
+      ph = cgrp / gpp;
+      tap = row >> 5; c = (cgrp - ph * gpp) * 32 + (row & 31); co = wtile * 64 + col; KK = 9;
     } else {
       const int kh = row >> 5, j = (row >> 2) & 7, q = row & 3;
       if (j >= 7) continue;
@@ -306,14 +310,15 @@ __global__ __launch_bounds__(256) void k_ring_scatter(const float* __restrict__ 
     if (co >= cout_log || c >= cin_log) continue;
     float s = 0.f;
     for (int g = 0; g < G; ++g) s += grp[((size_t)sub * G + g) * total + i];
-    gw[((size_t)co * cin_log + c) * KK + tap] += s;
+    gw[((size_t)co * (cin_log * U2) + (size_t)c * U2 + ph) * KK + tap] += s;
   }
 }
 
 // ------------------------------------------------------------------------------------------------------------- host side
 static int ring_mode(const ConvGeom& g) {
-  if (g.stride != 1 || g.ups != 1 || g.KH != g.KW || (long long)g.Ho * g.Wo < 64 * 64 || g.Ho != g.H || g.Wo != g.W) return -1;
-  if (g.KH == 3 && g.pad == 1 && g.Cin % 32 == 0 && g.Cin <= 64 && g.Cout % 64 == 0 && g.Cout <= 128) return 0;
+  if (g.stride != 1 || g.KH != g.KW || (long long)g.Ho * g.Wo < 64 * 64 || g.Ho != g.Hl || g.Wo != g.Wl) return -1;
+  if (g.KH == 3 && g.pad == 1 && g.Cin % 32 == 0 && g.ups * g.ups * g.Cin <= 256 && g.Cout % 64 == 0 && g.Cout <= 256) return 0;
+  if (g.ups != 1) return -1;
   if (g.KH == 7 && g.pad == 3 && g.reflect && g.Cin == 4 && g.Cout == 64) return 1;
   if (g.KH == 7 && g.pad == 3 && g.reflect && g.Cin == 64 && g.Cout == 4) return 2;
   return -1;
@@ -327,7 +332,7 @@ static RingPlan ring_plan(const ConvGeom& g) {
   const int Yd = mode == 2 ? g.H + 6 : g.Ho, Xd = mode == 2 ? g.W + 6 : g.Wo;
   pl.nseg = (Xd + 31) / 32;
   pl.ntiles = mode == 0 ? g.Cout / 64 : 1;
-  pl.ngroups = mode == 0 ? g.Cin / 32 : 1;
+  pl.ngroups = mode == 0 ? g.ups * g.ups * g.Cin / 32 : 1;
   const int sub = pl.ntiles * pl.ngroups;
   int nrs = 768 / (g.N * pl.nseg * sub);                     // ~768 resident workgroups (3 per CU: 164 / 134 VGPRs, 51 / 32 KB of LDS)
   if (nrs < 1) nrs = 1;
@@ -364,12 +369,13 @@ int vcg_ring_wgrad(const ConvGeom& g, const float* x, const float* dy, float* gw
     p.w_reflect = 1; p.w_off = 3;
   } else {                               // U / stem: x shifts (through the padding), dy is the plain operand
     const int pad = g.pad;
-    p.ring = x; p.Hr = g.H; p.Wr = g.W; p.Cr = g.Cin; p.ring_bytes = (uint32_t)xb;
+    p.ring = x; p.Hr = g.Hl; p.Wr = g.Wl; p.Cr = g.Cin; p.ring_bytes = (uint32_t)xb;
     p.wide = dy; p.Hw = g.Ho; p.Ww = g.Wo; p.Cw = g.Cout; p.wide_bytes = (uint32_t)db;
     p.Yd = g.Ho; p.Xd = g.Wo;
     p.r_reflect = g.reflect; p.r_off = pad; p.r_shift = 0;
     p.w_reflect = 0; p.w_off = 0;
   }
+  p.r_ups = mode == 0 ? g.ups : 1; p.r_gpp = mode == 0 ? g.Cin / 32 : 1;
   p.nseg = pl.nseg; p.nrs = pl.nrs; p.rows_per_band = pl.rows;
   p.slabs = (float*)ws;
   const dim3 grid(pl.nwg, pl.ntiles, pl.ngroups);
@@ -386,7 +392,7 @@ int vcg_ring_wgrad(const ConvGeom& g, const float* x, const float* dy, float* gw
   hipLaunchKernelGGL(k_ring_sum, dim3((total4 + 255) / 256, pl.G, sub), dim3(256), 0, st, (const float4*)ws, (float4*)grp, total4, pl.nwg,
                      pl.per_group);
   hipLaunchKernelGGL(k_ring_scatter, dim3((pl.NR * 64 + 255) / 256, sub), dim3(256), 0, st, (const float*)grp, gw_oihw, pl.G, pl.NR, mode,
-                     g.cin_log, g.cout_log, pl.ngroups, pl.ntiles);
+                     g.cin_log, g.cout_log, pl.ngroups, pl.ntiles, g.ups * g.ups, mode == 0 ? g.Cin / 32 : 1);
   VCG_LAUNCH_CHECK("vcg_conv_wgrad(ring reduce)");
   return 0;
 }
