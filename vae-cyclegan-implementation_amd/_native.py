@@ -9,7 +9,8 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-LIB_PATH = os.path.join(_HERE, "libvcg.so")
+# VCG_LIBVCG: load another build of the same sources (A/B runs of kernel variants, tools/); the default is the in-tree library
+LIB_PATH = os.environ.get("VCG_LIBVCG") or os.path.join(_HERE, "libvcg.so")
 SOURCES = ["conv_igemm.hip", "conv_thin.hip", "conv_wino.hip", "conv_slab.hip", "conv_ring.hip", "gemm_split.hip", "norm.hip", "misc.hip", "input.hip"]
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "vcg.h")
 
@@ -81,6 +82,8 @@ def hipcc_path():
 
 def build(force=False, verbose=False):
     """hipcc --offload-arch=gfx950 -> libvcg.so next to this file (cross-compiles without a GPU)."""
+    if os.environ.get("VCG_LIBVCG"):
+        return LIB_PATH                              # a variant build made by hand: never rebuilt here
     srcs = [os.path.join(CSRC, s) for s in SOURCES]
     deps = srcs + [os.path.join(CSRC, "vcg_common.h"), HEADER]
     if not force and os.path.exists(LIB_PATH):
