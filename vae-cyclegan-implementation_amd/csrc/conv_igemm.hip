@@ -679,7 +679,8 @@ __global__ __launch_bounds__(256, 2) void k_conv_dgrad(ConvP p) {
   const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
   const int a_row = tid >> 3, a_u = tid & 7;
   const int s = p.stride, sshift = s - 1;
-  const int cls = p.ksplit > 1 ? 0 : (int)blockIdx.z;     // blockIdx.z: parity class (stride 2) OR K slice
+  // blockIdx.z = parity class (stride 2: s * s of them) + s * s * K slice
+  const int cls = (int)blockIdx.z % (s * s), kslice = (int)blockIdx.z / (s * s);
   const int ca = cls / s, cb = cls % s;
   const int kh0 = (ca + p.pad) % s, kw0 = (cb + p.pad) % s;
   const int nKH = (p.KH - kh0 + s - 1) / s, nKW = (p.KW - kw0 + s - 1) / s;
@@ -711,8 +712,8 @@ __global__ __launch_bounds__(256, 2) void k_conv_dgrad(ConvP p) {
   float4 va[AR], ve[AR], vb[BR];
   int nkt = (Kc + BK - 1) / BK;
   int kt0 = 0;
-  if (p.ksplit > 1) {                      // stride 1 only: blockIdx.z is the K slice, not a parity class
-    kt0 = (int)blockIdx.z * p.kt_per;
+  if (p.ksplit > 1) {
+    kt0 = kslice * p.kt_per;
     int kt1 = kt0 + p.kt_per;
     nkt = kt1 < nkt ? kt1 : nkt;
   }
@@ -830,7 +831,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_dgrad(ConvP p) {
 
   // epilogue: column J = (q, c) -> physical pixel (h*ups + i, w*ups + j), channel c.
   // A K slice writes its raw partial into slab[z] in the same physical layout; k_splitk_finish sums them.
-  float* const dst = p.ksplit > 1 ? p.slab + (size_t)blockIdx.z * p.N * p.H * p.W * p.Cin : p.out;
+  float* const dst = p.ksplit > 1 ? p.slab + (size_t)kslice * p.N * p.H * p.W * p.Cin : p.out;
 #pragma unroll
   for (int j = 0; j < NI; ++j) {
     const int J = n0 + wn * (BN / WN) + j * 32 + l31;
@@ -874,7 +875,8 @@ __global__ __launch_bounds__(256, 2) void k_conv_dgrad_split(ConvP p) {
   const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
   const int a_row = tid >> 3, a_u = tid & 7;
   const int s = p.stride, sshift = s - 1;
-  const int cls = p.ksplit > 1 ? 0 : (int)blockIdx.z;     // blockIdx.z: parity class (stride 2) OR K slice
+  // blockIdx.z = parity class (stride 2: s * s of them) + s * s * K slice
+  const int cls = (int)blockIdx.z % (s * s), kslice = (int)blockIdx.z / (s * s);
   const int ca = cls / s, cb = cls % s;
   const int kh0 = (ca + p.pad) % s, kw0 = (cb + p.pad) % s;
   const int nKH = (p.KH - kh0 + s - 1) / s, nKW = (p.KW - kw0 + s - 1) / s;
@@ -913,8 +915,8 @@ __global__ __launch_bounds__(256, 2) void k_conv_dgrad_split(ConvP p) {
   u32x4 vbp[BP];
   int nkt = (Kc + BK - 1) / BK;
   int kt0 = 0;
-  if (p.ksplit > 1) {                      // stride 1 only: blockIdx.z is the K slice, not a parity class
-    kt0 = (int)blockIdx.z * p.kt_per;
+  if (p.ksplit > 1) {
+    kt0 = kslice * p.kt_per;
     int kt1 = kt0 + p.kt_per;
     nkt = kt1 < nkt ? kt1 : nkt;
   }
@@ -1068,7 +1070,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_dgrad_split(ConvP p) {
 
   // epilogue: column J = (q, c) -> physical pixel (h*ups + i, w*ups + j), channel c.
   // A K slice writes its raw partial into slab[z] in the same physical layout; k_splitk_finish sums them.
-  float* const dst = p.ksplit > 1 ? p.slab + (size_t)blockIdx.z * p.N * p.H * p.W * p.Cin : p.out;
+  float* const dst = p.ksplit > 1 ? p.slab + (size_t)kslice * p.N * p.H * p.W * p.Cin : p.out;
 #pragma unroll
   for (int j = 0; j < NI; ++j) {
     const int J = n0 + wn * (BN / WN) + j * 32 + l31;
@@ -2266,8 +2268,17 @@ static int dgrad_setup(const ConvGeom& g, ConvP& p, int& bm, int& bn, int& nspli
   p.NB = g.ups * g.ups * g.Cin;
   p.fd_hcwc = make_fastdiv((uint32_t)(p.Hc * p.Wc));
   p.fd_wc = make_fastdiv((uint32_t)p.Wc);
-  // stride 2 uses blockIdx.z for its parity classes, so only stride 1 can slice K
-  gemm_plan(p.Mc, p.NB, (g.KH * g.KW * g.Cout + BK - 1) / BK, g.stride == 1, bm, bn, nsplit, kt_per, 1, true);
+  // stride s: s * s parity classes, each a GEMM over its own (KH / s) x (KW / s) taps — the planner sees them as batches,
+  // and blockIdx.z = class + s * s * K slice
+  const int s = g.stride;
+  gemm_plan(p.Mc, p.NB, (g.KH * g.KW * g.Cout + BK - 1) / BK, s == 1, bm, bn, nsplit, kt_per, 1, true);
+  if (s > 1 && g.KH % s == 0 && g.KW % s == 0) {
+    // the unsliced plan fills the chip for the large maps (measured: slicing made 64 -> 128 at 128^2 and 128 -> 256 at 64^2
+    // slower); the deep layer (256 -> 512 at 32^2: 256 workgroups) is the one that needs its K cut
+    const long long wgs = ((p.Mc + bm - 1) / bm) * ((p.NB + bn - 1) / bn) * s * s;
+    if (wgs < 384)
+      gemm_plan(p.Mc, p.NB, ((g.KH / s) * (g.KW / s) * g.Cout + BK - 1) / BK, true, bm, bn, nsplit, kt_per, s * s, true);
+  }
   return 0;
 }
 
@@ -2315,7 +2326,7 @@ extern "C" int vcg_conv_dgrad(const float* dy, const float* wf, float* dx, const
     VCG_CHECK_ARG(ws && ws_bytes >= vcg_conv_dgrad_workspace(cd), "vcg_conv_dgrad: workspace too small (%zu)", ws_bytes);
     p.ksplit = nsplit; p.kt_per = kt_per; p.slab = (float*)ws;
   }
-  dim3 grid((p.Mc + bm - 1) / bm, (p.NB + bn - 1) / bn, nsplit > 1 ? nsplit : g.stride * g.stride);
+  dim3 grid((p.Mc + bm - 1) / bm, (p.NB + bn - 1) / bn, nsplit * g.stride * g.stride);
   hipStream_t st = (hipStream_t)stream;
   {
     const double gemm_flops = 2.0 * g.M * (double)g.K * g.Cout;   // stride 2: the parity classes together visit every tap once
