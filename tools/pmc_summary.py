@@ -37,8 +37,9 @@ def load(path, counter):
     return [rows[k] for k in sorted(rows)]
 
 
-WGRAD = ("k_conv_wgrad", "k_wino_dy", "k_wino_wgrad_reduce", "k_wgrad_reduce", "k_wgrad_scatter", "k_slab_sum", "k_colsum")
-DGRAD = ("k_conv_dgrad", "k_wino_out_pad", "k_wino_fold", "k_fold_pad", "k_conv_thin<1>", "k_kwfold")
+WGRAD = ("k_conv_wgrad", "k_wino_dy", "k_wino_wgrad_reduce", "k_wgrad_reduce", "k_wgrad_scatter", "k_slab_sum", "k_colsum",
+         "k_wgrad_ring", "k_ring_sum", "k_ring_scatter")
+DGRAD = ("k_conv_dgrad", "k_wino_out_pad", "k_wino_out_fold", "k_wino_fold", "k_fold_pad", "k_conv_thin<1>")
 FWD = ("k_conv_fwd", "k_wino_out", "k_conv_thin<0>", "k_splitk_finish")
 
 
@@ -53,10 +54,13 @@ def families(seq):
         elif n.startswith("k_wino_in"):
             nxt = [seq[j]["name"] for j in range(i + 1, min(i + 4, len(seq)))]
             fam[i] = "conv_wgrad" if nxt and nxt[0].startswith("k_wino_dy") else \
-                     "conv_dgrad" if len(nxt) > 1 and nxt[1].startswith("k_wino_out_pad") else "conv_fwd"
+                     "conv_dgrad" if len(nxt) > 1 and nxt[1].startswith(("k_wino_out_pad", "k_wino_out_fold")) else "conv_fwd"
         elif n.startswith("k_gemm_split"):
             nxt = seq[i + 1]["name"] if i + 1 < len(seq) else ""
-            fam[i] = "conv_dgrad" if nxt.startswith("k_wino_out_pad") else "conv_fwd"
+            fam[i] = "conv_dgrad" if nxt.startswith(("k_wino_out_pad", "k_wino_out_fold")) else "conv_fwd"
+        elif n.startswith(("k_conv_slab", "k_kwfold")):        # data gradient when a fold of the padded image follows
+            nxt = [seq[j]["name"] for j in range(i + 1, min(i + 3, len(seq)))]
+            fam[i] = "conv_dgrad" if any(x.startswith("k_fold_pad") for x in nxt) else "conv_fwd"
         elif n.startswith(FWD):
             fam[i] = "conv_fwd"
         elif n.startswith("k_in_bwd") or n.startswith("k_in_partial<1>") or n.startswith("k_in_final<1>"):
