@@ -45,5 +45,7 @@ def run(cin, cout, h, w, n):
           f"dgrad hip {rel(dxh, dx64):.2e} cpu32 {rel(dx32, dx64):.2e} | wgrad hip {rel(dwh, dw64):.2e} cpu32 {rel(dw32, dw64):.2e}")
 
 
-for cfg in [(64, 64, 32, 32, 2), (512, 512, 8, 8, 2), (1024, 1024, 16, 16, 2), (256, 128, 32, 32, 2), (2048, 1024, 4, 4, 2)]:
+for cfg in [(64, 64, 32, 32, 2), (512, 512, 8, 8, 2), (1024, 1024, 16, 16, 2), (256, 128, 32, 32, 2), (2048, 1024, 4, 4, 2),
+            # round 2: shapes that take the LDS-slab forward / data gradient and the row-ring weight gradient (maps >= 64 x 64)
+            (32, 64, 128, 128, 2), (64, 128, 64, 96, 2), (128, 256, 64, 64, 1)]:
     run(*cfg)
