@@ -97,6 +97,15 @@ def test_launch_plans_are_host_side_and_consistent(pkg):
     assert lib.vcg_conv_fwd_workspace(u4) == 0
     # ... and it runs on the LDS-slab kernels: the data gradient over the padded domain (H + 2) x (W + 2), folded afterwards
     assert lib.vcg_conv_dgrad_workspace(u4) == 8 * 258 * 258 * 32 * f4 + 256
+    # ... and its weight gradient on the row-ring kernel: one [288][64] partial per workgroup + 16 group sums (conv_ring.hip)
+    def ring_ws(n, yd, xd, nr, sub=1):
+        nseg = (xd + 31) // 32
+        nrs = max(768 // (n * nseg * sub), 1)
+        rows = max((yd + nrs - 1) // nrs, 8)
+        nwg = n * nseg * ((yd + rows - 1) // rows)
+        per = (nwg + 15) // 16
+        return (sub * nwg + sub * ((nwg + per - 1) // per)) * nr * 64 * f4 + 256
+    assert 0 <= lib.vcg_conv_wgrad_workspace(u4) - (ring_ws(8, 256, 256, 288) + 255) // 256 * 256 <= 1 << 20     # + bias column sums
     # the latent convs 1024 -> 64: Kc Cout / (Kc + Cout) = 60 is under every Winograd gate (forward 64, data gradient 80):
     # no transformed copies, the planes of the direct split-operand kernels instead
     mu = _desc(8, 16, 16, 1024, 64, 3)
@@ -106,6 +115,8 @@ def test_launch_plans_are_host_side_and_consistent(pkg):
     # (+ that copy's pre-split planes [32][7 * 64 / 32][3][32] for the LDS-slab column kernel)
     assert lib.vcg_pack_weight_floats(head) == ((49 * 64 * 4 + 63) // 64) * 64 + 7 * 64 * 32 + 7 * 64 * 48
     assert lib.vcg_conv_fwd_workspace(head) == 8 * 256 * (256 + 6) * 32 * f4 + 256
+    # its weight gradient: the ring kernel over the PADDED input pixels (262 x 262), 7 tap rows x 32 columns per partial
+    assert 0 <= lib.vcg_conv_wgrad_workspace(head) - (ring_ws(8, 262, 262, 224) + 255) // 256 * 256 <= 1 << 20
     # encoder stem 3 -> 64: the data gradient takes the folded path (padded-domain dxp + P), the forward does not
     stem = _desc(8, 256, 256, 4, 64, 7, pad=3, cin_log=3)
     assert lib.vcg_pack_weight_floats(stem) == ((49 * 4 * 64 + 63) // 64) * 64 + 7 * 64 * 32 + 7 * 64 * 48 + 64 * 7 * 48     # K = 196 -> 7 blocks
