@@ -23,6 +23,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--batch", type=int, default=8)
+    ap.add_argument("--defer", action="store_true", help="what-if: copy the metrics to pinned memory without waiting for them "
+                    "(no per-step host sync); reports the mean step time over --steps against the synchronous loop")
     args = ap.parse_args()
     pkg = importlib.import_module("vae-cyclegan-implementation_amd")
     ops, N = pkg.ops, pkg.Networks
@@ -43,6 +45,27 @@ def main():
         stamps.append(time.perf_counter())
         return inner(named, reducer)
 
+    if args.defer:
+        def deferred(named, reducer=None):
+            keys = list(named.keys())
+            vec = torch.stack([named[k].detach().reshape(()) for k in keys])
+            host = torch.empty(vec.shape, dtype=vec.dtype, pin_memory=True)
+            host.copy_(vec, non_blocking=True)
+            return dict.fromkeys(keys, 0.0)
+
+        for mode, fn in (("synchronous read-back", inner), ("deferred read-back", deferred), ("synchronous read-back", inner),
+                         ("deferred read-back", deferred)):
+            N._metrics_to_host = fn
+            for i in range(3):
+                model.training_step(pool[i % 4])
+            gc.collect()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(args.steps):
+                model.training_step(pool[i % 4])
+            torch.cuda.synchronize()
+            print(f"{mode}: {(time.perf_counter() - t0) / args.steps * 1e3:.2f} ms/step over {args.steps} steps")
+        return
     N._metrics_to_host = stamped
     for i in range(3):
         model.training_step(pool[i % 4])
