@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define VCG_ABI_VERSION 1
+#define VCG_ABI_VERSION 2   /* round 2: vcg_adam_step takes 1 - beta; vcg_conv_fwd_in, vcg_conv_wgrad_saved, input transforms, profiling */
 
 /* conv descriptor: int32[16] ------------------------------------------------ */
 enum {

@@ -30,7 +30,7 @@ def test_library_builds_and_exports_every_declared_symbol(pkg):
 def test_python_binding_covers_the_header(pkg):
     assert sorted(pkg._native.SIGNATURES) == header_symbols()
     lib = pkg._native.lib()
-    assert lib.vcg_abi_version() == 1
+    assert lib.vcg_abi_version() == 2
 
 
 def test_code_object_targets_gfx950(pkg):

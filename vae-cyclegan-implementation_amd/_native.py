@@ -117,7 +117,7 @@ def lib():
             fn = getattr(handle, name)
             fn.restype = res
             fn.argtypes = args
-        if handle.vcg_abi_version() != 1:
+        if handle.vcg_abi_version() != 2:
             raise RuntimeError("libvcg.so ABI version mismatch; rebuild it")
         _lib = handle
     return _lib
