@@ -179,13 +179,22 @@ int vcg_fullmap_wgrad(const float* g, const float* x, const float* wsn_k, const 
 
 /* Input transforms on the device — the torchvision pipelines of train.py:184-190, 248-262, 309-319 ------------------------- */
 /* RandomHorizontal/VerticalFlip -> RandomResizedCrop(S, BICUBIC) | Resize((S,S)) -> ToTensor for N decoded uint8 HWC images
-   packed in `arena`.  params[n][16] (device, int32): arena byte offset lo, hi; source H, W; crop box y0, x0, h, w in
-   FLIPPED-image coordinates; flip_h; flip_v; filter (0 bicubic, 1 bilinear).  Pillow's antialiased convolution resize in
-   floating point.  out: (N, S, S, 4) fp32, channel 3 = 0 — the layout every network entry point takes.                        */
-int vcg_input_resample(const unsigned char* arena, const int32_t* params, float* out, int N, int S, void* stream);
+   packed in `arena`.  params[n][16] (device, int32): source offset lo, hi; source H, W; crop box y0, x0, h, w in
+   FLIPPED-image coordinates; flip_h; flip_v; filter (0 bicubic, 1 bilinear); source kind (0: uint8 RGB in `arena`, offset in
+   bytes; 1: float4 pixels in [0, 1] in `fsrc` — what vcg_input_prejitter left — offset in pixels; fsrc may be NULL when no
+   sample uses it).  Pillow's antialiased convolution resize in floating point.  out: (N, S, S, 4) fp32, channel 3 = 0 — the
+   layout every network entry point takes.                                                                                     */
+int vcg_input_resample(const unsigned char* arena, const float* fsrc, const int32_t* params, float* out, int N, int S,
+                       void* stream);
 /* torchvision ColorJitter (tensor-path formulas) in place on (N, S, S, 4).  jitter[n][8] (device, fp32): enabled, brightness,
    contrast, saturation, hue factors, order code o0 + 4 o1 + 16 o2 + 64 o3 (0 brightness, 1 contrast, 2 saturation, 3 hue). */
 int vcg_input_color_jitter(float* img, const float* jitter, int N, int S, void* stream);
+/* ColorJitter on WHOLE decoded frames, before any crop — hypersim's colour modality (Data_Manager.py:164-171 applies
+   color_transform first, then the spatial transform): unpacks N uint8 frames into float4 pixels in `fbuf` and jitters them
+   there.  frames[n][8] (device, int32): arena byte offset lo, hi; pixel count; fbuf pixel offset lo, hi.  var[n][4]: fbuf
+   pixel offset lo, hi; pixel count.  jitter[n][8] as above.                                                                   */
+int vcg_input_prejitter(const unsigned char* arena, const int32_t* frames, const float* jitter, const int32_t* var,
+                        float* fbuf, int N, void* stream);
 
 /* torch.optim.Adam.step — call sites Networks.py:312,894,1928-1935 ---------- */
 /* single-tensor torch formula on one flat buffer:

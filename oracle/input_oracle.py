@@ -62,8 +62,10 @@ def resample_weights(box0, box_len, out_len, filt):
 
 
 def resample(src, box, out_size, flip_h=False, flip_v=False, filt=0):
-    """src: (H, W, 3) uint8.  box = (y0, x0, h, w) in FLIPPED-image coordinates.  Returns (S, S, 3) float64 in [0, 1]
+    """src: (H, W, 3) uint8 — or a float image already in [0, 1] (hypersim's colour modality, jittered on the whole frame before
+    the crop: Data_Manager.py:164-171).  box = (y0, x0, h, w) in FLIPPED-image coordinates.  Returns (S, S, 3) float64 in [0, 1]
     (not clamped: bicubic overshoot stays, as ToTensor of a float image would keep it; Pillow's uint8 clips it)."""
+    unit = 255.0 if src.dtype == np.uint8 else 1.0
     img = src.astype(np.float64)
     if flip_h:
         img = img[:, ::-1]
@@ -79,7 +81,7 @@ def resample(src, box, out_size, flip_h=False, flip_v=False, filt=0):
     out = np.zeros((S, S, 3))
     for o, (first, wts) in enumerate(wy):
         out[o] = np.tensordot(tmp[first:first + len(wts)], wts, axes=([0], [0]))
-    return out / 255.0
+    return out / unit
 
 
 def _gray(img):

@@ -81,6 +81,43 @@ def test_draws_follow_torchvision_get_params(pkg):
     assert ip.draw_crop(np.random.RandomState(0), 100, 1000, (0.9, 1.0)) == (0, 450, 100, 100)    # never fits: centred square
 
 
+def test_hypersim_folder_scan_follows_the_reference_layout(pkg, tmp_path):
+    """Data_Manager.py:68-138: <root>/<scene>/cam_XX/frame_NNNN_<modality>.png; a frame that lacks a requested modality is
+    skipped; paired -> both modalities of ONE frame, one modality -> x is y, unpaired -> y from a uniformly drawn frame."""
+    from PIL import Image
+    ip = pkg.input_pipeline
+    root = tmp_path / "hypersim"
+    rng = np.random.RandomState(0)
+    for scene, cam, frames, mods in (("ai_001_001_unknown", "cam_00", ("0000", "0001", "0002"), ("color", "depth")),
+                                     ("ai_001_002_kitchen", "cam_01", ("0000", "0001"), ("color", "depth")),
+                                     ("ai_001_002_kitchen", "cam_02", ("0005",), ("color",))):          # no depth: skipped for 2 modalities
+        d = root / scene / cam
+        d.mkdir(parents=True, exist_ok=True)
+        for f in frames:
+            for m in mods:
+                Image.fromarray(rng.randint(0, 255, (12, 16, 3), dtype=np.uint8)).save(d / f"frame_{f}_{m}.png")
+    (root / "README.txt").write_text("not a scene")
+    both = ip.HypersimFolders(str(root), ["color", "depth"], paired=True)
+    assert len(both) == 5 and both.pre_jitter == (True, False)
+    x, y = both.pair(0, np.random.RandomState(1))
+    assert x.shape == (12, 16, 3) and y.shape == (12, 16, 3) and not np.array_equal(x, y)
+    assert np.array_equal(x, np.asarray(Image.open(both.samples[0][0]).convert("RGB")))
+    single = ip.HypersimFolders(str(root), ["color"], paired=True)
+    assert len(single) == 6
+    x, y = single.pair(5, np.random.RandomState(1))
+    assert x is y
+    unp = ip.HypersimFolders(str(root), ["depth", "color"], paired=False)
+    assert unp.pre_jitter == (False, True)
+    ys = {unp.pair(0, np.random.RandomState(s))[1].tobytes() for s in range(40)}
+    assert len(ys) > 1                                                                       # y comes from drawn frames
+    sub = both.subset([3, 4])
+    assert len(sub) == 2 and sub.samples[0] == both.samples[3]
+    with pytest.raises(ValueError):
+        ip.HypersimFolders(str(root), ["color", "depth", "normal"], paired=True)
+    with pytest.raises(ValueError):
+        ip.HypersimFolders(str(tmp_path / "nothing"), ["color"], paired=True)
+
+
 # --------------------------------------------------------------------------------------------- GPU: the kernels
 def _run_resample(pkg, device, srcs, geos, S):
     import ctypes
@@ -95,7 +132,7 @@ def _run_resample(pkg, device, srcs, geos, S):
     da, dg = torch.from_numpy(arena).to(device), torch.from_numpy(g).to(device)
     out = torch.empty((len(srcs), S, S, 4), dtype=torch.float32, device=device)
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-    pkg._native.check(lib.vcg_input_resample(ctypes.c_void_p(da.data_ptr()), ctypes.c_void_p(dg.data_ptr()), ctypes.c_void_p(out.data_ptr()),
+    pkg._native.check(lib.vcg_input_resample(ctypes.c_void_p(da.data_ptr()), None, ctypes.c_void_p(dg.data_ptr()), ctypes.c_void_p(out.data_ptr()),
                                              len(srcs), S, st), "vcg_input_resample")
     return out
 
@@ -143,18 +180,20 @@ def test_color_jitter_kernel_matches_the_oracle(pkg, device):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("recipe", ["summer2winter", "maps", "test"])
+@pytest.mark.parametrize("recipe", ["summer2winter", "maps", "test", "hypersim", "hypersim_unpaired"])
 def test_pipeline_batches_equal_the_oracle_on_the_same_draws(recipe, pkg, device):
     """End to end: decode (thread pool) -> pinned arena -> side-stream upload + kernels, double-buffered.  Every batch must
     equal the oracle applied to the same images with the same draws, also while the NEXT batch is being staged."""
     ip = pkg.input_pipeline
     S, B = 64, 3
-    src = ip.SyntheticImages(10, min_side=80, max_side=160, seed=3, paired=recipe == "maps")
-    pipe = ip.DeviceInputPipeline(src, B, S, device, recipe=recipe, shuffle=True, seed=9, num_workers=2)
+    hyper = recipe.startswith("hypersim")                                               # x plays the `color` modality, y e.g. depth
+    src = ip.SyntheticImages(10, min_side=80, max_side=160, seed=3, paired=recipe in ("maps", "hypersim"),
+                             pre_jitter=(True, False) if hyper else (False, False))
+    pipe = ip.DeviceInputPipeline(src, B, S, device, recipe="hypersim" if hyper else recipe, shuffle=True, seed=9, num_workers=2)
     assert len(pipe) == 4
     seen = 0
     for batch in pipe:
-        geo, jit, imgs = pipe.last_draws
+        geo, jit, imgs, pre = pipe.last_draws
         nb = batch["x"].shape[0]
         assert tuple(batch["x"].shape) == (nb, 3, S, S) and pkg.ops.is_nhwc_view(batch["x"]) and batch["x"].is_cuda
         xs = batch["x"].permute(0, 2, 3, 1).cpu().numpy()
@@ -162,14 +201,21 @@ def test_pipeline_batches_equal_the_oracle_on_the_same_draws(recipe, pkg, device
         for k in range(nb):
             for got, r in ((xs[k], k), (ys[k], nb + k)):
                 g = geo[r]
-                ref = io.resample(imgs[r], tuple(g[4:8]), S, bool(g[8]), bool(g[9]), int(g[10]))
+                srcimg = imgs[r]
+                if r in pre:                                                             # jittered on the whole frame first
+                    pj = pre[r]
+                    srcimg = io.color_jitter(imgs[r] / 255.0, *pj[1:5].astype(np.float64), tuple((int(pj[5]) >> (2 * q)) & 3 for q in range(4)))
+                    assert g[11] == 1
+                ref = io.resample(srcimg, tuple(g[4:8]), S, bool(g[8]), bool(g[9]), int(g[10]))
                 if jit[r, 0]:
                     order = tuple((int(jit[r, 5]) >> (2 * q)) & 3 for q in range(4))
                     ref = io.color_jitter(ref, *jit[r, 1:5].astype(np.float64), order)
                 err = np.abs(got - ref)
                 assert np.quantile(err, 0.999) <= 3e-5 and (err > 1e-3).sum() <= 3, (recipe, k, err.max())
-            if recipe == "maps":
+            if recipe in ("maps", "hypersim"):
                 assert np.array_equal(geo[k, 4:11], geo[nb + k, 4:11])                   # both halves share one draw
+        if hyper:
+            assert set(pre) == set(range(nb)) and len({tuple(v) for v in pre.values()}) == nb   # every x jittered, each with its own draw
         seen += nb
     assert seen == 10
     # the batches feed a model without any conversion: one AE forward on the last one

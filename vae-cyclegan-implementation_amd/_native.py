@@ -65,7 +65,8 @@ SIGNATURES = {
     "vcg_fullmap_fwd": (_I, [_P, _P, _P, _P, _I, _Z, _P]),
     "vcg_fullmap_dgrad": (_I, [_P, _P, _P, _I, _Z, _P]),
     "vcg_fullmap_wgrad": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _Z, _P]),
-    "vcg_input_resample": (_I, [_P, _P, _P, _I, _I, _P]),
+    "vcg_input_resample": (_I, [_P, _P, _P, _P, _I, _I, _P]),
+    "vcg_input_prejitter": (_I, [_P, _P, _P, _P, _P, _I, _P]),
     "vcg_input_color_jitter": (_I, [_P, _P, _I, _I, _P]),
     "vcg_adam_step": (_I, [_P, _P, _P, _P, _Z, _F, _F, _F, _F, _F, _F, _F, _F, _P]),
 }

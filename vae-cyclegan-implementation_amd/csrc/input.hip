@@ -15,12 +15,17 @@
 //   k_color_jitter     torchvision's tensor-path formulas: brightness / contrast / saturation as clamped blends, hue as an
 //                      HSV rotation, the four in the drawn order; contrast needs the image's mean grey -> one workgroup
 //                      per image, reduction in LDS.
-// Both are HBM/latency-trivial (a batch is 16 x 256 x 256 pixels); they are written for clarity, one thread per pixel.
+//   hypersim's colour modality is jittered BEFORE the crop, on the whole image (Data_Manager.py:164-171: color_transform, then
+//   the shared spatial transform): k_u8_to_f4 unpacks the decoded image into a float4 buffer, k_color_jitter runs on it at
+//   full resolution (image sizes from `var`), and k_input_resample reads that buffer instead of the uint8 arena (params[11]).
+// All of it is HBM/latency-trivial (a batch is 16 x 256 x 256 pixels, or 16 full frames); written for clarity.
 #include "vcg_common.h"
 
 struct ResampleP {
   const unsigned char* arena;
-  const int32_t* params;     // [N][16]: arena offset lo, hi, H, W, box y0, x0, h, w (flipped-image coordinates), flip_h, flip_v, filter
+  const float4* fsrc;        // float4 image buffer for the samples with params[11] == 1 (offset = PIXEL index into it), or null
+  const int32_t* params;     // [N][16]: arena offset lo, hi, H, W, box y0, x0, h, w (flipped-image coordinates), flip_h, flip_v, filter,
+                             //          source (0: uint8 RGB in the arena, offset in bytes; 1: float4 in fsrc, already in [0, 1])
   float* out;                // (N, S, S, 4), channel 3 = 0
   int N, S;
 };
@@ -58,7 +63,10 @@ __global__ __launch_bounds__(256) void k_input_resample(ResampleP p) {
     const int rem = (int)(idx - (size_t)n * S * S);
     const int oy = rem / S, ox = rem - oy * S;
     const int32_t* q = p.params + (size_t)n * 16;
-    const unsigned char* src = p.arena + (((size_t)(uint32_t)q[1]) << 32 | (size_t)(uint32_t)q[0]);
+    const size_t soff = ((size_t)(uint32_t)q[1]) << 32 | (size_t)(uint32_t)q[0];
+    const unsigned char* src = p.arena + soff;
+    const bool fl = q[11] == 1;
+    const float4* fs = p.fsrc + (fl ? soff : 0);
     const int H = q[2], W = q[3], y0 = q[4], x0 = q[5], bh = q[6], bw = q[7], fh = q[8], fv = q[9], kind = q[10];
     float cy, cx, fsy, fsx;
     int ty0, ty1, tx0, tx1;
@@ -78,14 +86,19 @@ __global__ __launch_bounds__(256) void k_input_resample(ResampleP p) {
         const float wx = filt(((float)tx - cx + 0.5f) / fsx, kind);
         int xx = x0 + tx;
         if (fh) xx = W - 1 - xx;
-        const unsigned char* px = row + (size_t)xx * 3;
-        rr += wx * (float)px[0];
-        rg += wx * (float)px[1];
-        rb += wx * (float)px[2];
+        if (fl) {
+          const float4 v = fs[(size_t)yy * W + xx];
+          rr += wx * v.x; rg += wx * v.y; rb += wx * v.z;
+        } else {
+          const unsigned char* px = row + (size_t)xx * 3;
+          rr += wx * (float)px[0];
+          rg += wx * (float)px[1];
+          rb += wx * (float)px[2];
+        }
       }
       r += wy * rr; g += wy * rg; b += wy * rb;
     }
-    const float norm = 1.f / (255.f * (sx != 0.f ? sx : 1.f) * (sy != 0.f ? sy : 1.f));
+    const float norm = 1.f / ((fl ? 1.f : 255.f) * (sx != 0.f ? sx : 1.f) * (sy != 0.f ? sy : 1.f));
     *reinterpret_cast<float4*>(p.out + idx * 4) = make_float4(r * norm, g * norm, b * norm, 0.f);
   }
 }
@@ -128,8 +141,10 @@ __device__ __forceinline__ float4 hue_shift(float4 v, float hue) {
   return o;
 }
 
-// one workgroup per image; jitter[n][8] = enabled, brightness, contrast, saturation, hue, order code (o0 + 4 o1 + 16 o2 + 64 o3)
-__global__ __launch_bounds__(1024) void k_color_jitter(float* __restrict__ img, const float* __restrict__ jitter, int S) {
+// one workgroup per image; jitter[n][8] = enabled, brightness, contrast, saturation, hue, order code (o0 + 4 o1 + 16 o2 + 64 o3).
+// var == null: N images of S x S pixels back to back; else var[n][4] = pixel offset lo, hi, pixel count (whole decoded frames)
+__global__ __launch_bounds__(1024) void k_color_jitter(float* __restrict__ img, const float* __restrict__ jitter, int S,
+                                                       const int32_t* __restrict__ var) {
   __shared__ double red[1024];
   __shared__ float mean_s;
   const int n = blockIdx.x, tid = threadIdx.x;
@@ -137,8 +152,8 @@ __global__ __launch_bounds__(1024) void k_color_jitter(float* __restrict__ img, 
   if (j[0] == 0.f) return;                                       // uniform per workgroup
   const float fb = j[1], fc = j[2], fs = j[3], fhue = j[4];
   const int code = (int)j[5];
-  float4* px = reinterpret_cast<float4*>(img) + (size_t)n * S * S;
-  const int npx = S * S;
+  float4* px = reinterpret_cast<float4*>(img) + (var ? (((size_t)(uint32_t)var[n * 4 + 1]) << 32 | (size_t)(uint32_t)var[n * 4]) : (size_t)n * S * S);
+  const int npx = var ? var[n * 4 + 2] : S * S;
   for (int i = tid; i < npx; i += 1024) {                        // a uint8 PIL image: the resize's overshoot was clipped
     float4 v = px[i];
     v.x = clamp01(v.x); v.y = clamp01(v.y); v.z = clamp01(v.z);
@@ -177,11 +192,12 @@ __global__ __launch_bounds__(1024) void k_color_jitter(float* __restrict__ img, 
   }
 }
 
-extern "C" int vcg_input_resample(const unsigned char* arena, const int32_t* params, float* out, int N, int S, void* stream) {
+extern "C" int vcg_input_resample(const unsigned char* arena, const float* fsrc, const int32_t* params, float* out, int N, int S,
+                                  void* stream) {
   VCG_CHECK_ARG(arena && params && out, "vcg_input_resample: null pointer");
   VCG_CHECK_ARG(N > 0 && S > 0 && S <= 4096, "vcg_input_resample: bad N=%d S=%d", N, S);
   ResampleP p;
-  p.arena = arena; p.params = params; p.out = out; p.N = N; p.S = S;
+  p.arena = arena; p.fsrc = (const float4*)fsrc; p.params = params; p.out = out; p.N = N; p.S = S;
   size_t blocks = ((size_t)N * S * S + 255) / 256;
   if (blocks > 16384) blocks = 16384;
   hipLaunchKernelGGL(k_input_resample, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p);
@@ -192,7 +208,31 @@ extern "C" int vcg_input_resample(const unsigned char* arena, const int32_t* par
 extern "C" int vcg_input_color_jitter(float* img, const float* jitter, int N, int S, void* stream) {
   VCG_CHECK_ARG(img && jitter, "vcg_input_color_jitter: null pointer");
   VCG_CHECK_ARG(N > 0 && S > 0, "vcg_input_color_jitter: bad N=%d S=%d", N, S);
-  hipLaunchKernelGGL(k_color_jitter, dim3(N), dim3(1024), 0, (hipStream_t)stream, img, jitter, S);
+  hipLaunchKernelGGL(k_color_jitter, dim3(N), dim3(1024), 0, (hipStream_t)stream, img, jitter, S, (const int32_t*)nullptr);
   VCG_LAUNCH_CHECK("vcg_input_color_jitter");
+  return 0;
+}
+
+// decoded uint8 RGB frames -> float4 pixels in [0, 1] (pad 0): frames[n][8] = arena byte offset lo, hi, pixel count, float-buffer
+// pixel offset lo, hi
+__global__ __launch_bounds__(256) void k_u8_to_f4(const unsigned char* __restrict__ arena, const int32_t* __restrict__ frames,
+                                                  float4* __restrict__ fbuf) {
+  const int32_t* q = frames + (size_t)blockIdx.y * 8;
+  const unsigned char* src = arena + (((size_t)(uint32_t)q[1]) << 32 | (size_t)(uint32_t)q[0]);
+  float4* dst = fbuf + (((size_t)(uint32_t)q[4]) << 32 | (size_t)(uint32_t)q[3]);
+  const int npx = q[2];
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < npx; i += gridDim.x * blockDim.x)
+    dst[i] = make_float4(src[3 * (size_t)i] * (1.f / 255.f), src[3 * (size_t)i + 1] * (1.f / 255.f), src[3 * (size_t)i + 2] * (1.f / 255.f), 0.f);
+}
+
+// ColorJitter on whole decoded frames, before any crop (hypersim's colour modality): unpack + jitter; the resample then reads
+// `fbuf` for these samples (params[11] == 1).  jitter[n][8] as above; var[n][4] = float-buffer pixel offset lo, hi, pixel count.
+extern "C" int vcg_input_prejitter(const unsigned char* arena, const int32_t* frames, const float* jitter, const int32_t* var,
+                                   float* fbuf, int N, void* stream) {
+  VCG_CHECK_ARG(arena && frames && jitter && var && fbuf, "vcg_input_prejitter: null pointer");
+  VCG_CHECK_ARG(N > 0, "vcg_input_prejitter: bad N=%d", N);
+  hipLaunchKernelGGL(k_u8_to_f4, dim3(256, N), dim3(256), 0, (hipStream_t)stream, arena, frames, (float4*)fbuf);
+  hipLaunchKernelGGL(k_color_jitter, dim3(N), dim3(1024), 0, (hipStream_t)stream, fbuf, jitter, 0, var);
+  VCG_LAUNCH_CHECK("vcg_input_prejitter");
   return 0;
 }

@@ -30,7 +30,9 @@ from . import _native, ops
 RECIPES = {
     "summer2winter": dict(hflip=0.5, vflip=0.0, scale=(0.33, 1.0), jitter=(0.2, 0.2, 0.2, 0.1), shared_draw=False),
     "maps": dict(hflip=0.5, vflip=0.0, scale=(0.33, 1.0), jitter=None, shared_draw=True),       # same RNG state for both halves
-    "hypersim": dict(hflip=0.5, vflip=0.3, scale=(0.33, 1.0), jitter=None, shared_draw=False),
+    # hypersim: both modalities of a sample go through the SAME random state (Data_Manager.py:160-165), the `color` modality is
+    # colour-jittered first, on the whole frame, then flipped / cropped / resized like the others (:169-174)
+    "hypersim": dict(hflip=0.5, vflip=0.3, scale=(0.33, 1.0), jitter=None, pre_jitter=(0.3, 0.3, 0.3, 0.15), shared_draw=True),
     "test": dict(hflip=0.0, vflip=0.0, scale=None, jitter=None, shared_draw=False, bilinear=True),   # Resize((S, S)) + ToTensor
 }
 
@@ -62,23 +64,31 @@ def draw_sample(rng, height, width, recipe):
         g[4:8] = (0, 0, height, width)
     g[10] = 1 if recipe.get("bilinear") else 0
     if recipe.get("jitter"):
-        b, c, s, h = recipe["jitter"]
-        order = rng.permutation(4)                                # torchvision: fn_idx = torch.randperm(4)
-        j[0] = 1.0
-        j[1] = rng.uniform(max(0.0, 1 - b), 1 + b)
-        j[2] = rng.uniform(max(0.0, 1 - c), 1 + c)
-        j[3] = rng.uniform(max(0.0, 1 - s), 1 + s)
-        j[4] = rng.uniform(-h, h)
-        j[5] = float(int(order[0]) + 4 * int(order[1]) + 16 * int(order[2]) + 64 * int(order[3]))
+        j = draw_jitter(rng, recipe["jitter"])
     return g, j
+
+
+def draw_jitter(rng, strengths):
+    """torchvision ColorJitter.get_params: the order of the four ops and their factors -> float32[8] as csrc/input.hip reads them"""
+    b, c, s, h = strengths
+    j = np.zeros(8, np.float32)
+    order = rng.permutation(4)                                    # torchvision: fn_idx = torch.randperm(4)
+    j[0] = 1.0
+    j[1] = rng.uniform(max(0.0, 1 - b), 1 + b)
+    j[2] = rng.uniform(max(0.0, 1 - c), 1 + c)
+    j[3] = rng.uniform(max(0.0, 1 - s), 1 + s)
+    j[4] = rng.uniform(-h, h)
+    j[5] = float(int(order[0]) + 4 * int(order[1]) + 16 * int(order[2]) + 64 * int(order[3]))
+    return j
 
 
 class SyntheticImages:
     """uint8 HWC image pairs of varying size drawn from a RandomState: smooth low-frequency content plus noise, so that
     resampling and jitter have something to act on.  For tests and for benchmarking the pipeline without a dataset."""
 
-    def __init__(self, count, min_side=300, max_side=640, seed=0, paired=False):
+    def __init__(self, count, min_side=300, max_side=640, seed=0, paired=False, pre_jitter=(False, False)):
         self.count, self.min_side, self.max_side, self.seed, self.paired = count, min_side, max_side, seed, paired
+        self.pre_jitter = pre_jitter                  # which half plays hypersim's `color` modality (jittered before the crop)
 
     def __len__(self):
         return self.count
@@ -148,6 +158,67 @@ class FolderPairs:
         return np.ascontiguousarray(img[:, :half]), np.ascontiguousarray(img[:, half:2 * half])
 
 
+class HypersimFolders:
+    """The reference's Hypersim tree as PNG frames (Data_Manager.py:18-138; the HDF5 download / conversion that produces it is
+    not part of the training path): <root>/<scene>/cam_XX/frame_NNNN_<modality>.png.  A sample needs every requested modality;
+    paired: x, y = the two modalities of one frame (one modality: x = y); unpaired: y is the second modality of a uniformly
+    drawn frame (:236-239).  `pre_jitter[k]` says whether half k is the `color` modality, which the reference colour-jitters
+    before the spatial transform."""
+
+    def __init__(self, root_dir, modalities, paired=True, indices=None):
+        from PIL import Image
+        self._Image = Image
+        if paired and len(modalities) not in (1, 2):
+            raise ValueError(f"paired_mode requires 1 or 2 modalities, got {len(modalities)}")
+        if not paired and len(modalities) != 2:
+            raise ValueError("Unpaired mode requires exactly 2 modalities")
+        self.modalities, self.paired = list(modalities), paired
+        self.pre_jitter = (modalities[0] == "color", modalities[-1] == "color")
+        samples = []
+        if not os.path.isdir(root_dir):
+            raise ValueError(f"No samples found in {root_dir}")
+        for scene in sorted(os.listdir(root_dir)):
+            sdir = os.path.join(root_dir, scene)
+            if not os.path.isdir(sdir):
+                continue
+            for cam in sorted(d for d in os.listdir(sdir) if d.startswith("cam_") and os.path.isdir(os.path.join(sdir, d))):
+                cdir = os.path.join(sdir, cam)
+                first = self.modalities[0]
+                for f in sorted(os.listdir(cdir)):
+                    if not (f.startswith("frame_") and f.endswith(f"_{first}.png")):
+                        continue
+                    frame_id = f[:-4].split("_")[1]
+                    paths = [os.path.join(cdir, f"frame_{frame_id}_{m}.png") for m in self.modalities]
+                    if all(os.path.exists(q) for q in paths):            # a frame that lacks a modality is skipped (:118-122)
+                        samples.append(paths)
+        if not samples:
+            raise ValueError(f"No samples found in {root_dir}")
+        self.all_samples = samples
+        self.samples = samples if indices is None else [samples[i] for i in indices]
+        if indices is None:
+            print(f"  Loaded dataset with {len(samples)} samples\n  Modalities: {', '.join(self.modalities)}")
+
+    def subset(self, indices):
+        """a view on some of the samples (train / test split, train.py:208-214); unpaired y draws stay within the subset's parent"""
+        sub = HypersimFolders.__new__(HypersimFolders)
+        sub.__dict__.update(self.__dict__)
+        sub.samples = [self.samples[i] for i in indices]
+        return sub
+
+    def __len__(self):
+        return len(self.samples)
+
+    def _open(self, path):
+        return np.asarray(self._Image.open(path).convert("RGB"))
+
+    def pair(self, idx, rng):
+        x = self._open(self.samples[idx][0])
+        if self.paired:
+            return x, (x if len(self.modalities) == 1 else self._open(self.samples[idx][1]))
+        j = int(rng.randint(0, len(self.all_samples)))                    # random.randint over the whole dataset (:238)
+        return x, self._open(self.all_samples[j][1])
+
+
 class DeviceInputPipeline:
     """len()-able iterable of {'x', 'y'} device batches (the reference's DataLoader surface, train.py:80-97).
 
@@ -177,6 +248,13 @@ class DeviceInputPipeline:
                 "g": torch.empty((2 * self.b, 16), dtype=torch.int32, device=self.dev),
                 "j": torch.empty((2 * self.b, 8), dtype=torch.float32, device=self.dev),
                 "out": torch.empty((2 * self.b, self.s, self.s, 4), dtype=torch.float32, device=self.dev),
+                "fpin": torch.empty((2 * self.b, 8), dtype=torch.int32).pin_memory(),      # pre-jitter: frames, var (csrc/input.hip)
+                "vpin": torch.empty((2 * self.b, 4), dtype=torch.int32).pin_memory(),
+                "pjpin": torch.empty((2 * self.b, 8), dtype=torch.float32).pin_memory(),
+                "f": torch.empty((2 * self.b, 8), dtype=torch.int32, device=self.dev),
+                "v": torch.empty((2 * self.b, 4), dtype=torch.int32, device=self.dev),
+                "pj": torch.empty((2 * self.b, 8), dtype=torch.float32, device=self.dev),
+                "fbuf": None,
                 "event": torch.cuda.Event(), "free": torch.cuda.Event(), "n": 0, "draws": None}
 
     def __len__(self):
@@ -196,7 +274,7 @@ class DeviceInputPipeline:
         geo, jit = np.zeros((2 * nb, 16), np.int32), np.zeros((2 * nb, 8), np.float32)
         for k in range(nb):
             gx, jx = draw_sample(self.rng, imgs[k].shape[0], imgs[k].shape[1], self.recipe)
-            if self.recipe.get("shared_draw") and imgs[nb + k].shape == imgs[k].shape:
+            if self.recipe.get("shared_draw") and getattr(self.src, "paired", True) and imgs[nb + k].shape == imgs[k].shape:
                 gy, jy = gx.copy(), jx.copy()                      # maps: the same RNG state transforms both halves
             else:
                 gy, jy = draw_sample(self.rng, imgs[nb + k].shape[0], imgs[nb + k].shape[1], self.recipe)
@@ -209,22 +287,53 @@ class DeviceInputPipeline:
             pin[off:off + flat.size] = flat
             geo.view(np.uint32)[k, 0], geo.view(np.uint32)[k, 1] = off & 0xFFFFFFFF, off >> 32
             off += flat.size
+        # hypersim's colour modality: ColorJitter on the whole frame before the crop.  Those frames are unpacked to float4 in
+        # `fbuf`, jittered there, and the resample reads them from it (geometry slot 11 = 1, offset = pixel index)
+        pre = self.recipe.get("pre_jitter")
+        which = getattr(self.src, "pre_jitter", (False, False)) if pre else (False, False)
+        pj_rows = [k for k in range(2 * nb) if which[0 if k < nb else 1]]
+        frames, var, pjit = np.zeros((2 * nb, 8), np.int32), np.zeros((2 * nb, 4), np.int32), np.zeros((2 * nb, 8), np.float32)
+        fpx = 0
+        for r, k in enumerate(pj_rows):
+            npx = imgs[k].shape[0] * imgs[k].shape[1]
+            frames.view(np.uint32)[r, 0], frames.view(np.uint32)[r, 1] = geo.view(np.uint32)[k, 0], geo.view(np.uint32)[k, 1]
+            frames[r, 2] = npx
+            frames.view(np.uint32)[r, 3], frames.view(np.uint32)[r, 4] = fpx & 0xFFFFFFFF, fpx >> 32
+            var.view(np.uint32)[r, 0], var.view(np.uint32)[r, 1], var[r, 2] = fpx & 0xFFFFFFFF, fpx >> 32, npx
+            if self.same_xy and k >= nb:
+                pjit[r] = pjit[pj_rows.index(k - nb)]                 # one modality: x = y is ONE transformed image
+            else:
+                pjit[r] = draw_jitter(self.rng, pre)
+            geo.view(np.uint32)[k, 0], geo.view(np.uint32)[k, 1], geo[k, 11] = fpx & 0xFFFFFFFF, fpx >> 32, 1
+            fpx += npx
+        if pj_rows and (slot["fbuf"] is None or slot["fbuf"].numel() < fpx * 4):
+            slot["fbuf"] = torch.empty(int(fpx * 4 * 1.25), dtype=torch.float32, device=self.dev)
         slot["gpin"][:2 * nb].copy_(torch.from_numpy(geo))
         slot["jpin"][:2 * nb].copy_(torch.from_numpy(jit))
+        if pj_rows:
+            slot["fpin"][:2 * nb].copy_(torch.from_numpy(frames))
+            slot["vpin"][:2 * nb].copy_(torch.from_numpy(var))
+            slot["pjpin"][:2 * nb].copy_(torch.from_numpy(pjit))
         lib = _native.lib()
         with torch.cuda.stream(self.stream):
             slot["arena"][:off].copy_(slot["pin"][:off], non_blocking=True)
             slot["g"][:2 * nb].copy_(slot["gpin"][:2 * nb], non_blocking=True)
             slot["j"][:2 * nb].copy_(slot["jpin"][:2 * nb], non_blocking=True)
             st = ctypes.c_void_p(self.stream.cuda_stream)
-            _native.check(lib.vcg_input_resample(ctypes.c_void_p(slot["arena"].data_ptr()), ctypes.c_void_p(slot["g"].data_ptr()),
-                                                 ctypes.c_void_p(slot["out"].data_ptr()), 2 * nb, self.s, st), "vcg_input_resample")
+            P = lambda t: ctypes.c_void_p(t.data_ptr())
+            if pj_rows:
+                for dst, srcp in (("f", "fpin"), ("v", "vpin"), ("pj", "pjpin")):
+                    slot[dst][:2 * nb].copy_(slot[srcp][:2 * nb], non_blocking=True)
+                _native.check(lib.vcg_input_prejitter(P(slot["arena"]), P(slot["f"]), P(slot["pj"]), P(slot["v"]), P(slot["fbuf"]),
+                                                      len(pj_rows), st), "vcg_input_prejitter")
+            _native.check(lib.vcg_input_resample(P(slot["arena"]), P(slot["fbuf"]) if pj_rows else None, P(slot["g"]), P(slot["out"]),
+                                                 2 * nb, self.s, st), "vcg_input_resample")
             if self.recipe.get("jitter"):
                 _native.check(lib.vcg_input_color_jitter(ctypes.c_void_p(slot["out"].data_ptr()), ctypes.c_void_p(slot["j"].data_ptr()),
                                                          2 * nb, self.s, st), "vcg_input_color_jitter")
             slot["event"].record(self.stream)
         slot["n"] = nb
-        slot["draws"] = (geo, jit, imgs)
+        slot["draws"] = (geo, jit, imgs, {k: pjit[r] for r, k in enumerate(pj_rows)})
 
     def __iter__(self):
         n = len(self.src)

@@ -24,6 +24,7 @@ from pathlib import Path
 
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # RCCL across processes needs dmabuf IPC on this driver
 
+import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 if __package__ in (None, ""):
@@ -200,11 +201,27 @@ def build_parser():
 
 def create_dataloaders(args, device, rank, world, epoch_seed):
     """reference train.py:174-357 (create_dataloaders_hypersim / _maps / _summer2winter) on the device-side input pipeline:
-    PIL decodes, the MI355X flips, crops, resamples, jitters and converts (input_pipeline.py).  `summer2winter` and `maps` read
-    the reference's directory layouts; `hypersim`'s HDF5-derived tree (Data_Manager.py:18-326) is not rebuilt."""
+    PIL decodes, the MI355X flips, crops, resamples, jitters and converts (input_pipeline.py), from the reference's directory
+    layouts (hypersim: the PNG scene tree Data_Manager.py:18-138 reads; its download / HDF5 conversion is out of scope)."""
     if args.dataset == "hypersim":
-        raise NotImplementedError("--dataset hypersim: the Hypersim scene tree of Data_Manager.py:18-326 is not rebuilt; "
-                                  "use summer2winter, maps or synthetic")
+        # reference train.py:174-239: one HypersimDataset with the TRAINING transforms, random_split into train / test
+        mods = [m for m in (args.source_modality, args.target_modality) if m]
+        if len(mods) == 2 and mods[0] == mods[1]:
+            mods = mods[:1]          # the reference keys its images by modality name: two equal names are ONE image, x is y
+        if not mods:
+            raise ValueError("--dataset hypersim needs --source_modality (and --target_modality)")
+        full = input_pipeline.HypersimFolders(os.path.join(args.data_dir, "hypersim"), mods, paired=args.paired or len(mods) == 1)
+        kw = dict(num_workers=max(1, args.num_workers), same_xy=len(mods) == 1)
+        order = np.random.RandomState(args.seed).permutation(len(full))
+        ntrain = int((1 - args.test_split) * len(full)) if args.test_split > 0 else len(full)
+        print(f"Training samples: {ntrain}" + (f", Testing samples: {len(full) - ntrain}" if args.test_split > 0 else ""))
+        train = input_pipeline.DeviceInputPipeline(full.subset(order[:ntrain]), args.batch_size, args.image_size, device,
+                                                   recipe="hypersim", shuffle=True, seed=epoch_seed * 64 + rank, **kw)
+        test = None
+        if args.test_split > 0 and ntrain < len(full):
+            test = input_pipeline.DeviceInputPipeline(full.subset(order[ntrain:]), args.batch_size, args.image_size, device,
+                                                      recipe="hypersim", shuffle=False, seed=epoch_seed * 64 + rank, **kw)
+        return train, test
     root = os.path.join(args.data_dir, args.dataset)
     same_xy = args.architecture in ("autoencoder", "vae")
     test_split = "test" if args.dataset == "summer2winter" else "val"
@@ -239,12 +256,22 @@ def main(args):
         if args.source_modality != args.target_modality:
             raise ValueError("Source and target modalities should be the same for Autoencoder/VAE architectures.")
 
-    output_dir = Path(args.output_dir) / f"{args.architecture}_{datetime.now().strftime('%m%d_%H%M')}_synthetic"
-    if rank == 0:
-        output_dir.mkdir(parents=True, exist_ok=True)
-        with open(output_dir / "args.json", "w") as f:
-            json.dump(vars(args), f, indent=2)
-        print(f"Using device: {device}  world size {world}\nOutput directory: {output_dir}")
+    # reference train.py:395-411: a resumed run continues in its checkpoint's directory, a new one gets
+    # <architecture>_<timestamp>_<source>_to_<target>_<dataset> and writes its args.json there
+    if args.resume:
+        if not Path(args.resume).exists():
+            raise FileNotFoundError(f"No checkpoint found at {args.resume}")
+        output_dir = Path(args.resume).parent
+        if rank == 0:
+            print(f"Using device: {device}  world size {world}\nResuming run in directory: {output_dir}")
+    else:
+        output_dir = Path(args.output_dir) / (f"{args.architecture}_{datetime.now().strftime('%m%d_%H%M')}_{args.source_modality}_to_"
+                                              f"{args.target_modality}_{args.dataset}")
+        if rank == 0:
+            output_dir.mkdir(parents=True, exist_ok=True)
+            with open(output_dir / "args.json", "w") as f:
+                json.dump(vars(args), f, indent=2)
+            print(f"Using device: {device}  world size {world}\nOutput directory: {output_dir}")
 
     torch.manual_seed(args.seed)                     # identical replicas
     ops.manual_seed(args.seed + 7919 * (rank + 1))   # per-rank eps stream
@@ -294,7 +321,7 @@ def main(args):
                 print(f"  {k}: {v:.6f}")
         # on the test set (reference train.py:533-537: every log_image_freq epochs); here a held-out synthetic stream.
         # validation_step has no exchange in it: every rank validates its own shard, rank 0 prints its numbers
-        if args.log_image_freq > 0 and epoch % args.log_image_freq == 0:
+        if args.log_image_freq > 0 and epoch % args.log_image_freq == 0 and not (image_loaders and image_loaders[1] is None):
             test_loader = image_loaders[1] if image_loaders else SyntheticLoader(
                 args.batch_size, args.image_size, max(1, args.steps_per_epoch // 10), device, args.seed + 1, rank, same_xy, epoch)
             test_loss, test_comps, *_ = validate(model, test_loader, device, args)
