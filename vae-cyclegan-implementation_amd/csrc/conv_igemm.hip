@@ -2332,7 +2332,10 @@ extern "C" int vcg_conv_dgrad(const float* dy, const float* wf, float* dx, const
     const double gemm_flops = 2.0 * g.M * (double)g.K * g.Cout;   // stride 2: the parity classes together visit every tap once
     const bool planes = bm == 128 && bn >= 64 && wfd_wanted(g);       // weight rows from the pre-split WFD planes of the pack
     if (planes) { p.b = wf + wfd_offset(g); p.b_bytes = (uint32_t)(wfd_floats(g) * 4); }
-    const bool split = planes || bn == 32;
+    // layers without planes (the 4-channel dy of the 7x7 head: K = (tap, co) is not a multiple of 32 per tap) still run on the
+    // bf16 pipe when their tile is 128 x 64: the weight rows are split in the kernel from Wf
+    const bool nopl64 = !planes && bm == 128 && bn == 64 && g.Cout % 4 == 0;
+    const bool split = planes || bn == 32 || nopl64;
     VcgProfScope prof(!split ? "k_conv_dgrad<fp32 MFMA>" : bn == 128 ? "k_conv_dgrad_split<128, 2>" : bn == 64 ? "k_conv_dgrad_split<64, 2>"
                                                                                                              : "k_conv_dgrad_split<32, 1>",
                       gemm_flops, st);
@@ -2340,6 +2343,7 @@ extern "C" int vcg_conv_dgrad(const float* dy, const float* wf, float* dx, const
       if (bn == 128) hipLaunchKernelGGL((k_conv_dgrad_split<128, 2>), grid, dim3(256), 0, st, p);
       else hipLaunchKernelGGL((k_conv_dgrad_split<64, 2>), grid, dim3(256), 0, st, p);
     } else if (bn == 32) hipLaunchKernelGGL((k_conv_dgrad_split<32, 1>), grid, dim3(256), 0, st, p);
+    else if (nopl64) hipLaunchKernelGGL((k_conv_dgrad_split<64, 2, false>), grid, dim3(256), 0, st, p);
     else DISPATCH_DGRAD(bm, bn, grid, st, p);
   }
   if (nsplit > 1)
