@@ -27,6 +27,18 @@ def test_library_builds_and_exports_every_declared_symbol(pkg):
     assert not missing, f"declared in vcg.h but not exported: {missing}"
 
 
+def test_no_c_symbol_is_exported_behind_the_headers_back(pkg):
+    """Every `vcg_*` function with C linkage in the library is declared in include/vcg.h (internal helpers keep C++ linkage;
+    diagnostic hooks are named here)."""
+    import subprocess
+    path = pkg._native.build()
+    out = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True).stdout
+    exported = sorted({ln.split()[-1] for ln in out.splitlines() if ln.split() and ln.split()[-1].startswith("vcg_")})
+    diagnostic = {"vcg_debug_set_stamp"}                                   # stamp hook of the -DVCG_STAMP diagnostic build (a no-op here)
+    extra = [s for s in exported if s not in header_symbols() and s not in diagnostic]
+    assert not extra, f"exported with C linkage but not declared in vcg.h: {extra}"
+
+
 def test_python_binding_covers_the_header(pkg):
     assert sorted(pkg._native.SIGNATURES) == header_symbols()
     lib = pkg._native.lib()
