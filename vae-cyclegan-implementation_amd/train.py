@@ -23,6 +23,7 @@ from datetime import datetime
 from pathlib import Path
 
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # RCCL across processes needs dmabuf IPC on this driver
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")        # kernel arguments in device memory: shorter dispatch gaps (package __init__)
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
