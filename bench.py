@@ -132,6 +132,8 @@ def main():
     if red is not None:
         red.exposed_ms()                       # drop the warm-up's events
         red.stats["buckets_from_backward"] = red.stats["buckets_at_start"] = 0
+        red.wait_log.clear()
+        red.log.clear()
     t0 = time.perf_counter()
     for i in range(args.steps):
         last = model.training_step(pool[i % len(pool)])
@@ -167,7 +169,16 @@ def main():
     if world > 1:
         st = red.stats
         out["exchange_exposed_ms"] = round(exposed_ms, 3)
+        # what the process group actually saw: the first SCALE record must show that RCCL ran over N ranks on N devices
+        devs = torch.tensor([float(torch.cuda.current_device())], dtype=torch.float64, device=dev)
+        dlist = [torch.zeros_like(devs) for _ in range(world)]
+        dist.all_gather(dlist, devs)
+        out["process_group"] = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "rank0_device_count": torch.cuda.device_count(),
+                                "device_of_rank": [int(t.item()) for t in dlist],
+                                "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY"),
+                                "VCG_BUCKET_MB": os.environ.get("VCG_BUCKET_MB", "64 (default)")}
         out["exchange"] = {"buckets_launched_from_inside_backward": st["buckets_from_backward"], "buckets_launched_after_backward": st["buckets_at_start"],
+                           "buckets_ordered_after_a_second_stream": sum(1 for _, _, w in red.wait_log if w),
                            "bucket_bytes": red.bucket_elems * 4, "is": "sum-all-reduce (RCCL) of contiguous slices of each optimizer's flat "
                            "gradient buffer, launched as their last weight gradient is issued; exchange_exposed_ms = time the compute stream "
                            "spent waiting for them before the optimizer steps, per step, max over ranks"}

@@ -432,6 +432,31 @@ def gen_steps_fp64(N, meta):
     meta[key] = ms
 
 
+def gen_dp_batch2(N, out, meta):
+    """SURVEY.md §8e's DDP parity fixture: the reference's CycleVAEGAN.training_step (Networks.py:1973-2078) on a batch of TWO
+    256 x 256 pairs — what a 2-rank x batch-1 data-parallel step must reproduce in its rank-averaged metrics and its
+    world-averaged gradients (tests/test_gpu_parity.py::test_two_rank_step_equals_the_big_batch_step).  Same parameters
+    ("dp." keys), images (synth.batch(2, 256, SEED, step=3)) and eps (step=3) as that test; fp32 and fp64 runs."""
+    torch.set_num_threads(8)
+    key = "dp"
+    x, y = synth.batch(2, 256, SEED, step=3)
+    eps = synth.eps_list(6, (2, 64, 16, 16), SEED, step=3)
+    for dt, tag in ((torch.float32, ""), (torch.float64, "_fp64")):
+        model = N.CycleVAEGAN(latent_dim=64, paired=False)
+        load_synth_params(model, SEED, 0.02, prefix=key + ".")
+        model = model.to(dt)
+        model.configure_optimizers(lr=LR)
+        model.configure_loss(**LAMBDAS)
+        model.train()
+        with EpsInjector([e.astype(np.float64 if dt == torch.float64 else np.float32) for e in eps]):
+            m = model.training_step({"x": torch.from_numpy(x).to(dt), "y": torch.from_numpy(y).to(dt)})
+        meta[key + tag] = [m]
+        for pn, p in model.named_parameters():
+            if p.grad is not None:
+                out[f"{key}@step1/{'gck64' if tag else 'gck'}.{pn}"] = checksum(p.grad)
+        print(key + tag, m)
+
+
 def gen_vae1024(N, out, meta):
     """BASELINE.json configs[2] is `vae` with latent_dim 1024 (the reference CLI cannot reach it; the class can: Networks.py:856).
     64x64, batch 2, ONE training step from synthetic parameters (fp32 + fp64 gradients) and the eval-mode validation
@@ -565,7 +590,7 @@ def main():
     atoms, steps, meta = {}, {}, {"seed": SEED, "lr": LR, "lambdas": LAMBDAS,
                                   "torch": torch.__version__, "reference": "Baverne/VAE-CYCLEGAN-Implementation"}
     which = sys.argv[1:] or ["atoms", "steps", "validation", "cycleaegan", "cycle_nogan", "double", "single_gan", "steps_fp64", "vae1024", "train_epoch",
-                                 "checkpoint"]
+                                 "dp_batch2", "checkpoint"]
     if "atoms" in which:
         gen_atoms(N, atoms)
         np.savez_compressed(os.path.join(HERE, "atoms.npz"), **atoms)
@@ -621,13 +646,19 @@ def main():
         np.savez_compressed(os.path.join(HERE, "train_epoch.npz"), **arr)
         with open(os.path.join(HERE, "train_epoch_meta.json"), "w") as f:
             json.dump(cmeta, f, indent=1)
+    if "dp_batch2" in which:
+        arr, cmeta = {}, {"seed": SEED, "lr": LR, "lambdas": LAMBDAS, "torch": torch.__version__, "batch": 2, "batch_step": 3}
+        gen_dp_batch2(N, arr, cmeta)
+        np.savez_compressed(os.path.join(HERE, "dp_batch2.npz"), **arr)
+        with open(os.path.join(HERE, "dp_batch2_meta.json"), "w") as f:
+            json.dump(cmeta, f, indent=1)
     if "checkpoint" in which:
         with open(os.path.join(HERE, "checkpoint_skeleton.json"), "w") as f:
             json.dump(gen_checkpoint_skeleton(N), f, indent=0)
     for fn in ("atoms.npz", "steps.npz", "steps_meta.json", "validation.npz", "validation_meta.json", "cycleaegan.npz",
                "cycleaegan_meta.json", "cycle_nogan.npz", "cycle_nogan_meta.json", "double.npz",
                "double_meta.json", "single_gan.npz", "single_gan_meta.json", "vae1024.npz", "vae1024_meta.json", "train_epoch.npz",
-               "train_epoch_meta.json", "checkpoint_skeleton.json"):
+               "train_epoch_meta.json", "dp_batch2.npz", "dp_batch2_meta.json", "checkpoint_skeleton.json"):
         p = os.path.join(HERE, fn)
         if os.path.exists(p):
             print(fn, os.path.getsize(p), "bytes")

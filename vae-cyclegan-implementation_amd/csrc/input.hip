@@ -11,10 +11,15 @@
 // Semantics (restated in oracle/input_oracle.py, which cites the published algorithms):
 //   k_input_resample   Pillow's convolution resize of the CROP (antialiased: the filter is stretched by max(scale, 1)),
 //                      BICUBIC (Keys a = -0.5, support 2) or BILINEAR, flips folded into the tap addresses, ToTensor's
-//                      1/255 at the end; floating point throughout (Pillow rounds to uint8 after each of its two passes);
-//   k_color_jitter     torchvision's tensor-path formulas: brightness / contrast / saturation as clamped blends, hue as an
-//                      HSV rotation, the four in the drawn order; contrast needs the image's mean grey -> one workgroup
-//                      per image, reduction in LDS.
+//                      1/255 at the end; floating point through both passes (Pillow rounds to uint8 after each of its two),
+//                      then — params[12] — rounded and clipped to the uint8 grid the reference's PIL image lives on;
+//   k_color_jitter     ColorJitter as the reference runs it, on a uint8 PIL image (train.py:316; torchvision's _functional_pil
+//                      path): brightness / contrast / saturation = PIL.ImageEnhance, i.e. Image.blend against black / the
+//                      rounded mean of the L image / the L image, in C float, truncated to uint8 after every op; hue = a
+//                      wrapping integer shift of H in Pillow's uint8 HSV conversion (Convert.c, restated with float where the C
+//                      has float and double where a double literal promotes); the four in the drawn order; contrast needs the
+//                      image's mean -> one workgroup per image, integer reduction in LDS.  Bit-exact against the oracle's
+//                      restatement, which is pinned on Pillow itself (tests/test_input_pipeline.py).
 //   hypersim's colour modality is jittered BEFORE the crop, on the whole image (Data_Manager.py:164-171: color_transform, then
 //   the shared spatial transform): k_u8_to_f4 unpacks the decoded image into a float4 buffer, k_color_jitter runs on it at
 //   full resolution (image sizes from `var`), and k_input_resample reads that buffer instead of the uint8 arena (params[11]).
@@ -25,10 +30,17 @@ struct ResampleP {
   const unsigned char* arena;
   const float4* fsrc;        // float4 image buffer for the samples with params[11] == 1 (offset = PIXEL index into it), or null
   const int32_t* params;     // [N][16]: arena offset lo, hi, H, W, box y0, x0, h, w (flipped-image coordinates), flip_h, flip_v, filter,
-                             //          source (0: uint8 RGB in the arena, offset in bytes; 1: float4 in fsrc, already in [0, 1])
+                             //          source (0: uint8 RGB in the arena, offset in bytes; 1: float4 in fsrc, already in [0, 1]),
+                             //          quantise (1: round + clip the result to the uint8 grid, as the PIL image the reference resizes)
   float* out;                // (N, S, S, 4), channel 3 = 0
   int N, S;
 };
+
+// a value in [0, 1] -> the uint8 level Pillow would store: floor(255 v + 0.5) clipped to 0..255 (as a float holding an integer)
+__device__ __forceinline__ float u8_of(float v) {
+  const float t = floorf(v * 255.f + 0.5f);
+  return t < 0.f ? 0.f : (t > 255.f ? 255.f : t);
+}
 
 __device__ __forceinline__ float filt_bicubic(float x) {
   const float a = -0.5f;
@@ -99,96 +111,123 @@ __global__ __launch_bounds__(256) void k_input_resample(ResampleP p) {
       r += wy * rr; g += wy * rg; b += wy * rb;
     }
     const float norm = 1.f / ((fl ? 1.f : 255.f) * (sx != 0.f ? sx : 1.f) * (sy != 0.f ? sy : 1.f));
-    *reinterpret_cast<float4*>(p.out + idx * 4) = make_float4(r * norm, g * norm, b * norm, 0.f);
+    float4 o = make_float4(r * norm, g * norm, b * norm, 0.f);
+    if (q[12] == 1) {                             // Pillow: clip8(value + 0.5); ToTensor: uint8 / 255
+      o.x = __fdiv_rn(u8_of(o.x), 255.f); o.y = __fdiv_rn(u8_of(o.y), 255.f); o.z = __fdiv_rn(u8_of(o.z), 255.f);
+    }
+    *reinterpret_cast<float4*>(p.out + idx * 4) = o;
   }
 }
 
-__device__ __forceinline__ float clamp01(float v) { return v < 0.f ? 0.f : (v > 1.f ? 1.f : v); }
-__device__ __forceinline__ float gray_of(const float4& v) { return 0.299f * v.x + 0.587f * v.y + 0.114f * v.z; }
-
-__device__ __forceinline__ float4 hue_shift(float4 v, float hue) {
-  // torchvision _rgb2hsv / _hsv2rgb
-  const float r = v.x, g = v.y, b = v.z;
-  const float maxc = fmaxf(r, fmaxf(g, b)), minc = fminf(r, fminf(g, b));
-  const bool eqc = maxc == minc;
-  const float cr = maxc - minc;
-  const float s = cr / (eqc ? 1.f : maxc);
-  const float crd = eqc ? 1.f : cr;
-  const float rc = (maxc - r) / crd, gc = (maxc - g) / crd, bc = (maxc - b) / crd;
-  const float hr = (maxc == r) ? (bc - gc) : 0.f;
-  const float hg = (maxc == g && maxc != r) ? (2.f + rc - bc) : 0.f;
-  const float hb = (maxc != g && maxc != r) ? (4.f + gc - rc) : 0.f;
-  float h = (hr + hg + hb) / 6.f + 1.f;
-  h = h - floorf(h);
-  h = h + hue;
-  h = h - floorf(h);
-  const float h6 = h * 6.f;
-  float fi = floorf(h6);
-  const float f = h6 - fi;
-  int i = ((int)fi) % 6;
-  if (i < 0) i += 6;
-  const float val = maxc;
-  const float pp = clamp01(val * (1.f - s)), qq = clamp01(val * (1.f - f * s)), tt = clamp01(val * (1.f - (1.f - f) * s));
-  float4 o = v;
-  switch (i) {
-    case 0: o.x = val; o.y = tt; o.z = pp; break;
-    case 1: o.x = qq; o.y = val; o.z = pp; break;
-    case 2: o.x = pp; o.y = val; o.z = tt; break;
-    case 3: o.x = pp; o.y = qq; o.z = val; break;
-    case 4: o.x = tt; o.y = pp; o.z = val; break;
-    default: o.x = val; o.y = pp; o.z = qq; break;
+// ---- PIL-path ColorJitter on integer levels 0..255 held in floats --------------------------------------------------------
+// Pillow RGB -> L
+__device__ __forceinline__ int pil_L(int r, int g, int b) { return (r * 19595 + g * 38470 + b * 7471 + 0x8000) >> 16; }
+// Image.blend(degenerate, image, alpha) for one channel: C float  t = in1 + alpha * (in2 - in1),  truncated; clipped when alpha
+// is outside [0, 1] (Blend.c).  __fmul_rn / __fadd_rn: no fused multiply-add, as the C compiled for plain x86-64.
+__device__ __forceinline__ int pil_blend1(int deg, int v, float alpha, bool interp) {
+  const float t = __fadd_rn((float)deg, __fmul_rn(alpha, (float)(v - deg)));
+  if (interp) return (int)t & 255;                               // (UINT8)(float): truncation (0 <= t <= 255 here)
+  return t <= 0.f ? 0 : (t >= 255.f ? 255 : (int)t);
+}
+// Pillow Convert.c rgb2hsv_row + torchvision's wrapping H shift + hsv2rgb
+__device__ __forceinline__ void pil_hue(int& r, int& g, int& b, int shift) {
+  const int maxc = max(r, max(g, b)), minc = min(r, min(g, b));
+  int uh = 0, us = 0;
+  const int uv = maxc;
+  if (minc != maxc) {
+    const float cr = (float)(maxc - minc);
+    const float s = cr / (float)maxc;
+    const float rc = (float)(maxc - r) / cr, gc = (float)(maxc - g) / cr, bc = (float)(maxc - b) / cr;
+    float h;
+    if (r == maxc) h = bc - gc;
+    else if (g == maxc) h = (float)(2.0 + (double)rc - (double)bc);
+    else h = (float)(4.0 + (double)gc - (double)rc);
+    h = (float)fmod((double)h / 6.0 + 1.0, 1.0);
+    uh = (int)((double)h * 255.0); uh = uh < 0 ? 0 : (uh > 255 ? 255 : uh);
+    us = (int)((double)s * 255.0); us = us < 0 ? 0 : (us > 255 ? 255 : us);
   }
-  return o;
+  uh = (uh + shift) & 255;
+  if (us == 0) { r = g = b = uv; return; }
+  const double h6 = (double)uh * 6.0 / 255.0;
+  const int i = (int)floor(h6);
+  const float f = (float)(h6 - (double)(float)i);
+  const float fs = (float)((double)us / 255.0);
+  const double v = (double)uv;
+  int p = (int)floor(v * (1.0 - (double)fs) + 0.5);
+  int q = (int)floor(v * (1.0 - (double)__fmul_rn(fs, f)) + 0.5);
+  int t = (int)floor(v * (1.0 - (double)fs * (1.0 - (double)f)) + 0.5);
+  p = p < 0 ? 0 : (p > 255 ? 255 : p); q = q < 0 ? 0 : (q > 255 ? 255 : q); t = t < 0 ? 0 : (t > 255 ? 255 : t);
+  switch (i % 6) {
+    case 0: r = uv; g = t; b = p; break;
+    case 1: r = q; g = uv; b = p; break;
+    case 2: r = p; g = uv; b = t; break;
+    case 3: r = p; g = q; b = uv; break;
+    case 4: r = t; g = p; b = uv; break;
+    default: r = uv; g = p; b = q; break;
+  }
 }
 
 // one workgroup per image; jitter[n][8] = enabled, brightness, contrast, saturation, hue, order code (o0 + 4 o1 + 16 o2 + 64 o3).
-// var == null: N images of S x S pixels back to back; else var[n][4] = pixel offset lo, hi, pixel count (whole decoded frames)
+// var == null: N images of S x S pixels back to back; else var[n][4] = pixel offset lo, hi, pixel count (whole decoded frames).
+// Pixels come in and go out as floats in [0, 1]; inside they are the uint8 levels of the PIL image the reference jitters.
 __global__ __launch_bounds__(1024) void k_color_jitter(float* __restrict__ img, const float* __restrict__ jitter, int S,
                                                        const int32_t* __restrict__ var) {
-  __shared__ double red[1024];
-  __shared__ float mean_s;
+  __shared__ unsigned long long red[1024];
+  __shared__ int mean_s;
   const int n = blockIdx.x, tid = threadIdx.x;
   const float* j = jitter + (size_t)n * 8;
   if (j[0] == 0.f) return;                                       // uniform per workgroup
   const float fb = j[1], fc = j[2], fs = j[3], fhue = j[4];
   const int code = (int)j[5];
+  const int shift = (int)(fhue * 255.0) & 255;                   // np.uint8(hue_factor * 255): truncation toward zero, wrapping
   float4* px = reinterpret_cast<float4*>(img) + (var ? (((size_t)(uint32_t)var[n * 4 + 1]) << 32 | (size_t)(uint32_t)var[n * 4]) : (size_t)n * S * S);
   const int npx = var ? var[n * 4 + 2] : S * S;
-  for (int i = tid; i < npx; i += 1024) {                        // a uint8 PIL image: the resize's overshoot was clipped
+  for (int i = tid; i < npx; i += 1024) {                        // onto the uint8 grid (a no-op for levels that are already on it)
     float4 v = px[i];
-    v.x = clamp01(v.x); v.y = clamp01(v.y); v.z = clamp01(v.z);
+    v.x = u8_of(v.x); v.y = u8_of(v.y); v.z = u8_of(v.z);
     px[i] = v;
   }
   for (int k = 0; k < 4; ++k) {
     const int op = (code >> (2 * k)) & 3;
-    if (op == 1) {                                               // contrast: blend with the mean grey of the CURRENT image
+    if (op == 1) {                                               // contrast: the degenerate image is int(mean(L) + 0.5) of the CURRENT image
       __syncthreads();
-      double s = 0.0;
-      for (int i = tid; i < npx; i += 1024) s += (double)gray_of(px[i]);
+      unsigned long long s = 0;
+      for (int i = tid; i < npx; i += 1024) {
+        const float4 v = px[i];
+        s += (unsigned long long)pil_L((int)v.x, (int)v.y, (int)v.z);
+      }
       red[tid] = s;
       __syncthreads();
       for (int o = 512; o > 0; o >>= 1) {
         if (tid < o) red[tid] += red[tid + o];
         __syncthreads();
       }
-      if (tid == 0) mean_s = (float)(red[0] / npx);
+      if (tid == 0) mean_s = (int)((double)red[0] / (double)npx + 0.5);
       __syncthreads();
     }
-    const float m = mean_s;
+    const int m = mean_s;
+    const float alpha = op == 0 ? fb : (op == 1 ? fc : fs);
+    const bool interp = alpha >= 0.f && alpha <= 1.f;
     for (int i = tid; i < npx; i += 1024) {
-      float4 v = px[i];
+      const float4 v = px[i];
+      int r = (int)v.x, g = (int)v.y, b = (int)v.z;
       if (op == 0) {
-        v.x = clamp01(fb * v.x); v.y = clamp01(fb * v.y); v.z = clamp01(fb * v.z);
+        r = pil_blend1(0, r, alpha, interp); g = pil_blend1(0, g, alpha, interp); b = pil_blend1(0, b, alpha, interp);
       } else if (op == 1) {
-        v.x = clamp01(fc * v.x + (1.f - fc) * m); v.y = clamp01(fc * v.y + (1.f - fc) * m); v.z = clamp01(fc * v.z + (1.f - fc) * m);
+        r = pil_blend1(m, r, alpha, interp); g = pil_blend1(m, g, alpha, interp); b = pil_blend1(m, b, alpha, interp);
       } else if (op == 2) {
-        const float gr = gray_of(v);
-        v.x = clamp01(fs * v.x + (1.f - fs) * gr); v.y = clamp01(fs * v.y + (1.f - fs) * gr); v.z = clamp01(fs * v.z + (1.f - fs) * gr);
+        const int L = pil_L(r, g, b);
+        r = pil_blend1(L, r, alpha, interp); g = pil_blend1(L, g, alpha, interp); b = pil_blend1(L, b, alpha, interp);
       } else {
-        v = hue_shift(v, fhue);
+        pil_hue(r, g, b, shift);
       }
-      px[i] = v;
+      px[i] = make_float4((float)r, (float)g, (float)b, 0.f);
     }
+  }
+  for (int i = tid; i < npx; i += 1024) {                        // ToTensor: uint8 / 255
+    float4 v = px[i];
+    v.x = __fdiv_rn(v.x, 255.f); v.y = __fdiv_rn(v.y, 255.f); v.z = __fdiv_rn(v.z, 255.f);
+    px[i] = v;
   }
 }
 

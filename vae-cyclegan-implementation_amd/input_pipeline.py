@@ -4,8 +4,9 @@ Replaces the reference's `Data_Manager.py` datasets + torchvision transform pipe
 (/root/reference/train.py:174-357, Data_Manager.py:327-451) for the training loop's input side.
 The reference decodes, flips, crops, resamples (bicubic), colour-jitters and converts every sample on the host with PIL;
 here the host only DECODES (PIL, a thread pool) and DRAWS the random parameters; the pixels are uploaded as uint8 — a
-quarter of the fp32 bytes — into a pinned staging arena, and flips + RandomResizedCrop + bicubic resampling + ColorJitter +
-ToTensor run as two HIP kernels (`csrc/input.hip`) on a side stream, one batch ahead of the step that consumes them
+quarter of the fp32 bytes — into a pinned staging arena, and flips + RandomResizedCrop + bicubic resampling (rounded to the
+uint8 grid of the PIL image the reference resizes) + ColorJitter (torchvision's PIL path: ImageEnhance blends and the uint8
+HSV hue shift, bit-exact against a restatement pinned on Pillow) + ToTensor run as two HIP kernels (`csrc/input.hip`) on a side stream, one batch ahead of the step that consumes them
 (double-buffered: batch k+1 is uploaded and transformed while step k trains).
 
 The random draws follow torchvision's published algorithms (RandomResizedCrop.get_params, ColorJitter.get_params, the flip
@@ -18,7 +19,6 @@ torchvision itself is absent from this image and the reference seeds nothing (it
 """
 import ctypes
 import os
-import threading
 from concurrent.futures import ThreadPoolExecutor
 
 import numpy as np
@@ -31,8 +31,15 @@ RECIPES = {
     "summer2winter": dict(hflip=0.5, vflip=0.0, scale=(0.33, 1.0), jitter=(0.2, 0.2, 0.2, 0.1), shared_draw=False),
     "maps": dict(hflip=0.5, vflip=0.0, scale=(0.33, 1.0), jitter=None, shared_draw=True),       # same RNG state for both halves
     # hypersim: both modalities of a sample go through the SAME random state (Data_Manager.py:160-165), the `color` modality is
-    # colour-jittered first, on the whole frame, then flipped / cropped / resized like the others (:169-174)
-    "hypersim": dict(hflip=0.5, vflip=0.3, scale=(0.33, 1.0), jitter=None, pre_jitter=(0.3, 0.3, 0.3, 0.15), shared_draw=True),
+    # colour-jittered first, on the whole frame, then flipped / cropped / resized like the others (:169-174).
+    # AS WRITTEN, that replay of the RNG state does not give `color` the other modality's geometry: its ColorJitter consumes
+    # draws (randperm(4) + four uniforms) BEFORE the flips and the crop are drawn, so those come from further down the
+    # stream — a `color` <-> `depth` pair is flipped and cropped independently (an x / y misalignment in the reference's
+    # paired hypersim training whenever one modality is `color`).  This build reproduces the reference as written
+    # (`color_shares_geometry=False`: an independent geometry draw for the colour modality), like its other quirks (VAEGAN's
+    # detach); VCG_HYPERSIM_ALIGNED=1 gives both modalities one geometry instead.
+    "hypersim": dict(hflip=0.5, vflip=0.3, scale=(0.33, 1.0), jitter=None, pre_jitter=(0.3, 0.3, 0.3, 0.15), shared_draw=True,
+                     color_shares_geometry=os.environ.get("VCG_HYPERSIM_ALIGNED", "0") == "1"),
     "test": dict(hflip=0.0, vflip=0.0, scale=None, jitter=None, shared_draw=False, bilinear=True),   # Resize((S, S)) + ToTensor
 }
 
@@ -63,6 +70,7 @@ def draw_sample(rng, height, width, recipe):
     else:
         g[4:8] = (0, 0, height, width)
     g[10] = 1 if recipe.get("bilinear") else 0
+    g[12] = 1                                  # onto the uint8 grid: the reference resizes a PIL image (train.py:309-319)
     if recipe.get("jitter"):
         j = draw_jitter(rng, recipe["jitter"])
     return g, j
@@ -227,13 +235,19 @@ class DeviceInputPipeline:
     on the event recorded behind those kernels."""
 
     def __init__(self, source, batch_size, image_size, device, recipe="summer2winter", shuffle=True, drop_last=False, seed=0,
-                 num_workers=4, same_xy=False, arena_bytes=None):
+                 num_workers=4, same_xy=False, arena_bytes=None, rank=0, world=1):
+        """`rank` / `world`: data parallelism — every rank draws the SAME per-epoch permutation (from `seed`, which must then
+        be equal on all ranks) and takes every world-th sample of it, truncated to equal length, so an epoch passes over the
+        data once and no sample appears twice in a global batch; the augmentation draws come from a per-rank stream."""
         self.src, self.b, self.s, self.dev = source, batch_size, image_size, device
         self.recipe = RECIPES[recipe] if isinstance(recipe, str) else recipe
         self.shuffle, self.drop_last, self.same_xy = shuffle, drop_last, same_xy
-        self.rng = np.random.RandomState(seed)
+        self.rank, self.world = int(rank), max(1, int(world))
+        self.order_rng = np.random.RandomState(seed)                     # the permutation: identical on every rank
+        self.rng = np.random.RandomState((seed * 64 + self.rank) % (2 ** 31 - 1)) if self.world > 1 else self.order_rng
         self.pool = ThreadPoolExecutor(max_workers=max(1, num_workers))
-        n = len(source)
+        self.prep = ThreadPoolExecutor(max_workers=1)                     # runs _prepare one batch ahead; its Future carries exceptions
+        n = len(source) // self.world
         self.nbatches = n // batch_size if drop_last else (n + batch_size - 1) // batch_size
         self.arena_bytes = arena_bytes or max(2 * batch_size * 1024 * 1024 * 3, 1 << 22)   # grown on demand
         self.slots = [self._make_slot() for _ in range(2)]
@@ -262,7 +276,14 @@ class DeviceInputPipeline:
 
     def _prepare(self, slot, indices):
         """decode (pool) + draw + pack into the pinned arena, then enqueue upload and kernels on the side stream"""
-        pairs = list(self.pool.map(lambda i: self.src.pair(i, np.random.RandomState(self.rng.randint(0, 2 ** 31 - 1))), indices))
+        with torch.cuda.device(self.dev):          # a fresh thread's current device is 0: pin / allocate on THIS rank's device
+            self._prepare_on_device(slot, indices)
+
+    def _prepare_on_device(self, slot, indices):
+        # the per-sample seeds (the unpaired y draws) are drawn HERE, in index order, not inside the pool's worker threads:
+        # their completion order is not deterministic and the run would not be reproducible for a given seed
+        seeds = [int(self.rng.randint(0, 2 ** 31 - 1)) for _ in indices]
+        pairs = list(self.pool.map(lambda a: self.src.pair(a[0], np.random.RandomState(a[1])), zip(indices, seeds)))
         imgs = [p[0] for p in pairs] + [p[1] for p in pairs]       # first the x images, then the y images
         need = sum(im.size for im in imgs)
         if need > slot["pin"].numel():                             # a batch of larger images than any before: grow both sides
@@ -272,9 +293,12 @@ class DeviceInputPipeline:
             slot["arena"] = torch.empty(cap, dtype=torch.uint8, device=self.dev)
         nb = len(pairs)
         geo, jit = np.zeros((2 * nb, 16), np.int32), np.zeros((2 * nb, 8), np.float32)
+        # hypersim as written: exactly one `color` modality breaks the shared geometry (RECIPES["hypersim"])
+        col = getattr(self.src, "pre_jitter", (False, False)) if self.recipe.get("pre_jitter") else (False, False)
+        shared = self.recipe.get("shared_draw") and (col[0] == col[1] or self.recipe.get("color_shares_geometry", True))
         for k in range(nb):
             gx, jx = draw_sample(self.rng, imgs[k].shape[0], imgs[k].shape[1], self.recipe)
-            if self.recipe.get("shared_draw") and getattr(self.src, "paired", True) and imgs[nb + k].shape == imgs[k].shape:
+            if shared and getattr(self.src, "paired", True) and imgs[nb + k].shape == imgs[k].shape:
                 gy, jy = gx.copy(), jx.copy()                      # maps: the same RNG state transforms both halves
             else:
                 gy, jy = draw_sample(self.rng, imgs[nb + k].shape[0], imgs[nb + k].shape[1], self.recipe)
@@ -337,18 +361,20 @@ class DeviceInputPipeline:
 
     def __iter__(self):
         n = len(self.src)
-        order = self.rng.permutation(n) if self.shuffle else np.arange(n)
+        order = self.order_rng.permutation(n) if self.shuffle else np.arange(n)
+        if self.world > 1:                                         # this rank's shard: every world-th sample, equal length on all ranks
+            order = order[:n - n % self.world][self.rank::self.world]
         batches = [order[i * self.b:(i + 1) * self.b] for i in range(self.nbatches)]
         if not batches:
             return
-        pending = threading.Thread(target=self._prepare, args=(self.slots[0], batches[0]))
-        pending.start()
+        pending = self.prep.submit(self._prepare, self.slots[0], batches[0])
         for k in range(len(batches)):
-            pending.join()
+            # .result() re-raises whatever _prepare raised (a truncated file, a failed vcg_input_* call, an allocation error):
+            # a bare thread would die silently and this loop would hand out the slot's previous batch
+            pending.result()
             slot = self.slots[k % 2]
             if k + 1 < len(batches):                               # batch k+1 is prepared while the caller trains on batch k
-                pending = threading.Thread(target=self._prepare, args=(self.slots[(k + 1) % 2], batches[k + 1]))
-                pending.start()
+                pending = self.prep.submit(self._prepare, self.slots[(k + 1) % 2], batches[k + 1])
             cur = torch.cuda.current_stream(self.dev)
             cur.wait_event(slot["event"])
             nb = slot["n"]

@@ -433,8 +433,10 @@ class _ConvBlockFn(torch.autograd.Function):
             dt = gp
         wparam, bparam = ctx.wparam, ctx.bparam
         saved = ctx.saved_state
-        ctx.saved_state = None                                        # one backward per forward: hand the 4x buffer back early
         if wparam is not None and wparam.requires_grad and id(wparam) not in _NO_WGRAD:
+            # hand the 4x buffer back once the weight gradient has consumed it — not on a traversal that skips the weight
+            # gradient (`no_wgrad`: the G phase through a discriminator), whose retained graph is differentiated again
+            ctx.saved_state = None
             gw = _grad_buffer(wparam)
             gb = _grad_buffer(bparam) if (bparam is not None and bparam.requires_grad) else None
             if spec.norm and spec.epi_act == ACT_NONE:
@@ -517,6 +519,18 @@ def manual_seed(seed):
     """Seed of the on-device Philox stream that draws eps (replaces torch.randn_like, Networks.py:225)."""
     _RNG["seed"] = int(seed) & 0xFFFFFFFFFFFFFFFF
     _RNG["offset"] = 0
+
+
+RANK_SEED_STRIDE = 7919
+
+
+def rank_seed(base, rank):
+    """Seed of rank `rank`'s eps stream in a data-parallel job whose base seed is `base` (train.py, utils.load_checkpoint)."""
+    return (int(base) + RANK_SEED_STRIDE * (int(rank) + 1)) & 0xFFFFFFFFFFFFFFFF
+
+
+def base_seed_of(seed, rank):
+    return (int(seed) - RANK_SEED_STRIDE * (int(rank) + 1)) & 0xFFFFFFFFFFFFFFFF
 
 
 def inject_eps(tensors):

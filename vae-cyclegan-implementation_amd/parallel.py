@@ -14,9 +14,11 @@ buckets that are launched FROM INSIDE the backward pass as they complete:
     step, the shared encoder of the Double models too); from the second step on a bucket is all-reduced the moment
     its last report arrives — F's gradients while G(x) is still being differentiated, G's decoder while its encoder
     is — and only the tail of the exchange is left for the discriminator backward to hide;
-  * the collective is ordered after the stream the weight gradients ran on (the side stream when
-    `ops.wgrad_overlap` is on): it is launched with that stream current, so RCCL's stream waits for exactly those
-    kernels and the data-gradient chain on the main stream is never blocked;
+  * the collective is ordered after EVERY stream that reported a gradient of the bucket (the side stream of
+    `ops.wgrad_overlap`, and the main stream for the full-map layer that ends a discriminator): it is launched with the
+    last reporter's stream current after that stream has been made to wait for the others (`_order_after`), so RCCL's
+    stream waits for exactly the kernels that wrote the slice and the data-gradient chain on the main stream is never
+    blocked;
   * the 1/world scaling is folded into the fused Adam launch (`grad_scale`): no extra pass over the gradients;
   * gradients the generator phase deposits on the discriminators as a by-product are never produced here
     (`ops.no_wgrad`), so nothing spurious is reduced.
@@ -25,8 +27,15 @@ xGMI is point-to-point (7 links x ~153 GB/s per GPU): buckets are large (default
 keep all links busy.  `stats` accumulates what the step still waits for (HIP events around `finish`): bench.py prints it
 as `exchange_exposed_ms` for N > 1.
 """
+import os
+
 import torch
 import torch.distributed as dist
+
+
+def default_bucket_bytes():
+    """VCG_BUCKET_MB: size at which a gradient bucket closes (default 64 MiB; xGMI is point-to-point, few large collectives)."""
+    return max(1, int(float(os.environ.get("VCG_BUCKET_MB", "64")) * (1 << 20)))
 
 
 class _Plan:
@@ -54,19 +63,21 @@ class _Plan:
         self.learning = {}
         self.remaining = None                    # per bucket: reports still to come in this backward
         self.launched = set()
+        self.streams = [[] for _ in self.buckets]  # per bucket: the distinct streams that reported into it in this backward
 
 
 class GradReducer:
-    def __init__(self, group=None, bucket_bytes=64 << 20):
+    def __init__(self, group=None, bucket_bytes=None):
         if not dist.is_initialized():
             raise RuntimeError("torch.distributed is not initialised")
         self.group = group
         self.world = dist.get_world_size(group)
-        self.bucket_elems = max(1, bucket_bytes // 4)
+        self.bucket_elems = max(1, (bucket_bytes if bucket_bytes is not None else default_bucket_bytes()) // 4)
         self._plans = {}
         self._pending = {}
         self._armed = None                       # the optimizer whose backward is running
         self.log = []                            # (tag, bucket, lo, hi, "backward" | "start") in launch order
+        self.wait_log = []                       # (bucket, launch stream, [other producer streams it was made to wait for])
         self.stats = {"exposed_ms_events": [], "buckets_from_backward": 0, "buckets_at_start": 0}
 
     def _plan(self, optimizer):
@@ -85,6 +96,7 @@ class GradReducer:
         pl = self._plan(optimizer)
         pl.launched = set()
         pl.learning = {}
+        pl.streams = [[] for _ in pl.buckets]
         if pl.expected is not None:
             pl.remaining = [0] * len(pl.buckets)
             pl.left = dict(pl.expected)
@@ -116,6 +128,8 @@ class GradReducer:
                                    "(this backward uses a parameter more often than the first one did)")
             pl.left[pid] -= 1
             pl.remaining[b] -= 1
+            if stream is not None and not any(s is stream or s == stream for s in pl.streams[b]):
+                pl.streams[b].append(stream)
             if pl.remaining[b] == 0:
                 self._launch(opt, pl, b, stream, "backward")
 
@@ -135,11 +149,24 @@ class GradReducer:
             if b not in pl.launched:
                 self._launch(optimizer, pl, b, None, "start")
 
+    def _order_after(self, b, stream, others, is_cuda):
+        """Make `stream` (the last reporter, on which the collective is launched) wait for every OTHER stream that wrote into
+        bucket b during this backward.  The last reporter's stream alone is not enough: a discriminator's full-map layer
+        reports from the main stream while its conv layers report from the side stream, and a bucket whose last report came
+        from the main stream would otherwise be reduced while the side stream is still accumulating into it."""
+        waited = [s for s in others if not (s is stream or s == stream)]
+        if is_cuda:
+            for s in waited:
+                stream.wait_stream(s)
+        self.wait_log.append((b, stream, waited))
+
     def _launch(self, optimizer, pl, b, stream, where):
         lo, hi = pl.buckets[b]
         flat = optimizer.flat_grad
+        if stream is not None:
+            self._order_after(b, stream, pl.streams[b], flat.is_cuda)
         if stream is not None and flat.is_cuda:
-            with torch.cuda.stream(stream):      # RCCL orders itself after the CURRENT stream: the one the weight gradients ran on
+            with torch.cuda.stream(stream):      # RCCL orders itself after the CURRENT stream, which now follows every producer
                 work = dist.all_reduce(flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         else:
             if flat.is_cuda:
@@ -208,7 +235,7 @@ def broadcast_parameters(model, src=0, group=None):
             ep[0] += 1
 
 
-def attach(model, group=None, bucket_bytes=64 << 20):
+def attach(model, group=None, bucket_bytes=None):
     """Give `model.training_step` a gradient exchange; returns the reducer."""
     from . import ops
     red = GradReducer(group, bucket_bytes)

@@ -162,7 +162,14 @@ def validate(model, dataloader, device, args):
                 loss_components[key] = loss_components.get(key, 0.0) + value
             last_Gx, last_Fy, last_x, last_y = Gx, Fy, batch["x"], batch["y"]
     n = len(dataloader)
-    return total_loss / n, {k: v / n for k, v in loss_components.items()}, last_Gx, last_Fy, last_x, last_y
+    avg_loss, avg = total_loss / n, {k: v / n for k, v in loss_components.items()}
+    red = getattr(model, "grad_reducer", None)
+    if red is not None:                               # data parallel: each rank validated its shard of the test set
+        keys = sorted(avg)
+        vec = torch.tensor([avg_loss] + [avg[k] for k in keys], dtype=torch.float32, device=device)
+        vec = red.average_metrics(vec).tolist()
+        avg_loss, avg = vec[0], dict(zip(keys, vec[1:]))
+    return avg_loss, avg, last_Gx, last_Fy, last_x, last_y
 
 
 def build_parser():
@@ -203,7 +210,9 @@ def build_parser():
 def create_dataloaders(args, device, rank, world, epoch_seed):
     """reference train.py:174-357 (create_dataloaders_hypersim / _maps / _summer2winter) on the device-side input pipeline:
     PIL decodes, the MI355X flips, crops, resamples, jitters and converts (input_pipeline.py), from the reference's directory
-    layouts (hypersim: the PNG scene tree Data_Manager.py:18-138 reads; its download / HDF5 conversion is out of scope)."""
+    layouts (hypersim: the PNG scene tree Data_Manager.py:18-138 reads; its download / HDF5 conversion is out of scope).
+    Under data parallelism every rank gets the same `epoch_seed` and takes its shard of the shared per-epoch permutation
+    (train and test sets alike): one epoch is one pass over the data, and `validate` averages the metrics over ranks."""
     if args.dataset == "hypersim":
         # reference train.py:174-239: one HypersimDataset with the TRAINING transforms, random_split into train / test
         mods = [m for m in (args.source_modality, args.target_modality) if m]
@@ -212,16 +221,16 @@ def create_dataloaders(args, device, rank, world, epoch_seed):
         if not mods:
             raise ValueError("--dataset hypersim needs --source_modality (and --target_modality)")
         full = input_pipeline.HypersimFolders(os.path.join(args.data_dir, "hypersim"), mods, paired=args.paired or len(mods) == 1)
-        kw = dict(num_workers=max(1, args.num_workers), same_xy=len(mods) == 1)
+        kw = dict(num_workers=max(1, args.num_workers), same_xy=len(mods) == 1, rank=rank, world=world)
         order = np.random.RandomState(args.seed).permutation(len(full))
         ntrain = int((1 - args.test_split) * len(full)) if args.test_split > 0 else len(full)
         print(f"Training samples: {ntrain}" + (f", Testing samples: {len(full) - ntrain}" if args.test_split > 0 else ""))
         train = input_pipeline.DeviceInputPipeline(full.subset(order[:ntrain]), args.batch_size, args.image_size, device,
-                                                   recipe="hypersim", shuffle=True, seed=epoch_seed * 64 + rank, **kw)
+                                                   recipe="hypersim", shuffle=True, seed=epoch_seed, **kw)
         test = None
         if args.test_split > 0 and ntrain < len(full):
             test = input_pipeline.DeviceInputPipeline(full.subset(order[ntrain:]), args.batch_size, args.image_size, device,
-                                                      recipe="hypersim", shuffle=False, seed=epoch_seed * 64 + rank, **kw)
+                                                      recipe="hypersim", shuffle=False, seed=epoch_seed, **kw)
         return train, test
     root = os.path.join(args.data_dir, args.dataset)
     same_xy = args.architecture in ("autoencoder", "vae")
@@ -229,16 +238,34 @@ def create_dataloaders(args, device, rank, world, epoch_seed):
     train_src = input_pipeline.FolderPairs(root, args.dataset, "train")
     test_src = input_pipeline.FolderPairs(root, args.dataset, test_split)
     print(f"Training samples: {len(train_src)}\nTesting samples: {len(test_src)}")
-    kw = dict(num_workers=max(1, args.num_workers), same_xy=same_xy)
+    kw = dict(num_workers=max(1, args.num_workers), same_xy=same_xy, rank=rank, world=world)
     train = input_pipeline.DeviceInputPipeline(train_src, args.batch_size, args.image_size, device, recipe=args.dataset, shuffle=True,
-                                               seed=epoch_seed * 64 + rank, **kw)
+                                               seed=epoch_seed, **kw)
     test = input_pipeline.DeviceInputPipeline(test_src, args.batch_size, args.image_size, device, recipe="test", shuffle=False,
-                                              seed=epoch_seed * 64 + rank, **kw)
+                                              seed=epoch_seed, **kw)
     return train, test
+
+
+DATASET_MODALITY_DEFAULTS = {                        # reference train.py:367-377
+    "hypersim": ("depth", "normal"),
+    "summer2winter": ("summer", "winter"),
+    "maps": ("satellite", "map"),
+    "synthetic": ("synthetic", "synthetic"),
+}
 
 
 def main(args):
     args.architecture = ALIASES.get(args.architecture, args.architecture)
+    # reference train.py:362-377, in its order: the autoencoder / VAE check sees the modalities as given, THEN the
+    # per-dataset defaults fill in what was not given (they name the run directory and select hypersim's frames)
+    if args.architecture in ("autoencoder", "vae"):
+        if args.source_modality != args.target_modality:
+            raise ValueError("Source and target modalities should be the same for Autoencoder/VAE architectures.")
+    default_source, default_target = DATASET_MODALITY_DEFAULTS[args.dataset]
+    if args.source_modality is None:
+        args.source_modality = default_source
+    if args.target_modality is None:
+        args.target_modality = default_target
     if args.dataset in ("summer2winter",):
         args.paired = False                          # reference train.py:380-382: unpaired data forces the unpaired objectives
     if args.no_cuda or not torch.cuda.is_available():
@@ -253,9 +280,6 @@ def main(args):
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=device)
-    if args.architecture in ("autoencoder", "vae"):
-        if args.source_modality != args.target_modality:
-            raise ValueError("Source and target modalities should be the same for Autoencoder/VAE architectures.")
 
     # reference train.py:395-411: a resumed run continues in its checkpoint's directory, a new one gets
     # <architecture>_<timestamp>_<source>_to_<target>_<dataset> and writes its args.json there
@@ -275,7 +299,7 @@ def main(args):
             print(f"Using device: {device}  world size {world}\nOutput directory: {output_dir}")
 
     torch.manual_seed(args.seed)                     # identical replicas
-    ops.manual_seed(args.seed + 7919 * (rank + 1))   # per-rank eps stream
+    ops.manual_seed(ops.rank_seed(args.seed, rank))  # per-rank eps stream
     model = create_model(args.architecture, paired=args.paired, latent_dim=args.latent_dim).to(device)
     model.configure_optimizers(lr=args.lr)
     model.configure_loss(lambda_kl=args.lambda_kl, lambda_gan=args.lambda_gan, lambda_identity=args.lambda_identity,
@@ -321,7 +345,8 @@ def main(args):
             for k, v in comps.items():
                 print(f"  {k}: {v:.6f}")
         # on the test set (reference train.py:533-537: every log_image_freq epochs); here a held-out synthetic stream.
-        # validation_step has no exchange in it: every rank validates its own shard, rank 0 prints its numbers
+        # validation_step has no exchange in it: every rank validates its shard of the test set and `validate` averages
+        # the metrics over ranks
         if args.log_image_freq > 0 and epoch % args.log_image_freq == 0 and not (image_loaders and image_loaders[1] is None):
             test_loader = image_loaders[1] if image_loaders else SyntheticLoader(
                 args.batch_size, args.image_size, max(1, args.steps_per_epoch // 10), device, args.seed + 1, rank, same_xy, epoch)

@@ -18,19 +18,37 @@ from . import ops
 LAST_EXTRAS = {}
 
 
+def _rank():
+    """Rank of this process in the data-parallel job (0 when single-process)."""
+    try:
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            return dist.get_rank()
+    except Exception:
+        pass
+    return int(os.environ.get("RANK", "0"))
+
+
 def save_checkpoint(model, epoch, loss, args, filename, best_test_loss=None):
     """reference utils.py:17-28.  Tensors are written from the CPU so the file loads on a machine without a GPU
     (the reference's own loader passes map_location anyway).  Two keys are ADDED to the reference's five (its loader
     reads the ones it knows and ignores the rest): the position of the on-device eps stream (`vcg_eps_rng`) so that a
     resumed run draws the eps it would have drawn, and the best test loss so far (`vcg_best_test_loss`) so that a
-    resumed run does not overwrite best_model.pth with a worse model."""
+    resumed run does not overwrite best_model.pth with a worse model.
+
+    Under data parallelism one rank writes the file but every rank draws from its OWN eps stream
+    (`ops.rank_seed(base, rank)`): what is saved is the BASE seed (the writer's seed with its rank offset taken out) and
+    the stream offset, which is the same on all ranks (they run identical steps); `load_checkpoint` re-derives each
+    rank's seed from the base."""
+    rank = _rank()
+    seed = int(ops._RNG["seed"])
     checkpoint = {
         "epoch": epoch,
         "model_state_dict": {k: v.detach().cpu() for k, v in model.state_dict().items()},
         "optimizer_states": _to_cpu(model.save_optimizer_states()),
         "loss": loss,
         "args": vars(args),
-        "vcg_eps_rng": {"seed": int(ops._RNG["seed"]), "offset": int(ops._RNG["offset"])},
+        "vcg_eps_rng": {"seed": seed, "offset": int(ops._RNG["offset"]), "base_seed": ops.base_seed_of(seed, rank), "rank": rank},
     }
     if best_test_loss is not None:
         checkpoint["vcg_best_test_loss"] = float(best_test_loss)
@@ -54,8 +72,13 @@ def load_checkpoint(model, filename, device):
         model.load_optimizer_states(checkpoint["optimizer_states"])
     LAST_EXTRAS.clear()
     if "vcg_eps_rng" in checkpoint:                      # ours: continue the eps stream where the saved run stood
-        ops._RNG["seed"] = int(checkpoint["vcg_eps_rng"]["seed"])
-        ops._RNG["offset"] = int(checkpoint["vcg_eps_rng"]["offset"])
+        rng = checkpoint["vcg_eps_rng"]
+        # every rank continues ITS stream: re-derive the per-rank seed from the base (a round-2 file has no base_seed: it
+        # was written by rank 0, whose seed is rank_seed(base, 0)); loading the writer's seed on every rank would make all
+        # ranks draw the same eps for their shards
+        base = int(rng["base_seed"]) if "base_seed" in rng else ops.base_seed_of(int(rng["seed"]), 0)
+        ops._RNG["seed"] = ops.rank_seed(base, _rank())
+        ops._RNG["offset"] = int(rng["offset"])
     if "vcg_best_test_loss" in checkpoint:
         LAST_EXTRAS["best_test_loss"] = float(checkpoint["vcg_best_test_loss"])
     ops.PARAM_EPOCH[0] += 1                              # load_state_dict wrote through .data: drop every weight pack
