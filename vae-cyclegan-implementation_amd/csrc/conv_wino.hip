@@ -14,6 +14,21 @@
 #include <stdlib.h>
 
 int vcg_gemm_split_batched(const float* A, const void* BtPlanes, float* C, int rows, int K, int N, int batches, hipStream_t st);
+// gemm_ws.hip: the 16 GEMMs with the input transform B^T d B computed by the kernel's producer waves (V never written)
+bool vcg_gemm_ws_enabled();
+int vcg_gemm_ws_wino(const float* x, const void* UPlanes, float* M, int Nimg, int H, int W, int Cin, int Hl, int Wl, int ups,
+                     int reflect, int off, int th, int tw, int Ncols, hipStream_t st);
+// VCG_WINO_FUSED=0: always materialise V with k_wino_in (A/B measurements).  Fused where it costs no repeated transform work:
+// at most `VCG_WINO_FUSED` N tiles of 128 columns (default 2: D1 and U2 forward, D1 / U2 / U1 data gradient) and nobody else
+// wants V (the weight gradient of D2 ... R takes the forward's V: those layers keep k_wino_in)
+static int wino_fused_max_ntiles() {
+  static const int v = [] { const char* e = getenv("VCG_WINO_FUSED"); return e ? atoi(e) : 2; }();
+  return v;
+}
+static bool wino_fused_ok(int cin_phys, int ncols, unsigned long long image_bytes) {
+  return vcg_gemm_ws_enabled() && cin_phys % 32 == 0 && ncols % 128 == 0 && ncols / 128 <= wino_fused_max_ntiles() &&
+         image_bytes < (1ull << 31);
+}
 
 struct WinoP {
   const float* x;
@@ -569,9 +584,13 @@ int vcg_wino_dgrad(const ConvGeom& g, const float* dy, const float* ud, float* d
   float* V = (float*)ws;
   float* M = V + (((size_t)16 * p.T * g.Cout + 63) / 64) * 64;
   p.v = V; p.m = M;
-  hipLaunchKernelGGL(k_wino_in, dim3(wino_blocks((size_t)p.T * g.Cout / 4)), dim3(256), 0, st, p);
-  VCG_LAUNCH_CHECK("vcg_conv_dgrad(winograd input transform)");
-  if (vcg_gemm_split_batched(V, ud, M, p.T, g.Cout, kc, 16, st)) return -2;
+  if (wino_fused_ok(g.Cout, kc, (unsigned long long)g.N * g.Ho * g.Wo * g.Cout * 4)) {                  // transform of the zero-extended dy inside the GEMM's producer waves
+    if (vcg_gemm_ws_wino(dy, ud, M, g.N, g.Ho, g.Wo, g.Cout, g.Ho, g.Wo, 1, 0, 2, p.th, p.tw, kc, st)) return -2;
+  } else {
+    hipLaunchKernelGGL(k_wino_in, dim3(wino_blocks((size_t)p.T * g.Cout / 4)), dim3(256), 0, st, p);
+    VCG_LAUNCH_CHECK("vcg_conv_dgrad(winograd input transform)");
+    if (vcg_gemm_split_batched(V, ud, M, p.T, g.Cout, kc, 16, st)) return -2;
+  }
   WinoP q = p;
   q.Kc = kc;                                      // the output side: k columns
   // output transform and fold in one pass: the padded image is never written
@@ -595,9 +614,13 @@ int vcg_wino_fwd(const ConvGeom& g, const float* x, const float* u, const float*
   float* V = v_keep ? v_keep : (float*)ws;
   float* M = (float*)ws + (((size_t)16 * p.T * p.Kc + 63) / 64) * 64;
   p.x = x; p.v = V; p.m = M; p.bias = bias; p.y = y;
-  hipLaunchKernelGGL(k_wino_in, dim3(wino_blocks((size_t)p.T * p.Kc / 4)), dim3(256), 0, st, p);
-  VCG_LAUNCH_CHECK("vcg_conv_fwd(winograd input transform)");
-  if (vcg_gemm_split_batched(V, u, M, p.T, p.Kc, g.Cout, 16, st)) return -2;
+  if (!v_keep && wino_fused_ok(g.Cin, g.Cout, (unsigned long long)g.N * g.H * g.W * g.Cin * 4)) {   // nobody else wants V: produce it inside the GEMM (gemm_ws.hip, MODE_WINO)
+    if (vcg_gemm_ws_wino(x, u, M, g.N, g.H, g.W, g.Cin, g.Hl, g.Wl, g.ups, g.reflect, 1, p.th, p.tw, g.Cout, st)) return -2;
+  } else {
+    hipLaunchKernelGGL(k_wino_in, dim3(wino_blocks((size_t)p.T * p.Kc / 4)), dim3(256), 0, st, p);
+    VCG_LAUNCH_CHECK("vcg_conv_fwd(winograd input transform)");
+    if (vcg_gemm_split_batched(V, u, M, p.T, p.Kc, g.Cout, 16, st)) return -2;
+  }
   if (in_part) {
     const NormPlan pl = vcg_norm_plan(g.N, p.th * p.tw, g.Cout);
     hipLaunchKernelGGL(k_wino_out_stats, dim3(pl.nchunk, g.N, pl.cgroups), dim3(256), 0, st, p, in_part, pl);

@@ -200,8 +200,12 @@ int vcg_split_planes(const float* x, void* bp, size_t rows, int K, hipStream_t s
   return 0;
 }
 
+bool vcg_gemm_ws_ok(int rows, int K, int N);
+int vcg_gemm_ws_batched(const float* A, const void* BtPlanes, float* C, int rows, int K, int N, int batches, hipStream_t st);
+
 // rows x K (fp32) times (N x K)^T (blocked planes) per batch; K % 32 == 0, N % 64 == 0
 int vcg_gemm_split_batched(const float* A, const void* BtPlanes, float* C, int rows, int K, int N, int batches, hipStream_t st) {
+  if (vcg_gemm_ws_ok(rows, K, N)) return vcg_gemm_ws_batched(A, BtPlanes, C, rows, K, N, batches, st);   // gemm_ws.hip (round 3)
   const float* Bt = (const float*)BtPlanes;
   VCG_CHECK_ARG(K % 32 == 0 && N % 64 == 0 && rows > 0, "vcg_gemm_split_batched: bad shape rows=%d K=%d N=%d", rows, K, N);
   VCG_CHECK_ARG((unsigned long long)rows * K * 4 < (1ull << 31) && (unsigned long long)N * K * 6 < (1ull << 31),
