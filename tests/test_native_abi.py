@@ -88,8 +88,9 @@ def test_launch_plans_are_host_side_and_consistent(pkg):
     # R-block conv: Winograd in all three directions
     r = _desc(8, 16, 16, 1024, 1024, 3)
     T, Tp, kc, co = 8 * 8 * 8, 8 * 9 * 9, 1024, 1024
-    # Wf (fp32) + U + Ud: the Winograd-transformed kernels as pre-split bf16 planes (3 pieces x 2 bytes = 1.5 floats per value)
-    assert lib.vcg_pack_weight_floats(r) == 9 * kc * co + 2 * 16 * kc * co * 3 // 2
+    # Wf (fp32) + U + Ud: the Winograd-transformed kernels as pre-split fp16 planes (2 pieces x 2 bytes = 1 float per value)
+    # + the 16-float header that keeps the kernel's largest magnitude (the planes hold w / s)
+    assert lib.vcg_pack_weight_floats(r) == 9 * kc * co + 2 * 16 * kc * co + 16
     assert lib.vcg_conv_fwd_workspace(r) == 16 * T * (kc + co) * f4 + 512
     assert lib.vcg_conv_dgrad_workspace(r) == 16 * Tp * (kc + co) * f4 + 1024       # V and M over the padded domain's 9 x 9 tiles
     assert lib.vcg_conv_wgrad_workspace(r) > 16 * T * (kc + co) * f4                  # transforms + stream-K slabs
@@ -99,13 +100,13 @@ def test_launch_plans_are_host_side_and_consistent(pkg):
     assert lib.vcg_conv_fwd_workspace(odd) < 16 * 8 * 7 * 7 * (kc + co) * f4
     # D block (folded PixelUnshuffle): Kc = 4 * 128
     d2 = _desc(8, 128, 128, 128, 256, 3, ups=2)
-    assert lib.vcg_pack_weight_floats(d2) == 9 * 512 * 256 + 2 * 16 * 512 * 256 * 3 // 2
+    assert lib.vcg_pack_weight_floats(d2) == 9 * 512 * 256 + 2 * 16 * 512 * 256 + 16
     assert lib.vcg_conv_fwd_workspace(d2) == 16 * (8 * 32 * 32) * (512 + 256) * f4 + 512
     # small channel counts: no transformed copies
     u4 = _desc(8, 256, 256, 32, 64, 3)
-    # Wf + the pre-split weight planes of the direct split-operand kernels: WFT [Cout][K/32][3][32] (forward), WFD
-    # [(tap, c)][Cout/32][3][32] (data gradient): 48 floats per (row, 32-wide block)
-    assert lib.vcg_pack_weight_floats(u4) == 9 * 32 * 64 + 64 * 9 * 48 + 9 * 32 * 2 * 48
+    # Wf + the pre-split weight planes of the direct split-operand kernels: WFT [Cout][K/32][2][32] (forward), WFD
+    # [(tap, c)][Cout/32][2][32] (data gradient): 32 floats per (row, 32-wide block); + the header
+    assert lib.vcg_pack_weight_floats(u4) == 9 * 32 * 64 + 64 * 9 * 32 + 9 * 32 * 2 * 32 + 16
     assert lib.vcg_conv_fwd_workspace(u4) == 0
     # ... and it runs on the LDS-slab kernels: the data gradient over the padded domain (H + 2) x (W + 2), folded afterwards
     assert lib.vcg_conv_dgrad_workspace(u4) == 8 * 258 * 258 * 32 * f4 + 256
@@ -121,22 +122,22 @@ def test_launch_plans_are_host_side_and_consistent(pkg):
     # the latent convs 1024 -> 64: Kc Cout / (Kc + Cout) = 60 is under every Winograd gate (forward 64, data gradient 80):
     # no transformed copies, the planes of the direct split-operand kernels instead
     mu = _desc(8, 16, 16, 1024, 64, 3)
-    assert lib.vcg_pack_weight_floats(mu) == 9 * 1024 * 64 + 64 * (9216 // 32) * 48 + 9 * 1024 * 2 * 48
+    assert lib.vcg_pack_weight_floats(mu) == 9 * 1024 * 64 + 64 * (9216 // 32) * 32 + 9 * 1024 * 2 * 32 + 16
     # decoder head 64 -> 3 (pitch 4), 7x7: Wf + the kw-folded copy [(kh, c)][32]; P buffer over the padded columns
     head = _desc(8, 256, 256, 64, 4, 7, pad=3, cout_log=3)
-    # (+ that copy's pre-split planes [32][7 * 64 / 32][3][32] for the LDS-slab column kernel)
-    assert lib.vcg_pack_weight_floats(head) == ((49 * 64 * 4 + 63) // 64) * 64 + 7 * 64 * 32 + 7 * 64 * 48
+    # (+ that copy's pre-split planes [32][7 * 64 / 32][2][32] for the LDS-slab column kernel, + the header)
+    assert lib.vcg_pack_weight_floats(head) == ((49 * 64 * 4 + 63) // 64) * 64 + 7 * 64 * 32 + 7 * 64 * 32 + 16
     assert lib.vcg_conv_fwd_workspace(head) == 8 * 256 * (256 + 6) * 32 * f4 + 256
     # its weight gradient: the ring kernel over the PADDED input pixels (262 x 262), 7 tap rows x 32 columns per partial
     assert 0 <= lib.vcg_conv_wgrad_workspace(head) - (ring_ws(8, 262, 262, 224) + 255) // 256 * 256 <= 1 << 20
     # encoder stem 3 -> 64: the data gradient takes the folded path (padded-domain dxp + P), the forward does not
     stem = _desc(8, 256, 256, 4, 64, 7, pad=3, cin_log=3)
-    assert lib.vcg_pack_weight_floats(stem) == ((49 * 4 * 64 + 63) // 64) * 64 + 7 * 64 * 32 + 7 * 64 * 48 + 64 * 7 * 48     # K = 196 -> 7 blocks
+    assert lib.vcg_pack_weight_floats(stem) == ((49 * 4 * 64 + 63) // 64) * 64 + 7 * 64 * 32 + 7 * 64 * 32 + 64 * 7 * 32 + 16     # K = 196 -> 7 blocks
     assert lib.vcg_conv_dgrad_workspace(stem) >= 8 * 262 * 262 * 4 * f4 + 8 * 262 * (256 + 12) * 32 * f4
     # stride-2 discriminator conv: direct everywhere; forward and data gradient may slice K (whole output- / input-sized
     # slabs; the data gradient's blockIdx.z enumerates parity class + 4 x slice)
     disc = _desc(8, 128, 128, 64, 128, 4, stride=2, pad=1)
-    assert lib.vcg_pack_weight_floats(disc) == 16 * 64 * 128 + 128 * 32 * 48 + 16 * 64 * 4 * 48
+    assert lib.vcg_pack_weight_floats(disc) == 16 * 64 * 128 + 128 * 32 * 32 + 16 * 64 * 4 * 32 + 16
     assert (lib.vcg_conv_fwd_workspace(disc) - 256) % (8 * 64 * 64 * 128 * f4) in (0, (8 * 64 * 64 * 128 * f4) - 256)
     assert lib.vcg_conv_dgrad_workspace(disc) % (8 * 128 * 128 * 64 * f4) in (0, 256)
 

@@ -1,5 +1,7 @@
-// Wave-specialised split-operand GEMM for the Winograd layers (round 3): the same arithmetic as gemm_split.hip
-// (fp32 operands as three bf16 pieces, six MFMAs per product, two fp32 accumulation chains), another schedule.
+// EXPERIMENT (round 3, not part of libvcg.so; built by tools/gemm_ws_probe.hip): a wave-specialised schedule for the split-operand
+// GEMM of the Winograd layers, in the bf16 x 3 arithmetic of rounds 1-2 (fp32 operands as three bf16 pieces, six MFMAs per
+// product, two fp32 accumulation chains).  Result (profiles/r03_gemm_ws_probe*.txt): within +-5 % of the 4-wave kernel in every
+// variant — the chip clocks down as the MFMA stream gets denser — so the schedule was not adopted; what was: half the MFMAs.
 //
 //   C[z][m][n] = sum_k A[z][m][k] * Bt[z][n][k]        A fp32 (or, MODE_WINO, produced on the fly from the image: below),
 //                                                      Bt pre-split "blocked planes" (gemm_split.hip), C fp32
@@ -25,8 +27,28 @@
 // one load — and V never exists in HBM.  Used for the layers whose V traffic bounds them and that have one or two
 // N tiles (D1, D2, U2: no transform is repeated more than twice); the compute-bound many-N-tile layers keep a
 // materialised V (33-134 MB, L2 / MALL resident) so that the transform is done once.
-#include "vcg_common.h"
+#include "../vae-cyclegan-implementation_amd/csrc/vcg_common.h"
 #include <stdlib.h>
+
+// (this experiment runs the bf16 x 3 arithmetic of rounds 1-2: x = h + m + l, six products)
+__device__ __forceinline__ void split4(const float4& v, uint2& h, uint2& m, uint2& l) {
+  const float x[4] = {v.x, v.y, v.z, v.w};
+  unsigned short hs[4], ms[4], ls[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const __bf16 hb = (__bf16)x[i];
+    const float r1 = x[i] - (float)hb;
+    const __bf16 mb = (__bf16)r1;
+    const float r2 = r1 - (float)mb;
+    const __bf16 lb = (__bf16)r2;
+    hs[i] = __builtin_bit_cast(unsigned short, hb);
+    ms[i] = __builtin_bit_cast(unsigned short, mb);
+    ls[i] = __builtin_bit_cast(unsigned short, lb);
+  }
+  h = make_uint2((uint32_t)hs[0] | ((uint32_t)hs[1] << 16), (uint32_t)hs[2] | ((uint32_t)hs[3] << 16));
+  m = make_uint2((uint32_t)ms[0] | ((uint32_t)ms[1] << 16), (uint32_t)ms[2] | ((uint32_t)ms[3] << 16));
+  l = make_uint2((uint32_t)ls[0] | ((uint32_t)ls[1] << 16), (uint32_t)ls[2] | ((uint32_t)ls[3] << 16));
+}
 
 typedef unsigned int u32x4w __attribute__((ext_vector_type(4)));
 

@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 # VCG_LIBVCG: load another build of the same sources (A/B runs of kernel variants, tools/); the default is the in-tree library
 LIB_PATH = os.environ.get("VCG_LIBVCG") or os.path.join(_HERE, "libvcg.so")
-SOURCES = ["conv_igemm.hip", "conv_thin.hip", "conv_wino.hip", "conv_slab.hip", "conv_ring.hip", "gemm_split.hip", "gemm_ws.hip", "norm.hip", "misc.hip", "input.hip"]
+SOURCES = ["conv_igemm.hip", "conv_thin.hip", "conv_wino.hip", "conv_slab.hip", "conv_ring.hip", "gemm_split.hip", "norm.hip", "misc.hip", "input.hip"]
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "vcg.h")
 
 _c = ctypes

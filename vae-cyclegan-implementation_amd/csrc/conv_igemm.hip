@@ -61,6 +61,8 @@ struct ConvP {
   // channel, as chunk `(m0 % HoWo) / 128` of image `m0 / HoWo` in the [N][nchunk][Cout][2] double partials of norm.hip
   double* in_part;
   int in_nchunk;
+  // fp16 x 2 split-operand kernels (vcg_common.h): the largest magnitude of the tensor behind `a` and of the one behind `b`
+  VcgAmax amax_a, amax_b;
 };
 
 #define BK 32
@@ -406,38 +408,45 @@ __global__ __launch_bounds__(256, TWO ? 2 : 3) void k_conv_fwd(ConvP p) {   // T
   VCG_STAMP_AT(3);
 }
 
-// one K-step (32) of the split-operand product: two 16-wide slices x six bf16 MFMAs per 32x32 accumulator.
-// The dominant h*h products go to `acc`, the five cross terms (<= 2^-7 of them) to `lo`: every add into an fp32
-// accumulator rounds relative to the accumulator's magnitude, so feeding all six into one chain would cost six
-// roundings of the big running sum per slice instead of one (measured: 7.9e-7 -> see tools/conv_accuracy.py).
+// one K-step (32) of the split-operand product: two 16-wide slices x three fp16 MFMAs per 32x32 accumulator (vcg_common.h:
+// x / s = h + l).  The dominant h*h products go to `acc`, the two cross terms (<= 2^-11 of them) to `lo`: every add into an
+// fp32 accumulator rounds relative to the accumulator's magnitude, so feeding all three into one chain would cost three
+// roundings of the big running sum per slice instead of one.
 template <int MI, int NI, int RA, int RB>
-__device__ __forceinline__ void split_mma_ktile(f32x16 (&acc)[MI][NI], f32x16 (&lo)[MI][NI], const unsigned char (&As)[3][RA],
-                                                const unsigned char (&Bs)[3][RB], const uint32_t (&fa)[MI], const uint32_t (&fb)[NI],
+__device__ __forceinline__ void split_mma_ktile(f32x16 (&acc)[MI][NI], f32x16 (&lo)[MI][NI], const unsigned char (&As)[VCG_NP][RA],
+                                                const unsigned char (&Bs)[VCG_NP][RB], const uint32_t (&fa)[MI], const uint32_t (&fb)[NI],
                                                 const int (&sa)[MI], const int (&sb)[NI], int lh) {
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
-    bf16x8 a[3][MI], b[3][NI];
+    f16x8 a[VCG_NP][MI], b[VCG_NP][NI];
 #pragma unroll
-    for (int pc = 0; pc < 3; ++pc) {
+    for (int pc = 0; pc < VCG_NP; ++pc) {
 #pragma unroll
-      for (int i = 0; i < MI; ++i) a[pc][i] = *reinterpret_cast<const bf16x8*>(&As[pc][fa[i] + (((2 * s + lh) ^ sa[i]) << 4)]);
+      for (int i = 0; i < MI; ++i) a[pc][i] = *reinterpret_cast<const f16x8*>(&As[pc][fa[i] + (((2 * s + lh) ^ sa[i]) << 4)]);
 #pragma unroll
-      for (int j = 0; j < NI; ++j) b[pc][j] = *reinterpret_cast<const bf16x8*>(&Bs[pc][fb[j] + (((2 * s + lh) ^ sb[j]) << 4)]);
+      for (int j = 0; j < NI; ++j) b[pc][j] = *reinterpret_cast<const f16x8*>(&Bs[pc][fb[j] + (((2 * s + lh) ^ sb[j]) << 4)]);
     }
 #pragma unroll
     for (int i = 0; i < MI; ++i)
 #pragma unroll
       for (int j = 0; j < NI; ++j) {
         f32x16 c = lo[i][j];
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][i], b[1][j], c, 0, 0, 0);     // smallest contributions first
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2][i], b[0][j], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[2][j], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][i], b[0][j], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[1][j], c, 0, 0, 0);
+        c = VCG_MFMA(a[1][i], b[0][j], c);
+        c = VCG_MFMA(a[0][i], b[1][j], c);
         lo[i][j] = c;
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[0][j], acc[i][j], 0, 0, 0);
+        acc[i][j] = VCG_MFMA(a[0][i], b[0][j], acc[i][j]);
       }
   }
+}
+// the operand scales of a split-operand kernel: 1 / sA (applied while A is split), 1 / sB (B, where the kernel splits it itself)
+// and sA * sB (the epilogue)
+struct SplitScales { float inv_a, inv_b, out; };
+__device__ __forceinline__ SplitScales split_scales(const ConvP& p) {
+  float sa, ia, sb, ib;
+  vcg_scale_of(vcg_amax_bits(p.amax_a), p.amax_a.shift, sa, ia);
+  vcg_scale_of(vcg_amax_bits(p.amax_b), p.amax_b.shift, sb, ib);
+  SplitScales r; r.inv_a = ia; r.inv_b = ib; r.out = sa * sb;
+  return r;
 }
 
 // The forward implicit GEMM on the bf16 matrix pipe with split operands (gemm_split.hip explains the arithmetic: three
@@ -449,10 +458,11 @@ __global__ __launch_bounds__(256, 2) void k_conv_fwd_split(ConvP p) {
   VCG_STAMP_AT(0);
   constexpr int BM = 128, WN = 2, WM = 2;
   constexpr int MI = BM / (32 * WM), NI = BN / (32 * WN), AR = BM / 32;
-  __shared__ __attribute__((aligned(16))) unsigned char As[3][BM * 64];
-  __shared__ __attribute__((aligned(16))) unsigned char Bs[3][BN * 64];
+  __shared__ __attribute__((aligned(16))) unsigned char As[VCG_NP][BM * 64];
+  __shared__ __attribute__((aligned(16))) unsigned char Bs[VCG_NP][BN * 64];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid / WN, wn = wid % WN, l31 = lane & 31, lh = lane >> 5;
+  const SplitScales sc = split_scales(p);
   // Tile assignment.  Batched GEMMs (XCD-aware, cdna_hip_programming.md T1): workgroup ids round-robin over the 8
   // XCDs, each with its own L2, so the launch is cut into 8 contiguous runs of the N-fastest tile order — the N
   // tiles that share an A tile then run back to back on ONE XCD instead of fetching it into eight L2s.
@@ -511,11 +521,11 @@ __global__ __launch_bounds__(256, 2) void k_conv_fwd_split(ConvP p) {
   // weight tile from the WfT PLANES (the transposed pack, split into bf16 pieces when it was packed: [Cout][K/32][3][32],
   // K zero-padded to 32): thread (row b_r = tid >> 2, 16-byte chunk b_q = tid & 3 of a 64-byte piece row); pass j =
   // (64-row half, piece).  Rows past Cout fall off the end of the buffer and read as zeros.
-  constexpr int BP = 3 * BN / 64;
+  constexpr int BP = VCG_NP * BN / 64;
   const int b_q = tid & 3, b_r = tid >> 2;
   const int KB = (p.K + 31) / 32;
-  const uint32_t boff0 = (uint32_t)(((size_t)(n0 + b_r) * KB) * 192 + b_q * 16);
-  const uint32_t bhalf = (uint32_t)KB * (64u * 192u);
+  const uint32_t boff0 = (uint32_t)(((size_t)(n0 + b_r) * KB) * VCG_PBYTES + b_q * 16);
+  const uint32_t bhalf = (uint32_t)KB * (64u * VCG_PBYTES);
   const uint32_t bsoff0 = (uint32_t)(b_r * 64 + ((b_q ^ ((b_r >> 2) & 3)) << 4));
   u32x4 vbp[BP];
   // LDS byte offset of this thread's quad in a piece image (row r, chunk a_u >> 1 swizzled by (r >> 2) & 3, half a_u & 1)
@@ -557,19 +567,18 @@ __global__ __launch_bounds__(256, 2) void k_conv_fwd_split(ConvP p) {
     }
 #pragma unroll
     for (int j = 0; j < BP; ++j)
-      vbp[j] = __builtin_amdgcn_raw_buffer_load_b128(rb, (int)(boff0 + (uint32_t)(j / 3) * bhalf + (uint32_t)(j % 3) * 64u + (uint32_t)kt * 192u), 0, 0);
+      vbp[j] = __builtin_amdgcn_raw_buffer_load_b128(rb, (int)(boff0 + (uint32_t)(j / VCG_NP) * bhalf + (uint32_t)(j % VCG_NP) * 64u + (uint32_t)kt * VCG_PBYTES), 0, 0);
   };
   auto store_tiles = [&]() {
 #pragma unroll
     for (int r = 0; r < AR; ++r) {
-      uint2 h, m, l;
-      split4(va[r], h, m, l);
+      uint2 h, l;
+      split4h(va[r], sc.inv_a, h, l);
       *reinterpret_cast<uint2*>(&As[0][soff[r]]) = h;
-      *reinterpret_cast<uint2*>(&As[1][soff[r]]) = m;
-      *reinterpret_cast<uint2*>(&As[2][soff[r]]) = l;
+      *reinterpret_cast<uint2*>(&As[1][soff[r]]) = l;
     }
 #pragma unroll
-    for (int j = 0; j < BP; ++j) *reinterpret_cast<u32x4*>(&Bs[j % 3][bsoff0 + 4096 * (j / 3)]) = vbp[j];
+    for (int j = 0; j < BP; ++j) *reinterpret_cast<u32x4*>(&Bs[j % VCG_NP][bsoff0 + 4096 * (j / VCG_NP)]) = vbp[j];
   };
   uint32_t fa[MI], fb[NI];
   int sa[MI], sb[NI];
@@ -617,7 +626,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_fwd_split(ConvP p) {
       for (int e = 0; e < 16; ++e) {
         const int row = (e & 3) + 8 * (e >> 2) + 4 * lh;
         const int m = m0 + wm * (BM / WM) + i * 32 + row;
-        const float v = act_apply(acc[i][j][e] + bv, act);
+        const float v = act_apply(acc[i][j][e] * sc.out + bv, act);
         if (cv && m < p.M) dst[(size_t)m * p.Cout + co] = v;
         s1 += v;
         s2 += v * v;
@@ -868,10 +877,11 @@ __global__ __launch_bounds__(256, 2) void k_conv_dgrad_split(ConvP p) {
   VCG_STAMP_AT(0);
   constexpr int BM = 128, WM = 4 / WN;
   constexpr int MI = BM / (32 * WM), NI = BN / (32 * WN), AR = BM / 32, BR = BN / 32;
-  __shared__ __attribute__((aligned(16))) unsigned char As[3][BM * 64];
-  __shared__ __attribute__((aligned(16))) unsigned char Bs[3][BN * 64];
+  __shared__ __attribute__((aligned(16))) unsigned char As[VCG_NP][BM * 64];
+  __shared__ __attribute__((aligned(16))) unsigned char Bs[VCG_NP][BN * 64];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid / WN, wn = wid % WN, l31 = lane & 31, lh = lane >> 5;
+  const SplitScales sc = split_scales(p);
   const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
   const int a_row = tid >> 3, a_u = tid & 7;
   const int s = p.stride, sshift = s - 1;
@@ -908,7 +918,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_dgrad_split(ConvP p) {
   float4 va[AR], ve[AR], vb[BPL ? 1 : BR];
   // BPL: the weight rows come pre-split from the pack's dgrad planes [(tap, J)][Cout/32][3][32] (Cout % 32 == 0): thread
   // (row b_r = tid >> 2, 16-byte chunk b_q = tid & 3 of a 64-byte piece row), pass j = (64-row half, piece)
-  constexpr int BP = BPL ? 3 * BN / 64 : 1;
+  constexpr int BP = BPL ? VCG_NP * BN / 64 : 1;
   const int b_q = tid & 3, b_r = tid >> 2;
   const int CB = p.Cout / 32;
   const uint32_t bsoff0 = (uint32_t)(b_r * 64 + ((b_q ^ ((b_r >> 2) & 3)) << 4));
@@ -1001,8 +1011,8 @@ __global__ __launch_bounds__(256, 2) void k_conv_dgrad_split(ConvP p) {
       const bool kvt = kt * 32 < Kc;
 #pragma unroll
       for (int j = 0; j < BP; ++j) {
-        const int J = n0 + b_r + 64 * (j / 3);
-        const uint32_t off = (kvt && J < p.NB) ? (uint32_t)((((size_t)tf * p.NB + J) * CB + cob) * 192 + (j % 3) * 64 + b_q * 16) : VCG_OOB;
+        const int J = n0 + b_r + 64 * (j / VCG_NP);
+        const uint32_t off = (kvt && J < p.NB) ? (uint32_t)((((size_t)tf * p.NB + J) * CB + cob) * VCG_PBYTES + (j % VCG_NP) * 64 + b_q * 16) : VCG_OOB;
         vbp[j] = __builtin_amdgcn_raw_buffer_load_b128(rb, (int)off, 0, 0);
       }
     } else {
@@ -1020,23 +1030,21 @@ __global__ __launch_bounds__(256, 2) void k_conv_dgrad_split(ConvP p) {
 #pragma unroll
     for (int r = 0; r < AR; ++r) {
       const float4 v = make_float4(va[r].x + ve[r].x, va[r].y + ve[r].y, va[r].z + ve[r].z, va[r].w + ve[r].w);   // ve == 0 off the edges
-      uint2 h, m, l;
-      split4(v, h, m, l);
+      uint2 h, l;
+      split4h(v, sc.inv_a, h, l);
       *reinterpret_cast<uint2*>(&As[0][soff[r]]) = h;
-      *reinterpret_cast<uint2*>(&As[1][soff[r]]) = m;
-      *reinterpret_cast<uint2*>(&As[2][soff[r]]) = l;
+      *reinterpret_cast<uint2*>(&As[1][soff[r]]) = l;
     }
     if constexpr (BPL) {
 #pragma unroll
-      for (int j = 0; j < BP; ++j) *reinterpret_cast<u32x4*>(&Bs[j % 3][bsoff0 + 4096 * (j / 3)]) = vbp[j];
+      for (int j = 0; j < BP; ++j) *reinterpret_cast<u32x4*>(&Bs[j % VCG_NP][bsoff0 + 4096 * (j / VCG_NP)]) = vbp[j];
     } else {
 #pragma unroll
       for (int r = 0; r < BR; ++r) {
-        uint2 h, m, l;
-        split4(vb[r], h, m, l);
+        uint2 h, l;
+        split4h(vb[r], sc.inv_b, h, l);
         *reinterpret_cast<uint2*>(&Bs[0][soff[r]]) = h;
-        *reinterpret_cast<uint2*>(&Bs[1][soff[r]]) = m;
-        *reinterpret_cast<uint2*>(&Bs[2][soff[r]]) = l;
+        *reinterpret_cast<uint2*>(&Bs[1][soff[r]]) = l;
       }
     }
   };
@@ -1091,7 +1099,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_dgrad_split(ConvP p) {
           uint32_t wq = rem - hq * (uint32_t)p.Wc;
           int h = (int)hq * s + ca, w = (int)wq * s + cb;
           size_t off = ((size_t)((int)n * p.H + h * p.ups + qi) * p.W + (w * p.ups + qj)) * p.Cin + c;
-          dst[off] = acc[i][j][e];
+          dst[off] = acc[i][j][e] * sc.out;
         }
       }
     }
@@ -1307,12 +1315,12 @@ __device__ __forceinline__ uint32_t tr_off(int row, int col) {       // byte off
 }
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 template <int COLS>
-__device__ __forceinline__ bf16x8 tr_frag(const unsigned char* img, int row0, int col) {   // rows row0 .. row0+7 of column `col`
+__device__ __forceinline__ f16x8 tr_frag(const unsigned char* img, int row0, int col) {   // rows row0 .. row0+7 of column `col`
   const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(img + tr_off<COLS>(row0, col)));
   const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(img + tr_off<COLS>(row0 + 4, col)));
   typedef short s16x8 __attribute__((ext_vector_type(8)));
   const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-  return __builtin_bit_cast(bf16x8, v);
+  return __builtin_bit_cast(f16x8, v);
 }
 
 template <int BN>
@@ -1322,10 +1330,11 @@ __global__ __launch_bounds__(256, 2) void k_conv_wgrad_split(ConvP p) {
   constexpr int WR = NT / 128;                                 // wave rows (x 2 wave columns)
   constexpr int MI = BM / (32 * WR), NI = BN / 64;
   constexpr int RQ = BM / 4, PS = NT / RQ, AP = BK / PS, BE = (BK * BN / 4) / NT;
-  __shared__ __attribute__((aligned(16))) unsigned char Xs[3][BK * BM * 2];   // [piece][32 pixels][128 rows of dW] bf16
-  __shared__ __attribute__((aligned(16))) unsigned char Ds[3][BK * BN * 2];   // [piece][32 pixels][128 columns] bf16
+  __shared__ __attribute__((aligned(16))) unsigned char Xs[VCG_NP][BK * BM * 2];   // [piece][32 pixels][128 rows of dW] fp16
+  __shared__ __attribute__((aligned(16))) unsigned char Ds[VCG_NP][BK * BN * 2];   // [piece][32 pixels][128 columns] fp16
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid >> 1, wn = wid & 1, l31 = lane & 31, lh = lane >> 5;
+  const SplitScales sc = split_scales(p);
   const int rq = tid % RQ, ps = tid / RQ;
   const uint32_t bstep = (uint32_t)(BK * p.Cout * 4);
   // When Wo % 32 == 0 the 32 pixels of a K' step lie in one image row: (n, oh) and the row part of the
@@ -1445,23 +1454,21 @@ __global__ __launch_bounds__(256, 2) void k_conv_wgrad_split(ConvP p) {
   auto store_tiles = [&]() {
 #pragma unroll
     for (int a = 0; a < AP; ++a) {
-      uint2 h, m, l;
-      split4(va[a], h, m, l);
+      uint2 h, l;
+      split4h(va[a], sc.inv_a, h, l);
       const uint32_t o = tr_off<BM>(ps + PS * a, rq * 4);
       *reinterpret_cast<uint2*>(&Xs[0][o]) = h;
-      *reinterpret_cast<uint2*>(&Xs[1][o]) = m;
-      *reinterpret_cast<uint2*>(&Xs[2][o]) = l;
+      *reinterpret_cast<uint2*>(&Xs[1][o]) = l;
     }
 #pragma unroll
     for (int e = 0; e < BE; ++e) {
       const int idx = tid + NT * e;
       const int pp = idx / (BN / 4), j4 = idx % (BN / 4);
-      uint2 h, m, l;
-      split4(vb[e], h, m, l);
+      uint2 h, l;
+      split4h(vb[e], sc.inv_b, h, l);
       const uint32_t o = tr_off<BN>(pp, j4 * 4);
       *reinterpret_cast<uint2*>(&Ds[0][o]) = h;
-      *reinterpret_cast<uint2*>(&Ds[1][o]) = m;
-      *reinterpret_cast<uint2*>(&Ds[2][o]) = l;
+      *reinterpret_cast<uint2*>(&Ds[1][o]) = l;
     }
   };
   // transposing fragment reads: 16-lane group g = lane >> 4 handles columns 16 (g & 1) .. +15 of a 32-wide MFMA tile and
@@ -1479,9 +1486,9 @@ __global__ __launch_bounds__(256, 2) void k_conv_wgrad_split(ConvP p) {
 #pragma unroll
     for (int s2 = 0; s2 < 2; ++s2) {
       const int row0 = 16 * s2 + 8 * lh + tq;
-      bf16x8 af[3][MI], bfr[3][NI];
+      f16x8 af[VCG_NP][MI], bfr[VCG_NP][NI];
 #pragma unroll
-      for (int pc = 0; pc < 3; ++pc) {
+      for (int pc = 0; pc < VCG_NP; ++pc) {
 #pragma unroll
         for (int i = 0; i < MI; ++i) af[pc][i] = tr_frag<BM>(Xs[pc], row0, wm * (BM / WR) + i * 32 + tcol);
 #pragma unroll
@@ -1492,13 +1499,10 @@ __global__ __launch_bounds__(256, 2) void k_conv_wgrad_split(ConvP p) {
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
           f32x16 c = lo[i][j];
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][i], bfr[1][j], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2][i], bfr[0][j], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bfr[2][j], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][i], bfr[0][j], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bfr[1][j], c, 0, 0, 0);
+          c = VCG_MFMA(af[1][i], bfr[0][j], c);
+          c = VCG_MFMA(af[0][i], bfr[1][j], c);
           lo[i][j] = c;
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bfr[0][j], acc[i][j], 0, 0, 0);
+          acc[i][j] = VCG_MFMA(af[0][i], bfr[0][j], acc[i][j]);
         }
     }
     __syncthreads();
@@ -1524,7 +1528,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_wgrad_split(ConvP p) {
       for (int e = 0; e < 16; ++e) {
         const int row = (e & 3) + 8 * (e >> 2) + 4 * lh;
         const int Rr = r0 + wm * (BM / WR) + i * 32 + row;
-        if (Rr < p.K) slab[(size_t)Rr * p.Cout + co] = acc[i][j][e];
+        if (Rr < p.K) slab[(size_t)Rr * p.Cout + co] = acc[i][j][e] * sc.out;
       }
     }
   }
@@ -1771,6 +1775,8 @@ __global__ __launch_bounds__(256) void k_pack_weight_t(const float* __restrict__
 template <bool DGRAD>
 __global__ __launch_bounds__(256) void k_pack_planes(const float* __restrict__ w, unsigned short* __restrict__ bp, ConvP p, int cin_log,
                                                      int cout_log) {
+  float psc, pinv;                                                  // the planes hold w / s, s from the kernel's amax (p.amax_b)
+  vcg_scale_of(vcg_amax_bits(p.amax_b), p.amax_b.shift, psc, pinv);
   const int U2 = p.ups * p.ups, KK = p.KH * p.KW;
   const int cinL = cin_log * U2;
   const int KB = (p.K + 31) / 32, CB = p.Cout / 32;
@@ -1790,7 +1796,7 @@ __global__ __launch_bounds__(256) void k_pack_planes(const float* __restrict__ w
         for (int e = 0; e < 4; ++e)
           if (co0 + e < cout_log) v[e] = w[(((size_t)(co0 + e) * cinL + (size_t)c * U2 + q) * p.KH + kh) * p.KW + kw];
       }
-      o = bp + (row * CB + co0 / 32) * 96 + (co0 & 31);
+      o = bp + (row * CB + co0 / 32) * VCG_PBLK + (co0 & 31);
     } else {
       const int co = (int)(idx / ((size_t)KB * 8));
       const int k0 = (int)(idx - (size_t)co * KB * 8) * 4;       // 4 consecutive k: one tap, channels c .. c + 3
@@ -1807,13 +1813,12 @@ __global__ __launch_bounds__(256) void k_pack_planes(const float* __restrict__ w
             v[e] = w[(((size_t)co * cinL + cl) * p.KH + kh) * p.KW + kw];
           }
       }
-      o = bp + ((size_t)co * KB + k0 / 32) * 96 + (k0 & 31);
+      o = bp + ((size_t)co * KB + k0 / 32) * VCG_PBLK + (k0 & 31);
     }
-    uint2 h, m, l;
-    split4(make_float4(v[0], v[1], v[2], v[3]), h, m, l);
+    uint2 h, l;
+    split4h(make_float4(v[0], v[1], v[2], v[3]), pinv, h, l);
     *reinterpret_cast<uint2*>(o) = h;
-    *reinterpret_cast<uint2*>(o + 32) = m;
-    *reinterpret_cast<uint2*>(o + 64) = l;
+    *reinterpret_cast<uint2*>(o + 32) = l;
   }
 }
 
@@ -1931,6 +1936,7 @@ static void fill_params(const ConvGeom& g, ConvP& p) {
   p.a_bytes = p.b_bytes = 0; p.dbl_mirror = 0;
   p.bias = nullptr;
   p.in_part = nullptr; p.in_nchunk = 0;
+  p.amax_a = p.amax_b = vcg_amax_const(0);      // scale 1 (the fp32-MFMA kernels never look)
 }
 
 // Tile and K-slice choice.  The 256 CUs want >= 512 workgroups.  If the largest tile that reaches that
@@ -2038,8 +2044,8 @@ static bool wft_wanted(const ConvGeom& g) { return g.Cout >= 64 && g.Cin % 4 == 
 static bool wfd_wanted(const ConvGeom& g) {
   return g.Cout >= 64 && g.Cout % 32 == 0 && !wino_takes_dgrad(g) && !vcg_thin_fold_dgrad_ok(g) && !vcg_thin_dgrad_ok(g);
 }
-static size_t wft_floats(const ConvGeom& g) { return (size_t)g.Cout * ((g.K + 31) / 32) * 48; }               // 192 bytes per (co, K block)
-static size_t wfd_floats(const ConvGeom& g) { return (size_t)g.KH * g.KW * g.ups * g.ups * g.Cin * (g.Cout / 32) * 48; }
+static size_t wft_floats(const ConvGeom& g) { return (size_t)g.Cout * ((g.K + 31) / 32) * VCG_PFLOATS; }      // VCG_PBYTES per (co, K block)
+static size_t wfd_floats(const ConvGeom& g) { return (size_t)g.KH * g.KW * g.ups * g.ups * g.Cin * (g.Cout / 32) * VCG_PFLOATS; }
 static size_t wkd_offset(const ConvGeom& g) { return wf_floats(g) + (vcg_thin_fold_ok(g) ? vcg_thin_fold_weight_floats(g) : 0); }
 static size_t wft_offset(const ConvGeom& g) {
   return wf_floats(g) + wino_u_floats(g) + wino_ud_floats(g) +
@@ -2047,6 +2053,14 @@ static size_t wft_offset(const ConvGeom& g) {
          (vcg_thin_fold_dgrad_ok(g) ? vcg_thin_fold_dgrad_weight_floats(g) : 0);
 }
 static size_t wfd_offset(const ConvGeom& g) { return wft_offset(g) + (wft_wanted(g) ? wft_floats(g) : 0); }
+// the pack ends with a 16-float header: word 0 = bit pattern of the kernel's largest magnitude (what every plane set of
+// the pack was scaled by: vcg_common.h), read by the kernels that multiply by those planes
+static size_t wamax_offset(const ConvGeom& g) { return wfd_offset(g) + (wfd_wanted(g) ? wfd_floats(g) : 0); }
+const void* vcg_pack_amax(const ConvGeom& g, const float* wf) { return wf + wamax_offset(g); }
+__global__ void k_amax_store(VcgAmax a, uint32_t* dst) {
+  const uint32_t b = vcg_amax_bits(a);
+  if (threadIdx.x == 0) *dst = b;
+}
 // VCG_SLAB=0 keeps the slab kernels (conv_slab.hip) out of the dispatch: A/B measurements only
 static bool slab_enabled() {
   static const int on = [] { const char* e = getenv("VCG_SLAB"); return e ? atoi(e) : 1; }();
@@ -2089,17 +2103,25 @@ extern "C" size_t vcg_pack_weight_floats(const int32_t* cd) {
          + (vcg_thin_fold_ok(g) ? vcg_thin_fold_weight_floats(g) : 0)                   // + Wk (kw-folded thin forward)
          + (vcg_thin_fold_dgrad_ok(g) ? vcg_thin_fold_dgrad_weight_floats(g) : 0)       // + Wkd (kw-folded thin data gradient)
          + (wft_wanted(g) ? wft_floats(g) : 0)                                          // + WFT planes (split-operand direct forward)
-         + (wfd_wanted(g) ? wfd_floats(g) : 0);                                         // + WFD planes (split-operand direct data gradient)
+         + (wfd_wanted(g) ? wfd_floats(g) : 0)                                          // + WFD planes (split-operand direct data gradient)
+         + 16;                                                                          // + the header (wamax_offset)
 }
 
 extern "C" int vcg_pack_weight(const float* w_oihw, float* wf, const int32_t* cd, void* stream) {
   ConvGeom g;
   if (vcg_conv_geom(cd, &g, "vcg_pack_weight")) return -1;
   VCG_CHECK_ARG(w_oihw && wf, "vcg_pack_weight: null pointer");
-  if (vcg_thin_fold_ok(g) && vcg_thin_fold_pack(g, w_oihw, wf + wf_floats(g), (hipStream_t)stream)) return -2;
-  if (vcg_thin_fold_dgrad_ok(g) && vcg_thin_fold_dgrad_pack(g, w_oihw, wf + wkd_offset(g), (hipStream_t)stream)) return -2;
+  // the kernel's largest magnitude: every pre-split plane set below holds w / s (vcg_common.h), and the header keeps the
+  // bits for the kernels that consume the planes
+  const VcgAmaxOut aw = vcg_amax_new((hipStream_t)stream);
+  if (vcg_absmax_launch(w_oihw, (size_t)g.cout_log * g.cin_log * g.ups * g.ups * g.KH * g.KW, aw, (hipStream_t)stream)) return -2;
+  const VcgAmax amax_w = vcg_amax_in(aw);
+  hipLaunchKernelGGL(k_amax_store, dim3(1), dim3(64), 0, (hipStream_t)stream, amax_w, (uint32_t*)(wf + wamax_offset(g)));
+  if (vcg_thin_fold_ok(g) && vcg_thin_fold_pack(g, w_oihw, wf + wf_floats(g), amax_w, (hipStream_t)stream)) return -2;
+  if (vcg_thin_fold_dgrad_ok(g) && vcg_thin_fold_dgrad_pack(g, w_oihw, wf + wkd_offset(g), amax_w, (hipStream_t)stream)) return -2;
   if (wft_wanted(g)) {
     ConvP q; fill_params(g, q);
+    q.amax_b = amax_w;
     const size_t tot = (size_t)g.Cout * ((g.K + 31) / 32) * 8;
     int blocks = (int)((tot + 255) / 256); if (blocks > 8192) blocks = 8192;
     hipLaunchKernelGGL(k_pack_planes<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w_oihw, (unsigned short*)(wf + wft_offset(g)), q,
@@ -2108,14 +2130,15 @@ extern "C" int vcg_pack_weight(const float* w_oihw, float* wf, const int32_t* cd
   }
   if (wfd_wanted(g)) {
     ConvP q; fill_params(g, q);
+    q.amax_b = amax_w;
     const size_t tot = (size_t)g.KH * g.KW * g.ups * g.ups * g.Cin * (g.Cout / 4);
     int blocks = (int)((tot + 255) / 256); if (blocks > 8192) blocks = 8192;
     hipLaunchKernelGGL(k_pack_planes<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w_oihw, (unsigned short*)(wf + wfd_offset(g)), q,
                        g.cin_log, g.cout_log);
     VCG_LAUNCH_CHECK("vcg_pack_weight(WFD planes)");
   }
-  if (wino_takes_fwd(g) && vcg_wino_weight(g, w_oihw, wf + wf_floats(g), (hipStream_t)stream)) return -2;
-  if (wino_takes_dgrad(g) && vcg_wino_weight_dgrad(g, w_oihw, wf + wf_floats(g) + wino_u_floats(g), (hipStream_t)stream)) return -2;
+  if (wino_takes_fwd(g) && vcg_wino_weight(g, w_oihw, wf + wf_floats(g), amax_w, (hipStream_t)stream)) return -2;
+  if (wino_takes_dgrad(g) && vcg_wino_weight_dgrad(g, w_oihw, wf + wf_floats(g) + wino_u_floats(g), amax_w, (hipStream_t)stream)) return -2;
   ConvP p; fill_params(g, p);
   size_t total = (size_t)g.K * g.Cout;
   const int T = g.KH * g.KW * g.ups * g.ups;
@@ -2168,12 +2191,12 @@ static int conv_fwd_impl(const float* x, const float* wf, const float* bias, flo
   ConvGeom g;
   if (vcg_conv_geom(cd, &g, "vcg_conv_fwd")) return -1;
   VCG_CHECK_ARG(x && wf && y, "vcg_conv_fwd: null pointer");
-  if (vcg_thin_fold_ok(g)) return vcg_thin_fold_fwd(g, x, wf + wf_floats(g), bias, y, ws, ws_bytes, (hipStream_t)stream);
+  if (vcg_thin_fold_ok(g)) return vcg_thin_fold_fwd(g, x, wf + wf_floats(g), vcg_pack_amax(g, wf), bias, y, ws, ws_bytes, (hipStream_t)stream);
   if (vcg_thin_fwd_ok(g)) return vcg_thin_fwd(g, x, wf, bias, y, (hipStream_t)stream);
   if (vcg_wino_fwd_ok(g))
-    return vcg_wino_fwd(g, x, wf + wf_floats(g), bias, y, ws, ws_bytes, (hipStream_t)stream, in_part, in_nchunk, saved);
+    return vcg_wino_fwd(g, x, wf + wf_floats(g), vcg_pack_amax(g, wf), bias, y, ws, ws_bytes, (hipStream_t)stream, in_part, in_nchunk, saved);
   if (fwd_slab_ok(g))
-    return vcg_slab_fwd(g, x, wf + wft_offset(g), wft_floats(g) * 4, bias, y, in_part, in_nchunk, (hipStream_t)stream);
+    return vcg_slab_fwd(g, x, wf + wft_offset(g), wft_floats(g) * 4, vcg_pack_amax(g, wf), bias, y, in_part, in_nchunk, (hipStream_t)stream);
   ConvP p; fill_params(g, p);
   if (in_part) {
     p.in_part = in_part;
@@ -2194,9 +2217,13 @@ static int conv_fwd_impl(const float* x, const float* wf, const float* bias, flo
   dim3 grid((g.M + bm - 1) / bm, (g.Cout + bn - 1) / bn, nsplit);
   hipStream_t st = (hipStream_t)stream;
   const double gemm_flops = 2.0 * g.M * (double)g.K * g.Cout;
-  if (bm == 128 && bn >= 64 && wft_wanted(g)) {          // split-operand bf16 kernel, B^T from the pre-split WFT planes of the pack
+  if (bm == 128 && bn >= 64 && wft_wanted(g)) {          // split-operand fp16 kernel, B^T from the pre-split WFT planes of the pack
     p.b = wf + wft_offset(g);
     p.b_bytes = (uint32_t)(wft_floats(g) * 4);
+    const VcgAmaxOut ax = vcg_amax_new(st);              // the input's largest magnitude: its scale (vcg_common.h)
+    if (vcg_absmax_launch(x, (size_t)g.N * g.H * g.W * g.Cin, ax, st)) return -2;
+    p.amax_a = vcg_amax_in(ax);
+    p.amax_b = vcg_amax_stored(vcg_pack_amax(g, wf));
     VcgProfScope prof(bn == 128 ? "k_conv_fwd_split<128>" : "k_conv_fwd_split<64>", gemm_flops, st);
     if (bn == 128) hipLaunchKernelGGL((k_conv_fwd_split<128>), grid, dim3(256), 0, st, p);
     else hipLaunchKernelGGL((k_conv_fwd_split<64>), grid, dim3(256), 0, st, p);
@@ -2303,12 +2330,12 @@ extern "C" int vcg_conv_dgrad(const float* dy, const float* wf, float* dx, const
   VCG_CHECK_ARG(dy && wf && dx, "vcg_conv_dgrad: null pointer");
   VCG_CHECK_ARG(g.Hl % g.stride == 0 && g.Wl % g.stride == 0, "vcg_conv_dgrad: input %dx%d not divisible by stride", g.Hl, g.Wl);
   VCG_CHECK_ARG(g.stride == 1 || g.ups == 1, "vcg_conv_dgrad: stride 2 with ups 2 unsupported");
-  if (vcg_thin_fold_dgrad_ok(g)) return vcg_thin_fold_dgrad(g, dy, wf + wkd_offset(g), dx, ws, ws_bytes, (hipStream_t)stream);
+  if (vcg_thin_fold_dgrad_ok(g)) return vcg_thin_fold_dgrad(g, dy, wf + wkd_offset(g), vcg_pack_amax(g, wf), dx, ws, ws_bytes, (hipStream_t)stream);
   if (vcg_thin_dgrad_ok(g)) return vcg_thin_dgrad(g, dy, wf, dx, ws, ws_bytes, (hipStream_t)stream);
   if (vcg_wino_dgrad_ok(g))
-    return vcg_wino_dgrad(g, dy, wf + wf_floats(g) + wino_u_floats(g), dx, ws, ws_bytes, (hipStream_t)stream);
+    return vcg_wino_dgrad(g, dy, wf + wf_floats(g) + wino_u_floats(g), vcg_pack_amax(g, wf), dx, ws, ws_bytes, (hipStream_t)stream);
   if (dgrad_slab_ok(g))
-    return vcg_slab_dgrad(g, dy, wf + wfd_offset(g), wfd_floats(g) * 4, dx, ws, ws_bytes, (hipStream_t)stream);
+    return vcg_slab_dgrad(g, dy, wf + wfd_offset(g), wfd_floats(g) * 4, vcg_pack_amax(g, wf), dx, ws, ws_bytes, (hipStream_t)stream);
   ConvP p; fill_params(g, p);
   p.a = dy; p.b = wf; p.out = dx;
   {
@@ -2336,6 +2363,14 @@ extern "C" int vcg_conv_dgrad(const float* dy, const float* wf, float* dx, const
     // bf16 pipe when their tile is 128 x 64: the weight rows are split in the kernel from Wf
     const bool nopl64 = !planes && bm == 128 && bn == 64 && g.Cout % 4 == 0;
     const bool split = planes || bn == 32 || nopl64;
+    if (split) {                                            // fp16 x 2 kernels: the operands' largest magnitudes (vcg_common.h)
+      const VcgAmaxOut ad = vcg_amax_new(st);
+      if (vcg_absmax_launch(dy, (size_t)g.M * g.Cout, ad, st)) return -2;
+      // the kernel ADDS the sources that reflect padding folds onto a pixel before it splits the sum: up to 4 of them (9 on maps
+      // so small that a pixel has mirrors on both sides) — the operand is bounded by 2^4 x dy's largest magnitude, not by it
+      p.amax_a = vcg_amax_in(ad, g.reflect ? 4 : 0);
+      p.amax_b = vcg_amax_stored(vcg_pack_amax(g, wf));
+    }
     VcgProfScope prof(!split ? "k_conv_dgrad<fp32 MFMA>" : bn == 128 ? "k_conv_dgrad_split<128, 2>" : bn == 64 ? "k_conv_dgrad_split<64, 2>"
                                                                                                              : "k_conv_dgrad_split<32, 1>",
                       gemm_flops, st);
@@ -2435,13 +2470,14 @@ size_t vcg_wino_wgrad_core_workspace(const ConvGeom& g, int T) {
   return (size_t)wp.parts * 16 * q.K * q.Cout * sizeof(float) + 256;
 }
 int vcg_wino_wgrad_core(const ConvGeom& g, const float* V, const float* dM, int T, float* gw_oihw, void* ws, size_t ws_bytes,
-                        hipStream_t st) {
+                        hipStream_t st, const VcgAmax& amax_v, const VcgAmax& amax_dm) {
   const ConvGeom q = wino_gemm_geom(g, T);
   const WgradPlan wp = wgrad_plan(q, 16);
   VCG_CHECK_ARG(wp.grid > 0, "vcg_conv_wgrad: no launch plan for the Winograd path");
   VCG_CHECK_ARG(ws_bytes >= vcg_wino_wgrad_core_workspace(g, T), "vcg_conv_wgrad: Winograd slab workspace too small");
   ConvP p; fill_params(q, p);
   p.a = V; p.b = dM; p.out = (float*)ws;
+  p.amax_a = amax_v; p.amax_b = amax_dm;
   p.a_bytes = (uint32_t)((size_t)T * q.K * 4); p.b_bytes = (uint32_t)((size_t)T * q.Cout * 4);
   p.nbatch = 16; p.a_bstride = (uint32_t)((size_t)T * q.K); p.b_bstride = (uint32_t)((size_t)T * q.Cout);
   p.ktiles_total = wp.total; p.sk_len = wp.len; p.sk_units = wp.ntr * wp.ntn * wp.total; p.sk_ntn = wp.ntn;
@@ -2550,6 +2586,12 @@ extern "C" int vcg_conv_wgrad_saved(const float* x, const float* dy, float* gw_o
   p.fd_sklen = make_fastdiv((uint32_t)wp.len);
   dim3 grid(wp.grid);
   hipStream_t st = (hipStream_t)stream;
+  if (bm == 128) {                                          // fp16 x 2 kernel: both operands are activations, scaled by their own amax
+    const VcgAmaxOut aa = vcg_amax_new(st), ab = vcg_amax_new(st);
+    if (vcg_absmax_launch(p.a, (size_t)p.a_bytes / 4, aa, st) || vcg_absmax_launch(p.b, (size_t)p.b_bytes / 4, ab, st)) return -2;
+    // swapped roles: the rows are gathered from dy through the adjoint of the padding, i.e. as sums of up to 4 (9) sources
+    p.amax_a = vcg_amax_in(aa, (swapped && gorig.reflect) ? 4 : 0); p.amax_b = vcg_amax_in(ab);
+  }
   {
     VcgProfScope prof(bm == 128 ? (bn == 128 ? "k_conv_wgrad_split<128>" : "k_conv_wgrad_split<64>") : "k_conv_wgrad<fp32 MFMA>",
                       2.0 * g.M * (double)g.K * g.Cout, st);

@@ -36,6 +36,7 @@ struct RingP {
   int r_ups, r_gpp;       // U mode with a folded PixelUnshuffle: the ring tensor is (N, Hr * ups, Wr * ups, Cr), channel group z holds
                           // phase z / r_gpp (i = phase >> 1, j = phase & 1), channels 32 * (z % r_gpp) .. + 31   (ups 1: r_gpp = Cr / 32)
   uint32_t ring_bytes, wide_bytes;
+  VcgAmax amax_r, amax_w;   // largest magnitudes of the ring and of the wide tensor (fp16 x 2 operand scales, vcg_common.h)
 };
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t rg_srd(const void* ptr, uint32_t bytes) {
@@ -51,11 +52,11 @@ __device__ __forceinline__ uint32_t rg_woff(int row, int col) {
   return (uint32_t)(128 * row + 16 * ((col >> 3) ^ f) + (col & 7) * 2);
 }
 typedef __attribute__((address_space(3))) unsigned char rg_lds_t;       // 32-bit LDS addresses: no flat-pointer arithmetic per fragment
-__device__ __forceinline__ bf16x8 rg_tr2(rg_lds_t* a0, rg_lds_t* a1) {
+__device__ __forceinline__ f16x8 rg_tr2(rg_lds_t* a0, rg_lds_t* a1) {
   const rg_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) rg_s16x4*)a0);
   const rg_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) rg_s16x4*)a1);
   const rg_s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-  return __builtin_bit_cast(bf16x8, v);
+  return __builtin_bit_cast(f16x8, v);
 }
 
 template <bool THIN>
@@ -66,8 +67,12 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_ring(RingP p) {
   constexpr int RQ = THIN ? RPX : RPX * 8;                   // float4 quads per ring row segment
   constexpr int RA = (RQ + 255) / 256;
   constexpr int MAXT = THIN ? 4 : 5;                         // accumulator tiles per wave
-  __shared__ __attribute__((aligned(16))) unsigned char Rs[SLOTS][3][RPX * RROW];
-  __shared__ __attribute__((aligned(16))) unsigned char Ws[2][3][32 * 128];
+  __shared__ __attribute__((aligned(16))) unsigned char Rs[SLOTS][VCG_NP][RPX * RROW];
+  __shared__ __attribute__((aligned(16))) unsigned char Ws[2][VCG_NP][32 * 128];
+  float sR, invR, sW, invW;
+  vcg_scale_of(vcg_amax_bits(p.amax_r), p.amax_r.shift, sR, invR);
+  vcg_scale_of(vcg_amax_bits(p.amax_w), p.amax_w.shift, sW, invW);
+  const float oscale = sR * sW;
   const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform, and known to be
   const int l31 = lane & 31, lh = lane >> 5;
   const int nb = wid & 1, th = wid >> 1;
@@ -156,11 +161,10 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_ring(RingP p) {
 #pragma unroll
     for (int a = 0; a < RA; ++a) {
       if (rlds[a] == RG_OOB) continue;
-      uint2 h, m, l;
-      split4(vr[a], h, m, l);
+      uint2 h, l;
+      split4h(vr[a], invR, h, l);
       *reinterpret_cast<uint2*>(&Rs[slot][0][rlds[a]]) = h;
-      *reinterpret_cast<uint2*>(&Rs[slot][1][rlds[a]]) = m;
-      *reinterpret_cast<uint2*>(&Rs[slot][2][rlds[a]]) = l;
+      *reinterpret_cast<uint2*>(&Rs[slot][1][rlds[a]]) = l;
     }
   };
   auto load_wide = [&](int y) {
@@ -171,11 +175,10 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_ring(RingP p) {
   auto store_wide = [&](int buf) {
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
-      uint2 h, m, l;
-      split4(vw[e], h, m, l);
+      uint2 h, l;
+      split4h(vw[e], invW, h, l);
       *reinterpret_cast<uint2*>(&Ws[buf][0][wlds[e]]) = h;
-      *reinterpret_cast<uint2*>(&Ws[buf][1][wlds[e]]) = m;
-      *reinterpret_cast<uint2*>(&Ws[buf][2][wlds[e]]) = l;
+      *reinterpret_cast<uint2*>(&Ws[buf][1][wlds[e]]) = l;
     }
   };
 
@@ -191,7 +194,7 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_ring(RingP p) {
   const int tcol = 16 * g16 + 4 * tp;
   rg_lds_t* const ldsR = (rg_lds_t*)&Rs[0][0][0];
   rg_lds_t* const ldsW = (rg_lds_t*)&Ws[0][0][0];
-  constexpr int RPIECE = RPX * RROW, RSLOT = 3 * RPIECE, WPIECE = 32 * 128, WBUF = 3 * WPIECE;
+  constexpr int RPIECE = RPX * RROW, RSLOT = VCG_NP * RPIECE, WPIECE = 32 * 128, WBUF = VCG_NP * WPIECE;
 
   if (y0 < y1) {
     for (int k = 0; k < KH; ++k) {                          // the first step's tap rows
@@ -212,9 +215,9 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_ring(RingP p) {
 #pragma unroll
     for (int s2 = 0; s2 < 2; ++s2) {
       const int row0 = 16 * s2 + 8 * lh + tq;                // reduction row (segment pixel) of this lane's first read
-      bf16x8 bfr[3];
+      f16x8 bfr[VCG_NP];
 #pragma unroll
-      for (int pc = 0; pc < 3; ++pc)
+      for (int pc = 0; pc < VCG_NP; ++pc)
         bfr[pc] = rg_tr2(ldsW + buf * WBUF + pc * WPIECE + rg_woff(row0, nb * 32 + tcol),
                          ldsW + buf * WBUF + pc * WPIECE + rg_woff(row0 + 4, nb * 32 + tcol));
 #pragma unroll
@@ -230,19 +233,16 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_ring(RingP p) {
           slot = (y + kh) % SLOTS;
           off = (row0 + kw) * 64 + tcol * 2;
         }
-        bf16x8 af[3];
+        f16x8 af[VCG_NP];
 #pragma unroll
-        for (int pc = 0; pc < 3; ++pc)
+        for (int pc = 0; pc < VCG_NP; ++pc)
           af[pc] = rg_tr2(ldsR + slot * RSLOT + pc * RPIECE + off, ldsR + slot * RSLOT + pc * RPIECE + off + 4 * RROW);
         f32x16 c;
 #pragma unroll
         for (int e = 0; e < 16; ++e) c[e] = 0.f;
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bfr[1], c, 0, 0, 0);       // smallest contributions first
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2], bfr[0], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bfr[2], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bfr[0], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bfr[1], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bfr[0], c, 0, 0, 0);
+        c = VCG_MFMA(af[1], bfr[0], c);                     // smallest contributions first
+        c = VCG_MFMA(af[0], bfr[1], c);
+        c = VCG_MFMA(af[0], bfr[0], c);
         acc[t] += c;
         asm volatile("" : "+v"(acc[t]));                     // pin the add here: sunk to the end of the step, all chains stay live
         __builtin_amdgcn_sched_barrier(0);                   // keep one tap's fragments and chain live at a time (register budget)
@@ -265,7 +265,7 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_ring(RingP p) {
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
       const int m = (e & 3) + 8 * (e >> 2) + 4 * lh;
-      slab[(size_t)(tap * 32 + m) * 64 + nb * 32 + l31] = acc[t][e];
+      slab[(size_t)(tap * 32 + m) * 64 + nb * 32 + l31] = acc[t][e] * oscale;
     }
   }
 }
@@ -376,6 +376,11 @@ int vcg_ring_wgrad(const ConvGeom& g, const float* x, const float* dy, float* gw
     p.w_reflect = 0; p.w_off = 0;
   }
   p.r_ups = mode == 0 ? g.ups : 1; p.r_gpp = mode == 0 ? g.Cin / 32 : 1;
+  {
+    const VcgAmaxOut ar = vcg_amax_new(st), aw = vcg_amax_new(st);
+    if (vcg_absmax_launch(p.ring, (size_t)p.ring_bytes / 4, ar, st) || vcg_absmax_launch(p.wide, (size_t)p.wide_bytes / 4, aw, st)) return -2;
+    p.amax_r = vcg_amax_in(ar); p.amax_w = vcg_amax_in(aw);
+  }
   p.nseg = pl.nseg; p.nrs = pl.nrs; p.rows_per_band = pl.rows;
   p.slabs = (float*)ws;
   const dim3 grid(pl.nwg, pl.ntiles, pl.ngroups);

@@ -21,7 +21,7 @@ typedef unsigned int sl_u32x4 __attribute__((ext_vector_type(4)));
 
 struct SlabP {
   const float* in;          // (N, H, W, C) fp32
-  const void* planes;       // weight planes, 192 bytes per (row, 32-k block): 3 pieces x 32 bf16
+  const void* planes;       // weight planes, VCG_PBYTES per (row, 32-k block): VCG_NP pieces x 32 fp16 of w / sB (vcg_common.h)
   const float* bias;
   float* out;               // (N, Ho, Wo, Cout)
   double* in_part;          // InstanceNorm chunk partials [N][nchunk][Cout][2], or null
@@ -29,6 +29,7 @@ struct SlabP {
   int pad, reflect, act, tap_flip, nchunks, in_nchunk;
   int nbx, nby;             // pixel blocks per image
   uint32_t in_bytes, b_bytes, row_stride, tap_stride;
+  VcgAmax amax_a, amax_b;   // largest magnitudes of the input tensor and of the kernel the planes were split from
 };
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t sl_srd(const void* ptr, uint32_t bytes) {
@@ -42,11 +43,16 @@ __global__ __launch_bounds__(256, 2) void k_conv_slab(SlabP p) {
   static_assert(WM * WN == 4, "four waves");
   constexpr int BM = 64 * WM, BN = 32 * WN, PR = BM / 16, SH = PR + KH - 1, SW = 16 + KW - 1, SPX = SH * SW, NTAP = KH * KW;
   constexpr int AQ = (SPX * 8 + 255) / 256;                  // slab quads per thread
-  constexpr int BQ = (BN * 12 + 255) / 256;                  // 16-byte weight chunks per thread and tap
-  __shared__ __attribute__((aligned(16))) unsigned char As[3][SPX * 64];
-  __shared__ __attribute__((aligned(16))) unsigned char Bs[2][3][BN * 64];
+  constexpr int CPR = 4 * VCG_NP;                            // 16-byte chunks per weight row and 32-k block
+  constexpr int BQ = (BN * CPR + 255) / 256;                 // 16-byte weight chunks per thread and tap
+  __shared__ __attribute__((aligned(16))) unsigned char As[VCG_NP][SPX * 64];
+  __shared__ __attribute__((aligned(16))) unsigned char Bs[2][VCG_NP][BN * 64];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid / WN, wn = wid % WN, l31 = lane & 31, lh = lane >> 5;
+  float sA, invA, sB, invB;
+  vcg_scale_of(vcg_amax_bits(p.amax_a), p.amax_a.shift, sA, invA);
+  vcg_scale_of(vcg_amax_bits(p.amax_b), p.amax_b.shift, sB, invB);
+  const float oscale = sA * sB;
 
   int blk = blockIdx.x;
   const int n = blk / (p.nbx * p.nby);
@@ -82,7 +88,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_slab(SlabP p) {
 #pragma unroll
   for (int j = 0; j < BQ; ++j) {
     const int idx = tid + 256 * j;
-    const int row = idx / 12, r12 = idx - row * 12, pc = r12 >> 2, q = r12 & 3;
+    const int row = idx / CPR, r12 = idx - row * CPR, pc = r12 >> 2, q = r12 & 3;
     const bool ok = row < BN;
     boff[j] = ok ? (uint32_t)(n0 + row) * p.row_stride + (uint32_t)(r12 * 16) : SL_OOB;
     bsoff[j] = ok ? (uint32_t)(row * 64 + ((q ^ ((row >> 2) & 3)) << 4)) : SL_OOB;
@@ -109,7 +115,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_slab(SlabP p) {
   sl_u32x4 vb[BQ];
   auto load_b = [&](int chunk, int tap) {
     const uint32_t t = (uint32_t)(p.tap_flip ? NTAP - 1 - tap : tap);
-    const uint32_t o = t * p.tap_stride + (uint32_t)chunk * 192u;
+    const uint32_t o = t * p.tap_stride + (uint32_t)chunk * (uint32_t)VCG_PBYTES;
 #pragma unroll
     for (int j = 0; j < BQ; ++j) vb[j] = __builtin_amdgcn_raw_buffer_load_b128(rb, (int)(boff[j] != SL_OOB ? boff[j] + o : SL_OOB), 0, 0);
   };
@@ -134,11 +140,10 @@ __global__ __launch_bounds__(256, 2) void k_conv_slab(SlabP p) {
 #pragma unroll
       for (int a = 0; a < AQ; ++a) {
         if (soff[a] == SL_OOB) continue;
-        uint2 h, m, l;
-        split4(va[a], h, m, l);
+        uint2 h, l;
+        split4h(va[a], invA, h, l);
         *reinterpret_cast<uint2*>(&As[0][soff[a]]) = h;
-        *reinterpret_cast<uint2*>(&As[1][soff[a]]) = m;
-        *reinterpret_cast<uint2*>(&As[2][soff[a]]) = l;
+        *reinterpret_cast<uint2*>(&As[1][soff[a]]) = l;
       }
       if (chunk == 0) store_b(0);
       __syncthreads();
@@ -158,23 +163,20 @@ __global__ __launch_bounds__(256, 2) void k_conv_slab(SlabP p) {
       }
 #pragma unroll
       for (int k2 = 0; k2 < 2; ++k2) {
-        bf16x8 a[3][2], b[3];
+        f16x8 a[VCG_NP][2], b[VCG_NP];
 #pragma unroll
-        for (int pc = 0; pc < 3; ++pc) {
+        for (int pc = 0; pc < VCG_NP; ++pc) {
 #pragma unroll
-          for (int i = 0; i < 2; ++i) a[pc][i] = *reinterpret_cast<const bf16x8*>(&As[pc][fa[i] + (((2 * k2 + lh) ^ sa[i]) << 4)]);
-          b[pc] = *reinterpret_cast<const bf16x8*>(&Bs[buf][pc][fb + (((2 * k2 + lh) ^ sb) << 4)]);
+          for (int i = 0; i < 2; ++i) a[pc][i] = *reinterpret_cast<const f16x8*>(&As[pc][fa[i] + (((2 * k2 + lh) ^ sa[i]) << 4)]);
+          b[pc] = *reinterpret_cast<const f16x8*>(&Bs[buf][pc][fb + (((2 * k2 + lh) ^ sb) << 4)]);
         }
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
           f32x16 c = lo[i];
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][i], b[1], c, 0, 0, 0);       // smallest contributions first
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2][i], b[0], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[2], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][i], b[0], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[1], c, 0, 0, 0);
+          c = VCG_MFMA(a[1][i], b[0], c);                  // the cross terms in their own chain
+          c = VCG_MFMA(a[0][i], b[1], c);
           lo[i] = c;
-          acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[0], acc[i], 0, 0, 0);
+          acc[i] = VCG_MFMA(a[0][i], b[0], acc[i]);
         }
       }
       if (more) store_b(buf ^ 1);                         // the buffer tap s - 1 read: every wave passed the barrier after it
@@ -195,7 +197,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_slab(SlabP p) {
       const int row = (e & 3) + 8 * (e >> 2) + 4 * lh;
       const int m = wm * 64 + i * 32 + row;
       const int oy = oy0 + (m >> 4), ox = ox0 + (m & 15);
-      const float v = act_apply(acc[i][e] + lo[i][e] + bv, p.act);
+      const float v = act_apply((acc[i][e] + lo[i][e]) * oscale + bv, p.act);
       if (cv && oy < p.Ho && ox < p.Wo) p.out[(((size_t)n * p.Ho + oy) * p.Wo + ox) * p.Cout + co] = v;
       s1 += v;
       s2 += v * v;
@@ -271,9 +273,14 @@ bool vcg_slab_dgrad_ok(const ConvGeom& g) {
 }
 size_t vcg_slab_dgrad_workspace(const ConvGeom& g) { return (size_t)g.N * (g.H + 2) * (g.W + 2) * g.Cin * sizeof(float) + 256; }
 
-int vcg_slab_fwd(const ConvGeom& g, const float* x, const void* wft_planes, size_t planes_bytes, const float* bias, float* y,
-                 double* in_part, int* in_nchunk, hipStream_t st) {
+int vcg_slab_fwd(const ConvGeom& g, const float* x, const void* wft_planes, size_t planes_bytes, const void* w_amax, const float* bias,
+                 float* y, double* in_part, int* in_nchunk, hipStream_t st) {
   SlabP p = {};
+  {
+    const VcgAmaxOut ax = vcg_amax_new(st);
+    if (vcg_absmax_launch(x, (size_t)g.N * g.H * g.W * g.Cin, ax, st)) return -2;
+    p.amax_a = vcg_amax_in(ax); p.amax_b = vcg_amax_stored(w_amax);
+  }
   p.in = x; p.planes = wft_planes; p.bias = bias; p.out = y; p.in_part = in_part;
   p.N = g.N; p.H = g.H; p.W = g.W; p.C = g.Cin; p.Ho = g.Ho; p.Wo = g.Wo; p.Cout = g.Cout; p.cout_log = g.cout_log;
   p.pad = 1; p.reflect = g.reflect; p.act = g.act; p.tap_flip = 0; p.nchunks = g.Cin / 32;
@@ -283,7 +290,7 @@ int vcg_slab_fwd(const ConvGeom& g, const float* x, const void* wft_planes, size
   const unsigned long long ab = (unsigned long long)g.N * g.H * g.W * g.Cin * 4;
   VCG_CHECK_ARG(ab < (1ull << 31) && planes_bytes < (1ull << 31), "vcg_conv_fwd: tensor extents must stay below 2 GiB");
   p.in_bytes = (uint32_t)ab; p.b_bytes = (uint32_t)planes_bytes;
-  p.row_stride = (uint32_t)(9 * (g.Cin / 32) * 192); p.tap_stride = (uint32_t)((g.Cin / 32) * 192);
+  p.row_stride = (uint32_t)(9 * (g.Cin / 32) * VCG_PBYTES); p.tap_stride = (uint32_t)((g.Cin / 32) * VCG_PBYTES);
   {
     VcgProfScope prof("k_conv_slab<2, 2, 3, 3>", 2.0 * g.M * (double)g.K * g.Cout, st);
     hipLaunchKernelGGL((k_conv_slab<2, 2, 3, 3>), dim3(g.N * p.nbx * p.nby, g.Cout / 64), dim3(256), 0, st, p);
@@ -292,10 +299,15 @@ int vcg_slab_fwd(const ConvGeom& g, const float* x, const void* wft_planes, size
   return 0;
 }
 
-int vcg_slab_dgrad(const ConvGeom& g, const float* dy, const void* wfd_planes, size_t planes_bytes, float* dx, void* ws,
-                   size_t ws_bytes, hipStream_t st) {
+int vcg_slab_dgrad(const ConvGeom& g, const float* dy, const void* wfd_planes, size_t planes_bytes, const void* w_amax, float* dx,
+                   void* ws, size_t ws_bytes, hipStream_t st) {
   VCG_CHECK_ARG(ws && ws_bytes >= vcg_slab_dgrad_workspace(g), "vcg_conv_dgrad(slab): workspace too small");
   SlabP p = {};
+  {
+    const VcgAmaxOut ad = vcg_amax_new(st);
+    if (vcg_absmax_launch(dy, (size_t)g.N * g.Ho * g.Wo * g.Cout, ad, st)) return -2;
+    p.amax_a = vcg_amax_in(ad); p.amax_b = vcg_amax_stored(w_amax);
+  }
   p.in = dy; p.planes = wfd_planes; p.bias = nullptr; p.out = (float*)ws; p.in_part = nullptr;
   p.N = g.N; p.H = g.Ho; p.W = g.Wo; p.C = g.Cout; p.Ho = g.H + 2; p.Wo = g.W + 2; p.Cout = g.Cin; p.cout_log = g.Cin;
   p.pad = 2; p.reflect = 0; p.act = VCG_ACT_NONE; p.tap_flip = 1; p.nchunks = g.Cout / 32;
@@ -304,7 +316,7 @@ int vcg_slab_dgrad(const ConvGeom& g, const float* dy, const void* wfd_planes, s
   const unsigned long long ab = (unsigned long long)g.N * g.Ho * g.Wo * g.Cout * 4;
   VCG_CHECK_ARG(ab < (1ull << 31) && planes_bytes < (1ull << 31), "vcg_conv_dgrad: tensor extents must stay below 2 GiB");
   p.in_bytes = (uint32_t)ab; p.b_bytes = (uint32_t)planes_bytes;
-  p.row_stride = (uint32_t)((g.Cout / 32) * 192); p.tap_stride = (uint32_t)(g.Cin * (g.Cout / 32) * 192);
+  p.row_stride = (uint32_t)((g.Cout / 32) * VCG_PBYTES); p.tap_stride = (uint32_t)(g.Cin * (g.Cout / 32) * VCG_PBYTES);
   {
     const double flops = 2.0 * g.N * (double)p.Ho * p.Wo * 9.0 * g.Cout * g.Cin;
     VcgProfScope prof(wide ? "k_conv_slab<4, 1, 3, 3>" : "k_conv_slab<2, 2, 3, 3>", flops, st);
@@ -321,13 +333,18 @@ int vcg_slab_dgrad(const ConvGeom& g, const float* dy, const void* wfd_planes, s
 }
 
 // ---- the (KH x 1) convolution of the kw-folded thin layers (conv_thin.hip): P[n][oh][pc][32] over the padded columns --------
-// planes: [32 rows = (kw, co)][KH * C / 32 blocks][3][32], k = (kh, c).  Reflect or zero padding `pad` on both axes (the
+// planes: [32 rows = (kw, co)][KH * C / 32 blocks][VCG_NP][32], k = (kh, c).  Reflect or zero padding `pad` on both axes (the
 // column taps being part of N, a padded column pc simply reads input column reflect(pc - pad)).
 bool vcg_slab_col_ok(int KH, int C) { return KH == 7 && C % 32 == 0 && C <= 128; }
-int vcg_slab_col(const float* x, const void* planes, size_t planes_bytes, float* P, int N, int H, int W, int C, int Ho, int Wo,
-                 int KH, int pad, int reflect, hipStream_t st) {
+int vcg_slab_col(const float* x, const void* planes, size_t planes_bytes, const void* w_amax, float* P, int N, int H, int W, int C,
+                 int Ho, int Wo, int KH, int pad, int reflect, hipStream_t st) {
   VCG_CHECK_ARG(vcg_slab_col_ok(KH, C), "vcg_conv(kw-fold slab): unsupported KH=%d C=%d", KH, C);
   SlabP p = {};
+  {
+    const VcgAmaxOut ax = vcg_amax_new(st);
+    if (vcg_absmax_launch(x, (size_t)N * H * W * C, ax, st)) return -2;
+    p.amax_a = vcg_amax_in(ax); p.amax_b = vcg_amax_stored(w_amax);
+  }
   p.in = x; p.planes = planes; p.bias = nullptr; p.out = P; p.in_part = nullptr;
   p.N = N; p.H = H; p.W = W; p.C = C; p.Ho = Ho; p.Wo = Wo; p.Cout = 32; p.cout_log = 32;
   p.pad = pad; p.reflect = reflect; p.act = VCG_ACT_NONE; p.tap_flip = 0; p.nchunks = C / 32;
@@ -335,7 +352,7 @@ int vcg_slab_col(const float* x, const void* planes, size_t planes_bytes, float*
   const unsigned long long ab = (unsigned long long)N * H * W * C * 4;
   VCG_CHECK_ARG(ab < (1ull << 31) && planes_bytes < (1ull << 31), "vcg_conv(kw-fold slab): tensor extents must stay below 2 GiB");
   p.in_bytes = (uint32_t)ab; p.b_bytes = (uint32_t)planes_bytes;
-  p.row_stride = (uint32_t)(KH * (C / 32) * 192); p.tap_stride = (uint32_t)((C / 32) * 192);
+  p.row_stride = (uint32_t)(KH * (C / 32) * VCG_PBYTES); p.tap_stride = (uint32_t)((C / 32) * VCG_PBYTES);
   {
     VcgProfScope prof("k_conv_slab<4, 1, 7, 1>", 2.0 * N * (double)Ho * Wo * KH * C * 32, st);
     hipLaunchKernelGGL((k_conv_slab<4, 1, 7, 1>), dim3(N * p.nbx * p.nby, 1), dim3(256), 0, st, p);

@@ -147,30 +147,31 @@ size_t vcg_thin_dgrad_workspace(const ConvGeom& g) {
 int vcg_fwd_launch(const ConvGeom& g, const float* x, const float* wf, float* y, hipStream_t st);
 // conv_slab.hip: the same (KH x 1) convolution on the split-operand bf16 pipe, the input rows staged once per workgroup
 bool vcg_slab_col_ok(int KH, int C);
-int vcg_slab_col(const float* x, const void* planes, size_t planes_bytes, float* P, int N, int H, int W, int C, int Ho, int Wo,
+int vcg_slab_col(const float* x, const void* planes, size_t planes_bytes, const void* w_amax, float* P, int N, int H, int W, int C, int Ho, int Wo,
                  int KH, int pad, int reflect, hipStream_t st);
-// Wk / Wkd are followed by their pre-split planes [32 rows (kw, co)][KH C / 32][3 pieces][32 k] when that kernel can take the layer
-static size_t fold_planes_floats(int KH, int C) { return vcg_slab_col_ok(KH, C) ? (size_t)KH * C * 48 : 0; }
+// Wk / Wkd are followed by their pre-split planes [32 rows (kw, co)][KH C / 32][VCG_NP pieces][32 k] when that kernel can take the layer
+static size_t fold_planes_floats(int KH, int C) { return vcg_slab_col_ok(KH, C) ? (size_t)KH * C * VCG_PFLOATS : 0; }
 // planes of a packed fold matrix wk[(kh, c)][32] (fp32): one thread per (row n, 4 consecutive k)
-__global__ __launch_bounds__(256) void k_fold_planes(const float* __restrict__ wk, unsigned short* __restrict__ bp, int K) {
+__global__ __launch_bounds__(256) void k_fold_planes(const float* __restrict__ wk, unsigned short* __restrict__ bp, int K, VcgAmax amax) {
+  float sc, inv;                                                   // the planes hold wk / s, s from the kernel's amax (vcg_common.h)
+  vcg_scale_of(vcg_amax_bits(amax), amax.shift, sc, inv);
   const int total = 32 * (K / 4);
   for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
     const int n = idx / (K / 4), k0 = (idx - n * (K / 4)) * 4;
     const float4 v = make_float4(wk[(size_t)(k0 + 0) * 32 + n], wk[(size_t)(k0 + 1) * 32 + n], wk[(size_t)(k0 + 2) * 32 + n],
                                  wk[(size_t)(k0 + 3) * 32 + n]);
-    uint2 h, m, l;
-    split4(v, h, m, l);
-    unsigned short* o = bp + ((size_t)n * (K / 32) + k0 / 32) * 96 + (k0 & 31);
+    uint2 h, l;
+    split4h(v, inv, h, l);
+    unsigned short* o = bp + ((size_t)n * (K / 32) + k0 / 32) * VCG_PBLK + (k0 & 31);
     *reinterpret_cast<uint2*>(o) = h;
-    *reinterpret_cast<uint2*>(o + 32) = m;
-    *reinterpret_cast<uint2*>(o + 64) = l;
+    *reinterpret_cast<uint2*>(o + 32) = l;
   }
 }
-static int pack_fold_planes(float* wk, int KH, int C, hipStream_t st) {
+static int pack_fold_planes(float* wk, int KH, int C, const VcgAmax& amax_w, hipStream_t st) {
   if (!fold_planes_floats(KH, C)) return 0;
   const int K = KH * C;
   hipLaunchKernelGGL(k_fold_planes, dim3((32 * (K / 4) + 255) / 256), dim3(256), 0, st, (const float*)wk,
-                     (unsigned short*)(wk + (size_t)K * 32), K);
+                     (unsigned short*)(wk + (size_t)K * 32), K, amax_w);
   VCG_LAUNCH_CHECK("vcg_pack_weight(kw-fold planes)");
   return 0;
 }
@@ -209,12 +210,12 @@ __global__ __launch_bounds__(256) void k_pack_kwfold_dgrad(const float* __restri
 }
 bool vcg_thin_fold_dgrad_ok(const ConvGeom& g) { return vcg_thin_dgrad_ok(g) && g.KW * 4 <= 32 && g.cin_log <= 3; }
 size_t vcg_thin_fold_dgrad_weight_floats(const ConvGeom& g) { return (size_t)g.KH * g.Cout * 32 + fold_planes_floats(g.KH, g.Cout); }
-int vcg_thin_fold_dgrad_pack(const ConvGeom& g, const float* w_oihw, float* wk, hipStream_t st) {
+int vcg_thin_fold_dgrad_pack(const ConvGeom& g, const float* w_oihw, float* wk, const VcgAmax& amax_w, hipStream_t st) {
   const int total = g.KH * g.Cout * 32;
   hipLaunchKernelGGL(k_pack_kwfold_dgrad, dim3((total + 255) / 256), dim3(256), 0, st, w_oihw, wk, g.Cout, g.cin_log,
                      g.cout_log, g.KH, g.KW);
   VCG_LAUNCH_CHECK("vcg_pack_weight(kw-fold dgrad)");
-  return pack_fold_planes(wk, g.KH, g.Cout, st);
+  return pack_fold_planes(wk, g.KH, g.Cout, amax_w, st);
 }
 // geometry of the full correlation over the padded domain: dy (N, Ho, Wo, Cout) -> dxp (N, H + 2 pad, W + 2 pad, 4)
 static ConvGeom thin_dgrad_as_fwd(const ConvGeom& g) {
@@ -230,12 +231,12 @@ size_t vcg_thin_fold_dgrad_workspace(const ConvGeom& g) {
   return vcg_thin_dgrad_workspace(g) + 256 + vcg_thin_fold_workspace(f);
 }
 
-int vcg_thin_fold_pack(const ConvGeom& g, const float* w_oihw, float* wk, hipStream_t st) {
+int vcg_thin_fold_pack(const ConvGeom& g, const float* w_oihw, float* wk, const VcgAmax& amax_w, hipStream_t st) {
   const int total = g.KH * g.Cin * 32;
   hipLaunchKernelGGL(k_pack_kwfold, dim3((total + 255) / 256), dim3(256), 0, st, w_oihw, wk, g.Cin, g.cin_log, g.cout_log, g.KH,
                      g.KW);
   VCG_LAUNCH_CHECK("vcg_pack_weight(kw-fold)");
-  return pack_fold_planes(wk, g.KH, g.Cin, st);
+  return pack_fold_planes(wk, g.KH, g.Cin, amax_w, st);
 }
 __global__ __launch_bounds__(256) void k_kwfold_sum(const float* __restrict__ P, const float* __restrict__ bias,
                                                     float* __restrict__ y, int N, int H, int W, int Wp, int KW, int n_out,
@@ -262,14 +263,14 @@ __global__ __launch_bounds__(256) void k_kwfold_sum(const float* __restrict__ P,
     *reinterpret_cast<float4*>(y + idx * 4) = s;
   }
 }
-int vcg_thin_fold_fwd(const ConvGeom& g, const float* x, const float* wk, const float* bias, float* y, void* ws, size_t ws_bytes,
-                      hipStream_t st) {
+int vcg_thin_fold_fwd(const ConvGeom& g, const float* x, const float* wk, const void* w_amax, const float* bias, float* y, void* ws,
+                      size_t ws_bytes, hipStream_t st) {
   VCG_CHECK_ARG(ws && ws_bytes >= vcg_thin_fold_workspace(g), "vcg_conv_fwd: workspace too small for the kw-folded path");
   ConvGeom q = g;                                 // the (KH x 1) convolution over every padded column
   q.KW = 1; q.Cout = 32; q.cout_log = g.KW * 4; q.act = VCG_ACT_NONE;
   q.Wo = g.W + 2 * g.pad; q.Ho = g.Ho; q.M = g.N * q.Ho * q.Wo; q.taps = g.KH; q.K = g.KH * g.Cin;
   if (fold_planes_floats(g.KH, g.Cin)) {
-    if (vcg_slab_col(x, wk + (size_t)g.KH * g.Cin * 32, fold_planes_floats(g.KH, g.Cin) * 4, (float*)ws, g.N, g.H, g.W, g.Cin, q.Ho,
+    if (vcg_slab_col(x, wk + (size_t)g.KH * g.Cin * 32, fold_planes_floats(g.KH, g.Cin) * 4, w_amax, (float*)ws, g.N, g.H, g.W, g.Cin, q.Ho,
                      q.Wo, g.KH, g.pad, g.reflect, st))
       return -2;
   } else if (vcg_fwd_launch(q, x, wk, (float*)ws, st)) {
@@ -299,13 +300,13 @@ int vcg_thin_fwd(const ConvGeom& g, const float* x, const float* wf, const float
   return 0;
 }
 
-int vcg_thin_fold_dgrad(const ConvGeom& g, const float* dy, const float* wkd, float* dx, void* ws, size_t ws_bytes,
+int vcg_thin_fold_dgrad(const ConvGeom& g, const float* dy, const float* wkd, const void* w_amax, float* dx, void* ws, size_t ws_bytes,
                         hipStream_t st) {
   VCG_CHECK_ARG(ws && ws_bytes >= vcg_thin_fold_dgrad_workspace(g), "vcg_conv_dgrad(kw-fold): workspace too small");
   const ConvGeom f = thin_dgrad_as_fwd(g);
   float* dxp = (float*)ws;
   char* ws2 = (char*)ws + ((vcg_thin_dgrad_workspace(g) + 255) / 256) * 256;
-  if (vcg_thin_fold_fwd(f, dy, wkd, nullptr, dxp, ws2, ws_bytes - (size_t)(ws2 - (char*)ws), st)) return -2;
+  if (vcg_thin_fold_fwd(f, dy, wkd, w_amax, nullptr, dxp, ws2, ws_bytes - (size_t)(ws2 - (char*)ws), st)) return -2;
   size_t total = (size_t)g.N * g.H * g.W;
   int blocks = (int)((total + 255) / 256);
   if (blocks > 2048) blocks = 2048;

@@ -13,22 +13,10 @@
 #include "vcg_common.h"
 #include <stdlib.h>
 
-int vcg_gemm_split_batched(const float* A, const void* BtPlanes, float* C, int rows, int K, int N, int batches, hipStream_t st);
-// gemm_ws.hip: the 16 GEMMs with the input transform B^T d B computed by the kernel's producer waves (V never written)
-bool vcg_gemm_ws_enabled();
-int vcg_gemm_ws_wino(const float* x, const void* UPlanes, float* M, int Nimg, int H, int W, int Cin, int Hl, int Wl, int ups,
-                     int reflect, int off, int th, int tw, int Ncols, hipStream_t st);
-// VCG_WINO_FUSED=0: always materialise V with k_wino_in (A/B measurements).  Fused where it costs no repeated transform work:
-// at most `VCG_WINO_FUSED` N tiles of 128 columns (default 2: D1 and U2 forward, D1 / U2 / U1 data gradient) and nobody else
-// wants V (the weight gradient of D2 ... R takes the forward's V: those layers keep k_wino_in)
-static int wino_fused_max_ntiles() {
-  static const int v = [] { const char* e = getenv("VCG_WINO_FUSED"); return e ? atoi(e) : 2; }();
-  return v;
-}
-static bool wino_fused_ok(int cin_phys, int ncols, unsigned long long image_bytes) {
-  return vcg_gemm_ws_enabled() && cin_phys % 32 == 0 && ncols % 128 == 0 && ncols / 128 <= wino_fused_max_ntiles() &&
-         image_bytes < (1ull << 31);
-}
+int vcg_gemm_split_batched(const float* A, const void* BtPlanes, float* C, int rows, int K, int N, int batches, const VcgAmax& amax_a,
+                           const VcgAmax& amax_b, hipStream_t st, uint32_t* amax_a_keep = nullptr);
+// |G g G^T| <= (1.5)^2 max|g|: the transformed kernels are bounded by 4 x the kernel's largest magnitude
+#define WINO_U_SHIFT 2
 
 struct WinoP {
   const float* x;
@@ -40,6 +28,8 @@ struct WinoP {
   int th, tw, T, Kc;
   int off;     // patch origin = 2 * tile - off: 1 (pad 1) forward, 2 for the data gradient over the padded domain
   FastDiv fd_k4, fd_tw, fd_thtw, fd_c4, fd_co4;
+  unsigned long long* amax_slot;   // k_wino_in / k_wino_dy: where the largest magnitude of what they write goes (vcg_common.h), or null
+  uint32_t amax_gen;
 };
 
 __device__ __forceinline__ float4 f4sub(const float4& a, const float4& b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
@@ -47,6 +37,8 @@ __device__ __forceinline__ float4 f4sum(const float4& a, const float4& b) { retu
 
 // one thread: one tile x 4 consecutive k (same unshuffle phase (i, j), channels c..c+3)
 __global__ __launch_bounds__(256) void k_wino_in(WinoP p) {
+  __shared__ uint32_t amax_red[4];
+  uint32_t amax = 0;
   const uint32_t k4n = (uint32_t)p.Kc / 4;
   const size_t total = (size_t)p.T * k4n;
   for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
@@ -90,12 +82,16 @@ __global__ __launch_bounds__(256) void k_wino_in(WinoP p) {
     const size_t plane = (size_t)p.T * p.Kc;
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
-      *reinterpret_cast<float4*>(vb + (size_t)(a * 4 + 0) * plane) = f4sub(e[a][0], e[a][2]);
-      *reinterpret_cast<float4*>(vb + (size_t)(a * 4 + 1) * plane) = f4sum(e[a][1], e[a][2]);
-      *reinterpret_cast<float4*>(vb + (size_t)(a * 4 + 2) * plane) = f4sub(e[a][2], e[a][1]);
-      *reinterpret_cast<float4*>(vb + (size_t)(a * 4 + 3) * plane) = f4sub(e[a][1], e[a][3]);
+      const float4 o0 = f4sub(e[a][0], e[a][2]), o1 = f4sum(e[a][1], e[a][2]), o2 = f4sub(e[a][2], e[a][1]), o3 = f4sub(e[a][1], e[a][3]);
+      *reinterpret_cast<float4*>(vb + (size_t)(a * 4 + 0) * plane) = o0;
+      *reinterpret_cast<float4*>(vb + (size_t)(a * 4 + 1) * plane) = o1;
+      *reinterpret_cast<float4*>(vb + (size_t)(a * 4 + 2) * plane) = o2;
+      *reinterpret_cast<float4*>(vb + (size_t)(a * 4 + 3) * plane) = o3;
+      const uint32_t m01 = max(vcg_abs_bits4(o0), vcg_abs_bits4(o1)), m23 = max(vcg_abs_bits4(o2), vcg_abs_bits4(o3));
+      amax = max(amax, max(m01, m23));
     }
   }
+  if (p.amax_slot) vcg_amax_publish(amax, p.amax_slot, p.amax_gen, amax_red);     // uniform: the GEMM that reads V scales by it
 }
 
 // one thread: one tile x 4 output channels; y = A^T m A, A^T = [[1, 1, 1, 0], [0, 1, -1, -1]]
@@ -231,14 +227,16 @@ __global__ __launch_bounds__(256) void k_wino_out_stats(WinoP p, double* __restr
 
 // The transformed kernels (G g G^T)[xi], G = [[1, 0, 0], [.5, .5, .5], [.5, -.5, .5], [0, 0, 1]], written as the B^T operand of
 // the batched GEMM, already split into bf16 "blocked planes" (gemm_split.hip): for GEMM row n and reduction index kk,
-//     up[((xi * NR + n) * KD/32 + kk/32) * 96 + piece * 32 + kk % 32]
+//     up[((xi * NR + n) * KD/32 + kk/32) * VCG_PBLK + piece * 32 + kk % 32]      (fp16 pieces of the value / s, s from the kernel's amax)
 // DGRAD = false: the forward GEMM M = V . U^T — n = co (NR = Cout), kk = k = (phase, c) (KD = Kc);
 // DGRAD = true:  the data-gradient GEMM over the padded domain — n = k (NR = Kc), kk = co (KD = Cout), kernel flipped:
 //                Ud = transform of w[co][k][2 - a][2 - b].
 // One thread per (n, 4 consecutive kk): 36-byte OIHW reads, 8-byte stores per piece and transform point.
 template <bool DGRAD>
 __global__ __launch_bounds__(256) void k_wino_weight_planes(const float* __restrict__ w, unsigned short* __restrict__ up, int Cin,
-                                                            int Cout, int ups, int cin_log, int cout_log) {
+                                                            int Cout, int ups, int cin_log, int cout_log, VcgAmax amax) {
+  float sc, inv;
+  vcg_scale_of(vcg_amax_bits(amax), amax.shift, sc, inv);
   const int U2 = ups * ups, Kc = U2 * Cin;
   const int NR = DGRAD ? Kc : Cout, KD = DGRAD ? Cout : Kc;
   const size_t total = (size_t)NR * (KD / 4);
@@ -274,12 +272,11 @@ __global__ __launch_bounds__(256) void k_wino_weight_planes(const float* __restr
     }
 #pragma unroll
     for (int xi = 0; xi < 16; ++xi) {
-      uint2 hh, mm, ll;
-      split4(make_float4(t[xi][0], t[xi][1], t[xi][2], t[xi][3]), hh, mm, ll);
-      unsigned short* o = up + (((size_t)xi * NR + n) * (KD / 32) + kk / 32) * 96 + (kk & 31);
+      uint2 hh, ll;
+      split4h(make_float4(t[xi][0], t[xi][1], t[xi][2], t[xi][3]), inv, hh, ll);
+      unsigned short* o = up + (((size_t)xi * NR + n) * (KD / 32) + kk / 32) * VCG_PBLK + (kk & 31);
       *reinterpret_cast<uint2*>(o) = hh;
-      *reinterpret_cast<uint2*>(o + 32) = mm;
-      *reinterpret_cast<uint2*>(o + 64) = ll;
+      *reinterpret_cast<uint2*>(o + 32) = ll;
     }
   }
 }
@@ -432,6 +429,8 @@ __global__ __launch_bounds__(256) void k_wino_fold(const float* __restrict__ dxp
 
 // dM = A dy A^T (the adjoint of y = A^T M A), A = [[1, 0], [1, 1], [1, -1], [0, -1]]; one thread: one tile x 4 channels
 __global__ __launch_bounds__(256) void k_wino_dy(const float* __restrict__ dy, float* __restrict__ dm, WinoP p) {
+  __shared__ uint32_t amax_red[4];
+  uint32_t amax = 0;
   const uint32_t c4n = (uint32_t)p.Cout / 4;
   const size_t total = (size_t)p.T * c4n;
   const size_t plane = (size_t)p.T * p.Cout;
@@ -456,12 +455,15 @@ __global__ __launch_bounds__(256) void k_wino_dy(const float* __restrict__ dy, f
     float* mb = dm + (size_t)t * p.Cout + co;
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
+      const float4 o1 = f4sum(z[a][0], z[a][1]), o2 = f4sub(z[a][0], z[a][1]);
       *reinterpret_cast<float4*>(mb + (size_t)(a * 4 + 0) * plane) = z[a][0];
-      *reinterpret_cast<float4*>(mb + (size_t)(a * 4 + 1) * plane) = f4sum(z[a][0], z[a][1]);
-      *reinterpret_cast<float4*>(mb + (size_t)(a * 4 + 2) * plane) = f4sub(z[a][0], z[a][1]);
+      *reinterpret_cast<float4*>(mb + (size_t)(a * 4 + 1) * plane) = o1;
+      *reinterpret_cast<float4*>(mb + (size_t)(a * 4 + 2) * plane) = o2;
       *reinterpret_cast<float4*>(mb + (size_t)(a * 4 + 3) * plane) = f4sub(zero, z[a][1]);
+      amax = max(amax, max(max(vcg_abs_bits4(z[a][0]), vcg_abs_bits4(z[a][1])), max(vcg_abs_bits4(o1), vcg_abs_bits4(o2))));
     }
   }
+  if (p.amax_slot) vcg_amax_publish(amax, p.amax_slot, p.amax_gen, amax_red);
 }
 
 // ------------------------------------------------------------------ host side
@@ -489,17 +491,18 @@ bool vcg_wino_fwd_ok(const ConvGeom& g) {
   if (Kc * g.Cout < 64ull * (Kc + g.Cout)) return false;
   return T * Kc * 4 < (1ull << 31) && T * g.Cout * 4 < (1ull << 31) && T * Kc * 16 < (1ull << 32);
 }
-// one transformed copy of the kernel as bf16 blocked planes: 3 pieces x 2 bytes per value = 1.5 floats
-size_t vcg_wino_weight_floats(const ConvGeom& g) { return (size_t)16 * g.ups * g.ups * g.Cin * g.Cout * 3 / 2; }
+// one transformed copy of the kernel as fp16 blocked planes: VCG_NP pieces x 2 bytes per value
+size_t vcg_wino_weight_floats(const ConvGeom& g) { return (size_t)16 * g.ups * g.ups * g.Cin * g.Cout * VCG_NP / 2; }
 size_t vcg_wino_fwd_workspace(const ConvGeom& g) {
   const size_t T = (size_t)g.N * (g.Ho / 2) * (g.Wo / 2);
   return (size_t)16 * T * ((size_t)g.ups * g.ups * g.Cin + g.Cout) * sizeof(float) + 512;
 }
-int vcg_wino_weight(const ConvGeom& g, const float* w_oihw, float* u, hipStream_t st) {
+int vcg_wino_weight(const ConvGeom& g, const float* w_oihw, float* u, const VcgAmax& amax_w, hipStream_t st) {
   const size_t total = (size_t)g.ups * g.ups * g.Cin * g.Cout / 4;
+  VcgAmax au = amax_w; au.shift += WINO_U_SHIFT;
   // Bt operand of the forward GEMM M = V . U: [xi][co][k], k contiguous, pre-split
   hipLaunchKernelGGL(k_wino_weight_planes<false>, dim3(wino_blocks(total)), dim3(256), 0, st, w_oihw, (unsigned short*)u, g.Cin, g.Cout,
-                     g.ups, g.cin_log, g.cout_log);
+                     g.ups, g.cin_log, g.cout_log, au);
   VCG_LAUNCH_CHECK("vcg_wino_weight");
   return 0;
 }
@@ -514,6 +517,7 @@ static WinoP wino_params(const ConvGeom& g) {
   p.fd_thtw = make_fastdiv((uint32_t)(p.th * p.tw)); p.fd_c4 = make_fastdiv((uint32_t)g.Cin / 4);
   p.fd_co4 = make_fastdiv((uint32_t)g.Cout / 4);
   p.off = 1;
+  p.amax_slot = nullptr; p.amax_gen = 0;
   return p;
 }
 
@@ -530,9 +534,9 @@ size_t vcg_wino_wgrad_workspace(const ConvGeom& g) {
   const int T = g.N * (g.Ho / 2) * (g.Wo / 2);
   return vcg_wino_fwd_workspace(g) + vcg_wino_wgrad_core_workspace(g, T);
 }
-size_t vcg_wino_saved_floats(const ConvGeom& g) {
-  return vcg_wino_wgrad_ok(g) ? (size_t)16 * g.N * (g.Ho / 2) * (g.Wo / 2) * g.ups * g.ups * g.Cin : 0;
-}
+// the kept V, followed by the bit pattern of its largest magnitude (the weight gradient's GEMMs scale V by it, as the forward's did)
+static size_t wino_v_floats(const ConvGeom& g) { return (size_t)16 * g.N * (g.Ho / 2) * (g.Wo / 2) * g.ups * g.ups * g.Cin; }
+size_t vcg_wino_saved_floats(const ConvGeom& g) { return vcg_wino_wgrad_ok(g) ? wino_v_floats(g) + 16 : 0; }
 int vcg_wino_wgrad(const ConvGeom& g, const float* x, const float* dy, float* gw_oihw, void* ws, size_t ws_bytes, hipStream_t st,
                    const float* v_saved) {
   VCG_CHECK_ARG(ws && ws_bytes >= vcg_wino_wgrad_workspace(g), "vcg_conv_wgrad: workspace too small for the Winograd path");
@@ -541,11 +545,21 @@ int vcg_wino_wgrad(const ConvGeom& g, const float* x, const float* dy, float* gw
   float* dM = V + (((size_t)16 * p.T * p.Kc + 63) / 64) * 64;
   const size_t tbytes = vcg_wino_fwd_workspace(g);
   p.x = x; p.v = V;
-  if (v_saved) V = const_cast<float*>(v_saved);
-  else hipLaunchKernelGGL(k_wino_in, dim3(wino_blocks((size_t)p.T * p.Kc / 4)), dim3(256), 0, st, p);
+  VcgAmax amax_v;
+  if (v_saved) {
+    V = const_cast<float*>(v_saved);
+    amax_v = vcg_amax_stored(v_saved + wino_v_floats(g));
+  } else {
+    const VcgAmaxOut av = vcg_amax_new(st);
+    p.amax_slot = av.slot; p.amax_gen = av.gen;
+    hipLaunchKernelGGL(k_wino_in, dim3(wino_blocks((size_t)p.T * p.Kc / 4)), dim3(256), 0, st, p);
+    amax_v = vcg_amax_in(av);
+  }
+  const VcgAmaxOut ad = vcg_amax_new(st);
+  p.amax_slot = ad.slot; p.amax_gen = ad.gen;
   hipLaunchKernelGGL(k_wino_dy, dim3(wino_blocks((size_t)p.T * g.Cout / 4)), dim3(256), 0, st, dy, dM, p);
   VCG_LAUNCH_CHECK("vcg_conv_wgrad(winograd transforms)");
-  return vcg_wino_wgrad_core(g, V, dM, p.T, gw_oihw, (char*)ws + tbytes, ws_bytes - tbytes, st);
+  return vcg_wino_wgrad_core(g, V, dM, p.T, gw_oihw, (char*)ws + tbytes, ws_bytes - tbytes, st, amax_v, vcg_amax_in(ad));
 }
 
 // data gradient over the padded domain (see k_wino_weight_dgrad)
@@ -561,15 +575,17 @@ size_t vcg_wino_dgrad_workspace(const ConvGeom& g) {
   const size_t kc = (size_t)g.ups * g.ups * g.Cin;
   return (size_t)16 * Tp * (kc + g.Cout) * sizeof(float) + 1024;
 }
-int vcg_wino_weight_dgrad(const ConvGeom& g, const float* w_oihw, float* ud, hipStream_t st) {
+int vcg_wino_weight_dgrad(const ConvGeom& g, const float* w_oihw, float* ud, const VcgAmax& amax_w, hipStream_t st) {
   const size_t total = (size_t)g.ups * g.ups * g.Cin * g.Cout / 4;
+  VcgAmax au = amax_w; au.shift += WINO_U_SHIFT;
   // Bt operand of the data-gradient GEMM dXp = Vdy . Ud: [xi][k][co], co contiguous, kernel flipped, pre-split
   hipLaunchKernelGGL(k_wino_weight_planes<true>, dim3(wino_blocks(total)), dim3(256), 0, st, w_oihw, (unsigned short*)ud, g.Cin, g.Cout,
-                     g.ups, g.cin_log, g.cout_log);
+                     g.ups, g.cin_log, g.cout_log, au);
   VCG_LAUNCH_CHECK("vcg_wino_weight_dgrad");
   return 0;
 }
-int vcg_wino_dgrad(const ConvGeom& g, const float* dy, const float* ud, float* dx, void* ws, size_t ws_bytes, hipStream_t st) {
+int vcg_wino_dgrad(const ConvGeom& g, const float* dy, const float* ud, const void* w_amax, float* dx, void* ws, size_t ws_bytes,
+                   hipStream_t st) {
   VCG_CHECK_ARG(ws && ws_bytes >= vcg_wino_dgrad_workspace(g), "vcg_conv_dgrad: workspace too small for the Winograd path");
   const int kc = g.ups * g.ups * g.Cin;
   // input transform of dy: a plain (N, Ho, Wo, Cout) image, zero extension, patch origin 2 * tile - 2
@@ -578,19 +594,18 @@ int vcg_wino_dgrad(const ConvGeom& g, const float* dy, const float* ud, float* d
   p.N = g.N; p.H = g.Ho; p.W = g.Wo; p.Cin = g.Cout; p.Cout = kc; p.Hl = g.Ho; p.Wl = g.Wo; p.ups = 1;
   p.reflect = 0; p.act = VCG_ACT_NONE; p.cout_log = kc;
   p.th = g.Ho / 2 + 1; p.tw = g.Wo / 2 + 1; p.T = g.N * p.th * p.tw; p.Kc = g.Cout; p.off = 2;
+  p.amax_slot = nullptr; p.amax_gen = 0;
   p.fd_k4 = make_fastdiv((uint32_t)p.Kc / 4); p.fd_tw = make_fastdiv((uint32_t)p.tw);
   p.fd_thtw = make_fastdiv((uint32_t)(p.th * p.tw)); p.fd_c4 = make_fastdiv((uint32_t)p.Cin / 4);
   p.fd_co4 = make_fastdiv((uint32_t)kc / 4);
   float* V = (float*)ws;
   float* M = V + (((size_t)16 * p.T * g.Cout + 63) / 64) * 64;
   p.v = V; p.m = M;
-  if (wino_fused_ok(g.Cout, kc, (unsigned long long)g.N * g.Ho * g.Wo * g.Cout * 4)) {                  // transform of the zero-extended dy inside the GEMM's producer waves
-    if (vcg_gemm_ws_wino(dy, ud, M, g.N, g.Ho, g.Wo, g.Cout, g.Ho, g.Wo, 1, 0, 2, p.th, p.tw, kc, st)) return -2;
-  } else {
-    hipLaunchKernelGGL(k_wino_in, dim3(wino_blocks((size_t)p.T * g.Cout / 4)), dim3(256), 0, st, p);
-    VCG_LAUNCH_CHECK("vcg_conv_dgrad(winograd input transform)");
-    if (vcg_gemm_split_batched(V, ud, M, p.T, g.Cout, kc, 16, st)) return -2;
-  }
+  const VcgAmaxOut av = vcg_amax_new(st);
+  p.amax_slot = av.slot; p.amax_gen = av.gen;
+  hipLaunchKernelGGL(k_wino_in, dim3(wino_blocks((size_t)p.T * g.Cout / 4)), dim3(256), 0, st, p);
+  VCG_LAUNCH_CHECK("vcg_conv_dgrad(winograd input transform)");
+  if (vcg_gemm_split_batched(V, ud, M, p.T, g.Cout, kc, 16, vcg_amax_in(av), vcg_amax_stored(w_amax, WINO_U_SHIFT), st)) return -2;
   WinoP q = p;
   q.Kc = kc;                                      // the output side: k columns
   // output transform and fold in one pass: the padded image is never written
@@ -606,21 +621,22 @@ size_t vcg_wino_fwd_stats_doubles(const ConvGeom& g) {
   return (size_t)g.N * pl.nchunk * g.Cout * 2;
 }
 // v_keep: where to leave V = B^T x B for the weight gradient (vcg_wino_saved_floats), instead of the workspace
-int vcg_wino_fwd(const ConvGeom& g, const float* x, const float* u, const float* bias, float* y, void* ws, size_t ws_bytes,
-                 hipStream_t st, double* in_part, int* in_nchunk, float* v_keep) {
+int vcg_wino_fwd(const ConvGeom& g, const float* x, const float* u, const void* w_amax, const float* bias, float* y, void* ws,
+                 size_t ws_bytes, hipStream_t st, double* in_part, int* in_nchunk, float* v_keep) {
   VCG_CHECK_ARG(ws && ws_bytes >= vcg_wino_fwd_workspace(g), "vcg_conv_fwd: workspace too small for the Winograd path (%zu)",
                 ws_bytes);
   WinoP p = wino_params(g);
   float* V = v_keep ? v_keep : (float*)ws;
   float* M = (float*)ws + (((size_t)16 * p.T * p.Kc + 63) / 64) * 64;
   p.x = x; p.v = V; p.m = M; p.bias = bias; p.y = y;
-  if (!v_keep && wino_fused_ok(g.Cin, g.Cout, (unsigned long long)g.N * g.H * g.W * g.Cin * 4)) {   // nobody else wants V: produce it inside the GEMM (gemm_ws.hip, MODE_WINO)
-    if (vcg_gemm_ws_wino(x, u, M, g.N, g.H, g.W, g.Cin, g.Hl, g.Wl, g.ups, g.reflect, 1, p.th, p.tw, g.Cout, st)) return -2;
-  } else {
-    hipLaunchKernelGGL(k_wino_in, dim3(wino_blocks((size_t)p.T * p.Kc / 4)), dim3(256), 0, st, p);
-    VCG_LAUNCH_CHECK("vcg_conv_fwd(winograd input transform)");
-    if (vcg_gemm_split_batched(V, u, M, p.T, p.Kc, g.Cout, 16, st)) return -2;
-  }
+  const VcgAmaxOut av = vcg_amax_new(st);
+  p.amax_slot = av.slot; p.amax_gen = av.gen;
+  hipLaunchKernelGGL(k_wino_in, dim3(wino_blocks((size_t)p.T * p.Kc / 4)), dim3(256), 0, st, p);
+  VCG_LAUNCH_CHECK("vcg_conv_fwd(winograd input transform)");
+  // a kept V keeps its amax behind it (vcg_wino_saved_floats): the weight gradient's GEMMs will scale it the same way
+  if (vcg_gemm_split_batched(V, u, M, p.T, p.Kc, g.Cout, 16, vcg_amax_in(av), vcg_amax_stored(w_amax, WINO_U_SHIFT), st,
+                             v_keep ? reinterpret_cast<uint32_t*>(v_keep + wino_v_floats(g)) : nullptr))
+    return -2;
   if (in_part) {
     const NormPlan pl = vcg_norm_plan(g.N, p.th * p.tw, g.Cout);
     hipLaunchKernelGGL(k_wino_out_stats, dim3(pl.nchunk, g.N, pl.cgroups), dim3(256), 0, st, p, in_part, pl);

@@ -1,23 +1,22 @@
-// Batched dense GEMM for the Winograd layers on the bf16 matrix pipe with fp32-level accuracy ("split-operand" or
-// bf16x3 emulation):   C[z][m][n] = sum_k A[z][m][k] * Bt[z][n][k]      (A, Bt, C fp32 in memory; k contiguous in both)
+// Batched dense GEMM for the Winograd layers on the 16-bit matrix pipe with fp32-level accuracy ("split-operand" arithmetic):
+//     C[z][m][n] = sum_k A[z][m][k] * Bt[z][n][k]      (A, C fp32 in memory; Bt pre-split planes; k contiguous in both)
 //
-// gfx950 runs v_mfma_f32_32x32x16_bf16 at 16x the rate of v_mfma_f32_32x32x2_f32.  Every fp32 operand is split while
-// it is staged into LDS:  x = h + m + l  with  h = bf16(x), m = bf16(x - h), l = bf16(x - h - m)  (3 x 8 mantissa
-// bits = the 24 of fp32), and the six cross products of weight >= 2^-16 relative —  hh, hm, mh, hl, lh, mm  — are
-// accumulated in fp32 MFMA accumulators (h*h in one chain, the five cross terms in a second one).  What is dropped (ml, lm, ll) is below 2^-24 relative
-// to |a||b|: the result rounds like an fp32 GEMM (tools/gemm_split_probe.hip measures it against float64).
-// 6 bf16 MFMAs of 32 cycles replace 8 fp32 MFMAs of 64: 2.7x less matrix-pipe time; the kernel then runs at what its
-// staging (global -> split -> LDS) and its epilogue allow.
+// gfx950 runs v_mfma_f32_32x32x16_{f16,bf16} at 16x the rate of v_mfma_f32_32x32x2_f32.  Rounds 1-2 split every fp32 operand
+// into three bf16 pieces and accumulated six products; measured from inside (tools/gemm_ws_probe.hip, round 3) those kernels
+// were not held back by their schedule but by the chip's answer to a dense MFMA stream — a lower clock — so the lever is
+// MFMAs per product.  Round 3: x / s = h + l as two fp16 pieces (22 mantissa bits), s a power of two from the tensor's largest
+// magnitude (vcg_common.h), and the THREE products hh, hl, lh — h*h in one fp32 accumulation chain, the two cross terms
+// (<= 2^-11 of it) in a second one, summed and multiplied by sA * sB in the epilogue.  Dropped: l*l, below 2^-22.
+// Against float64 the GEMM rounds at 2.1e-7 (bf16 x 3: 1.7e-7; PyTorch-CPU fp32 on the same data 2.2-3.0e-7) and runs
+// 1.3-1.6x faster on the step's shapes (profiles/r03_gemm_fp16x2_probe.txt).
 //
 // The B operand of every call site is a WEIGHT (the Winograd-transformed kernels U / Ud): it is split once per optimizer
-// step, when it is packed ("blocked planes": for Bt[n][k], K % 32 == 0,  bp[(n * K/32 + kb) * 96 + piece * 32 + j]  as
-// bf16, piece 0 / 1 / 2 = h / m / l of Bt[n][32 kb + j] — 192 contiguous bytes per row and K block), so this kernel stages
-// B with plain 16-byte copies and only the activations (A) are split in the K loop: half of the loop's conversion
-// arithmetic gone for the 128-column tile (in-kernel stamps on a ping-pong variant showed that arithmetic to take as long
-// as the MFMAs it sits beside: profiles/r02_gemm_pp_stamps.txt).
+// step, when it is packed ("blocked planes": for Bt[n][k], K % 32 == 0,  bp[(n * K/32 + kb) * 64 + piece * 32 + j]  as fp16,
+// piece 0 / 1 = h / l of Bt[n][32 kb + j] / sB — 128 contiguous bytes per row and K block), so this kernel stages B with plain
+// 16-byte copies and only the activations (A) are scaled and split in the K loop.
 //
 // Tile 128 x BN (BN = 128 or 64), BK = 32, 256 threads = 2 x 2 waves, each wave (64 x BN/2) as 32x32 accumulators.
-// LDS images: per piece [rows][32] bf16, 64-byte rows, the four 16-byte chunks of a row XOR-swizzled by (row >> 2) & 3
+// LDS images: per piece [rows][32] fp16, 64-byte rows, the four 16-byte chunks of a row XOR-swizzled by (row >> 2) & 3
 // so that the ds_read_b128 fragment reads (lane = row, 16 consecutive rows per LDS cycle) are conflict-free.
 #include "vcg_common.h"
 
@@ -29,8 +28,10 @@ struct GemmSplitP {
   float* c;
   int rows, K, N;
   uint32_t a_bytes, b_bytes;          // per batch (buffer-load bounds)
-  uint32_t a_bstride, b_bstride;      // floats (a) / bf16 elements (bt planes: 3 per value) between batches
+  uint32_t a_bstride, b_bstride;      // floats (a) / fp16 elements (bt planes: VCG_NP per value) between batches
   size_t c_bstride;
+  VcgAmax amax_a, amax_b;             // largest magnitudes of A (all batches) and of the tensor Bt was split from
+  uint32_t* amax_a_keep;              // where to leave A's amax bits for a later call that reads the same A (the kept V), or null
 };
 
 __device__ __forceinline__ float4 gs_bload4(__amdgpu_buffer_rsrc_t r, uint32_t off) {
@@ -42,11 +43,18 @@ __device__ __forceinline__ float4 gs_bload4(__amdgpu_buffer_rsrc_t r, uint32_t o
 template <int BN>
 __global__ __launch_bounds__(256, 2) void k_gemm_split(GemmSplitP p) {
   constexpr int BM = 128, NI = BN / 64, MI = 2, AR = BM / 32;
-  // [piece][row][32 bf16] as raw bytes: 64 B per row
-  __shared__ __attribute__((aligned(16))) unsigned char As[3][BM * 64];
-  __shared__ __attribute__((aligned(16))) unsigned char Bs[3][BN * 64];
+  // [piece][row][32 fp16] as raw bytes: 64 B per row
+  __shared__ __attribute__((aligned(16))) unsigned char As[VCG_NP][BM * 64];
+  __shared__ __attribute__((aligned(16))) unsigned char Bs[VCG_NP][BN * 64];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid >> 1, wn = wid & 1, l31 = lane & 31, lh = lane >> 5;
+  float sa_, inv_a, sb_, inv_b;
+  {
+    const uint32_t abits = vcg_amax_bits(p.amax_a);
+    vcg_scale_of(abits, p.amax_a.shift, sa_, inv_a);
+    vcg_scale_of(vcg_amax_bits(p.amax_b), p.amax_b.shift, sb_, inv_b);
+    if (p.amax_a_keep && tid == 0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) *p.amax_a_keep = abits;
+  }
   // XCD-aware tile order (see k_conv_fwd): the N tiles that share an A tile run back to back on one XCD
   int mt, nt, zb;
   {
@@ -70,11 +78,11 @@ __global__ __launch_bounds__(256, 2) void k_gemm_split(GemmSplitP p) {
     aoff[i] = r < p.rows ? (uint32_t)(((size_t)r * p.K + s_u * 4) * 4) : GS_OOB;
   }
   // B planes: thread (row b_r = tid >> 2, 16-byte chunk b_q = tid & 3 of a 64-byte piece row); pass j = (row half, piece)
-  constexpr int BP = 3 * BN / 64;                                 // 16-byte copies per thread and K-step
+  constexpr int BP = VCG_NP * BN / 64;                            // 16-byte copies per thread and K-step
   const int b_q = tid & 3, b_r = tid >> 2;
   const int KB = p.K / 32;
-  const uint32_t boff0 = (uint32_t)(((size_t)(n0 + b_r) * KB) * 192 + b_q * 16);      // N % BN == 0: every row is in range
-  const uint32_t bhalf = (uint32_t)KB * (64u * 192u);
+  const uint32_t boff0 = (uint32_t)(((size_t)(n0 + b_r) * KB) * VCG_PBYTES + b_q * 16);      // N % BN == 0: every row is in range
+  const uint32_t bhalf = (uint32_t)KB * (64u * VCG_PBYTES);
   const uint32_t bsoff0 = (uint32_t)(b_r * 64 + ((b_q ^ ((b_r >> 2) & 3)) << 4));     // row + 64 keeps the swizzle term
   // LDS byte offset of this thread's quad inside a piece image: row r, chunk (u >> 1) swizzled, half (u & 1)
   uint32_t soff[AR];
@@ -84,8 +92,8 @@ __global__ __launch_bounds__(256, 2) void k_gemm_split(GemmSplitP p) {
     soff[i] = (uint32_t)(r * 64 + (((s_u >> 1) ^ ((r >> 2) & 3)) << 4) + ((s_u & 1) << 3));
   }
 
-  // acc: the h*h chain; lo: the five cross terms (<= 2^-7 of it).  One chain for all six would round the big running
-  // sum six times per slice instead of once.
+  // acc: the h*h chain; lo: the two cross terms (<= 2^-11 of it).  One chain for all three would round the big running
+  // sum three times per slice instead of once.
   f32x16 acc[MI][NI], lo[MI][NI];
 #pragma unroll
   for (int i = 0; i < MI; ++i)
@@ -102,19 +110,18 @@ __global__ __launch_bounds__(256, 2) void k_gemm_split(GemmSplitP p) {
     for (int i = 0; i < AR; ++i) va[i] = gs_bload4(ra, aoff[i] != GS_OOB ? aoff[i] + (uint32_t)kt * 128u : GS_OOB);
 #pragma unroll
     for (int j = 0; j < BP; ++j)
-      vb[j] = __builtin_amdgcn_raw_buffer_load_b128(rb, (int)(boff0 + (uint32_t)(j / 3) * bhalf + (uint32_t)(j % 3) * 64u + (uint32_t)kt * 192u), 0, 0);
+      vb[j] = __builtin_amdgcn_raw_buffer_load_b128(rb, (int)(boff0 + (uint32_t)(j / VCG_NP) * bhalf + (uint32_t)(j % VCG_NP) * 64u + (uint32_t)kt * VCG_PBYTES), 0, 0);
   };
   auto store_tiles = [&]() {
 #pragma unroll
     for (int i = 0; i < AR; ++i) {
-      uint2 h, m, l;
-      split4(va[i], h, m, l);
+      uint2 h, l;
+      split4h(va[i], inv_a, h, l);
       *reinterpret_cast<uint2*>(&As[0][soff[i]]) = h;
-      *reinterpret_cast<uint2*>(&As[1][soff[i]]) = m;
-      *reinterpret_cast<uint2*>(&As[2][soff[i]]) = l;
+      *reinterpret_cast<uint2*>(&As[1][soff[i]]) = l;
     }
 #pragma unroll
-    for (int j = 0; j < BP; ++j) *reinterpret_cast<u32x4g*>(&Bs[j % 3][bsoff0 + 4096 * (j / 3)]) = vb[j];
+    for (int j = 0; j < BP; ++j) *reinterpret_cast<u32x4g*>(&Bs[j % VCG_NP][bsoff0 + 4096 * (j / VCG_NP)]) = vb[j];
   };
   // fragment byte offsets (per k slice s: chunk 2s + lh)
   uint32_t fa[MI], fb[NI];
@@ -131,29 +138,26 @@ __global__ __launch_bounds__(256, 2) void k_gemm_split(GemmSplitP p) {
     if (kt + 1 < nkt) load_tiles(kt + 1);
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-      bf16x8 a[3][MI], b[3][NI];
+      f16x8 a[VCG_NP][MI], b[VCG_NP][NI];
 #pragma unroll
-      for (int pc = 0; pc < 3; ++pc) {
+      for (int pc = 0; pc < VCG_NP; ++pc) {
 #pragma unroll
         for (int i = 0; i < MI; ++i)
-          a[pc][i] = *reinterpret_cast<const bf16x8*>(&As[pc][fa[i] + (((2 * s + lh) ^ sa[i]) << 4)]);
+          a[pc][i] = *reinterpret_cast<const f16x8*>(&As[pc][fa[i] + (((2 * s + lh) ^ sa[i]) << 4)]);
 #pragma unroll
         for (int j = 0; j < NI; ++j)
-          b[pc][j] = *reinterpret_cast<const bf16x8*>(&Bs[pc][fb[j] + (((2 * s + lh) ^ sb[j]) << 4)]);
+          b[pc][j] = *reinterpret_cast<const f16x8*>(&Bs[pc][fb[j] + (((2 * s + lh) ^ sb[j]) << 4)]);
       }
-      // smallest contributions first: mm, lh, hl, mh, hm, hh
+      // the cross terms lh, hl in one chain, hh in the other
 #pragma unroll
       for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
           f32x16 c = lo[i][j];
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][i], b[1][j], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2][i], b[0][j], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[2][j], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][i], b[0][j], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[1][j], c, 0, 0, 0);
+          c = VCG_MFMA(a[1][i], b[0][j], c);
+          c = VCG_MFMA(a[0][i], b[1][j], c);
           lo[i][j] = c;
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[0][j], acc[i][j], 0, 0, 0);
+          acc[i][j] = VCG_MFMA(a[0][i], b[0][j], acc[i][j]);
         }
     }
     __syncthreads();
@@ -163,6 +167,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_split(GemmSplitP p) {
     }
   }
   float* const dst = p.c + (size_t)zb * p.c_bstride;
+  const float os = sa_ * sb_;
 #pragma unroll
   for (int j = 0; j < NI; ++j) {
     const int n = n0 + wn * (BN / 2) + j * 32 + l31;
@@ -173,51 +178,50 @@ __global__ __launch_bounds__(256, 2) void k_gemm_split(GemmSplitP p) {
       for (int e = 0; e < 16; ++e) {
         const int row = (e & 3) + 8 * (e >> 2) + 4 * lh;
         const int m = m0 + wm * 64 + i * 32 + row;
-        if (m < p.rows) dst[(size_t)m * p.N + n] = acc[i][j][e] + lo[i][j][e];
+        if (m < p.rows) dst[(size_t)m * p.N + n] = (acc[i][j][e] + lo[i][j][e]) * os;
       }
   }
 }
 
-// X[rows][K] fp32 -> blocked planes (see the top of this file); one thread per 4 consecutive k.  K % 32 == 0.
-__global__ __launch_bounds__(256) void k_split_planes(const float* __restrict__ x, unsigned short* __restrict__ bp, size_t quads, int K) {
+// X[rows][K] fp32 -> blocked planes of X / s (see the top of this file), s from `amax`; one thread per 4 consecutive k.  K % 32 == 0.
+__global__ __launch_bounds__(256) void k_split_planes(const float* __restrict__ x, unsigned short* __restrict__ bp, size_t quads, int K, VcgAmax amax) {
+  float s, inv;
+  vcg_scale_of(vcg_amax_bits(amax), amax.shift, s, inv);
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < quads; i += (size_t)gridDim.x * blockDim.x) {
     const size_t e = i * 4, row = e / K;
     const int k = (int)(e - row * K);
-    uint2 h, m, l;
-    split4(*reinterpret_cast<const float4*>(x + e), h, m, l);
-    unsigned short* o = bp + (row * (K / 32) + k / 32) * 96 + (k & 31);
+    uint2 h, l;
+    split4h(*reinterpret_cast<const float4*>(x + e), inv, h, l);
+    unsigned short* o = bp + (row * (K / 32) + k / 32) * VCG_PBLK + (k & 31);
     *reinterpret_cast<uint2*>(o) = h;
-    *reinterpret_cast<uint2*>(o + 32) = m;
-    *reinterpret_cast<uint2*>(o + 64) = l;
+    *reinterpret_cast<uint2*>(o + 32) = l;
   }
 }
-int vcg_split_planes(const float* x, void* bp, size_t rows, int K, hipStream_t st) {
+int vcg_split_planes(const float* x, void* bp, size_t rows, int K, const VcgAmax& amax, hipStream_t st) {
   VCG_CHECK_ARG(K % 32 == 0, "vcg_split_planes: K must be a multiple of 32");
   const size_t quads = rows * K / 4;
   size_t blocks = (quads + 255) / 256; if (blocks > 8192) blocks = 8192;
-  hipLaunchKernelGGL(k_split_planes, dim3((unsigned)blocks), dim3(256), 0, st, x, (unsigned short*)bp, quads, K);
+  hipLaunchKernelGGL(k_split_planes, dim3((unsigned)blocks), dim3(256), 0, st, x, (unsigned short*)bp, quads, K, amax);
   VCG_LAUNCH_CHECK("vcg_split_planes");
   return 0;
 }
 
-bool vcg_gemm_ws_ok(int rows, int K, int N);
-int vcg_gemm_ws_batched(const float* A, const void* BtPlanes, float* C, int rows, int K, int N, int batches, hipStream_t st);
-
 // rows x K (fp32) times (N x K)^T (blocked planes) per batch; K % 32 == 0, N % 64 == 0
-int vcg_gemm_split_batched(const float* A, const void* BtPlanes, float* C, int rows, int K, int N, int batches, hipStream_t st) {
-  if (vcg_gemm_ws_ok(rows, K, N)) return vcg_gemm_ws_batched(A, BtPlanes, C, rows, K, N, batches, st);   // gemm_ws.hip (round 3)
+int vcg_gemm_split_batched(const float* A, const void* BtPlanes, float* C, int rows, int K, int N, int batches, const VcgAmax& amax_a,
+                           const VcgAmax& amax_b, hipStream_t st, uint32_t* amax_a_keep) {
   const float* Bt = (const float*)BtPlanes;
   VCG_CHECK_ARG(K % 32 == 0 && N % 64 == 0 && rows > 0, "vcg_gemm_split_batched: bad shape rows=%d K=%d N=%d", rows, K, N);
-  VCG_CHECK_ARG((unsigned long long)rows * K * 4 < (1ull << 31) && (unsigned long long)N * K * 6 < (1ull << 31),
+  VCG_CHECK_ARG((unsigned long long)rows * K * 4 < (1ull << 31) && (unsigned long long)N * K * 2 * VCG_NP < (1ull << 31),
                 "vcg_gemm_split_batched: operand extents must stay below 2 GiB per batch");
   VCG_CHECK_ARG((unsigned long long)rows * K * (unsigned long long)batches < (1ull << 32) &&
-                    (unsigned long long)N * K * 3 * (unsigned long long)batches < (1ull << 32),
+                    (unsigned long long)N * K * VCG_NP * (unsigned long long)batches < (1ull << 32),
                 "vcg_gemm_split_batched: batch stride overflow");
   GemmSplitP p;
   p.a = A; p.bt = Bt; p.c = C; p.rows = rows; p.K = K; p.N = N;
-  p.a_bytes = (uint32_t)((size_t)rows * K * 4); p.b_bytes = (uint32_t)((size_t)N * K * 6);
-  p.a_bstride = (uint32_t)((size_t)rows * K); p.b_bstride = (uint32_t)((size_t)N * K * 3);
+  p.a_bytes = (uint32_t)((size_t)rows * K * 4); p.b_bytes = (uint32_t)((size_t)N * K * 2 * VCG_NP);
+  p.a_bstride = (uint32_t)((size_t)rows * K); p.b_bstride = (uint32_t)((size_t)N * K * VCG_NP);
   p.c_bstride = (size_t)rows * N;
+  p.amax_a = amax_a; p.amax_b = amax_b; p.amax_a_keep = amax_a_keep;
   const int bn = (N % 128 == 0) ? 128 : 64;
   dim3 grid((rows + 127) / 128, N / bn, batches);
   VcgProfScope prof(bn == 128 ? "k_gemm_split<128>" : "k_gemm_split<64>", 2.0 * rows * (double)K * N * batches, st);

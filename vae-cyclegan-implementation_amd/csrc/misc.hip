@@ -79,6 +79,56 @@ static int ew_blocks(size_t work) {
   return (int)b;
 }
 
+// ---------------------------------------------------------------- operand magnitudes for the fp16 x 2 kernels (vcg_common.h)
+// 4096 slots of 64 {generation, amax bits} words, zero at load; a slot is reused every 4096 calls, long after its last reader
+// (a stream runs a call's kernels in order, and a call's slot is read only by that call's own kernels).
+#define VCG_AMAX_SLOTS 4096
+__device__ unsigned long long g_vcg_amax_slots[VCG_AMAX_SLOTS * 64];
+#include <atomic>
+static std::atomic<uint32_t> g_amax_gen{0};
+VcgAmaxOut vcg_amax_new(hipStream_t) {
+  static thread_local unsigned long long* base[64] = {};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (dev < 0 || dev >= 64) dev = 0;
+  if (!base[dev]) {
+    void* p = nullptr;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_vcg_amax_slots)) != hipSuccess) p = nullptr;
+    base[dev] = (unsigned long long*)p;
+  }
+  VcgAmaxOut o;
+  uint32_t g = ++g_amax_gen;
+  if (g == 0) g = ++g_amax_gen;                  // generation 0 is "never written"
+  o.gen = g;
+  o.slot = base[dev] ? base[dev] + (size_t)(g % VCG_AMAX_SLOTS) * 64 : nullptr;
+  return o;
+}
+__global__ __launch_bounds__(256) void k_absmax(const float* __restrict__ tf, size_t n, unsigned long long* __restrict__ slot, uint32_t gen) {
+  __shared__ uint32_t red[4];
+  const float4* t = reinterpret_cast<const float4*>(tf);
+  const size_t n4 = n / 4;
+  uint32_t m = 0;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    const uint32_t b = vcg_abs_bits4(t[i]);
+    m = b > m ? b : m;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {                 // the tail of a tensor whose element count is not a multiple of 4
+    const uint32_t b = vcg_abs_bits(tf[n4 * 4 + threadIdx.x]);
+    m = b > m ? b : m;
+  }
+  vcg_amax_publish(m, slot, gen, red);
+}
+int vcg_absmax_launch(const float* t, size_t n, const VcgAmaxOut& out, hipStream_t st) {
+  VCG_CHECK_ARG(t && out.slot, "absmax: null pointer (no amax slot on this device)");
+  VCG_CHECK_ARG(((uintptr_t)t & 15) == 0, "absmax: the tensor must be 16-byte aligned");
+  size_t blocks = (n / 4 + 1023) / 1024;                          // ~4 float4 per thread
+  if (blocks > 1024) blocks = 1024;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(k_absmax, dim3((unsigned)blocks), dim3(256), 0, st, t, n, out.slot, out.gen);
+  VCG_LAUNCH_CHECK("absmax");
+  return 0;
+}
+
 // ---------------------------------------------------------------- layout
 __global__ void k_nchw_to_nhwc(const float* __restrict__ src, float* __restrict__ dst, int N, int C, int H, int W,
                                int P) {

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <string.h>
 #include "../../include/vcg.h"
 
 #define VCG_WAVE 64
@@ -114,25 +115,105 @@ __device__ static inline double wave_sum_d(double v) {
   return v;
 }
 
-// split-operand bf16 arithmetic (gemm_split.hip): 4 consecutive k of one row -> three 8-byte bf16 quads
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-__device__ __forceinline__ void split4(const float4& v, uint2& h, uint2& m, uint2& l) {
-  const float x[4] = {v.x, v.y, v.z, v.w};
-  unsigned short hs[4], ms[4], ls[4];
+// ---- split-operand arithmetic (gemm_split.hip) -------------------------------------------------------------------
+// Round 3: fp16 x 2.  Every fp32 operand x of an MFMA kernel is staged as  x / s = h + l  with h = fp16(x / s), l = fp16(x / s - h)
+// (2 x 11 = 22 mantissa bits) and s a power of two — exact to apply — that brings the operand TENSOR's largest magnitude into
+// [2^14, 2^15), under fp16's 65504.  Three products of relative weight >= 2^-11 (hh, hl, lh) go into fp32 MFMA accumulators, the
+// result is multiplied by sA * sB in the epilogue; the dropped ll term is below 2^-22.  Measured against float64 a GEMM rounds at
+// 2.1e-7 (the bf16 x 3 / six-product form of rounds 1-2: 1.7e-7; PyTorch-CPU fp32: 2.2-3.0e-7) — and issues half the MFMAs,
+// which on a chip that answers a denser MFMA stream with a lower clock is what moves the wall time (profiles/r03_gemm_fp16x2_probe.txt).
+// Elements more than 2^17 below the tensor's largest magnitude lose relative (not absolute) precision: their error stays 2^-40
+// of that magnitude, below the fp32 rounding of any sum they enter.
+#define VCG_NP 2                          // pieces per operand
+#define VCG_PBLK (32 * VCG_NP)            // 16-bit elements per (row, 32-k block) of "blocked planes": [piece][32]
+#define VCG_PBYTES (2 * VCG_PBLK)         // 128 bytes
+#define VCG_PFLOATS (VCG_PBYTES / 4)      // 32 floats
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2v __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));   // (tools/ probes of the rounds 1-2 arithmetic)
+#define VCG_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0)
+
+// 4 consecutive k of one row, already multiplied by 1 / s -> two 8-byte fp16 quads
+__device__ __forceinline__ void split4h(const float4& v, float inv, uint2& h, uint2& l) {
+  const float x[4] = {v.x * inv, v.y * inv, v.z * inv, v.w * inv};
+  _Float16 hh[4], ll[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const __bf16 hb = (__bf16)x[i];
-    const float r1 = x[i] - (float)hb;
-    const __bf16 mb = (__bf16)r1;
-    const float r2 = r1 - (float)mb;
-    const __bf16 lb = (__bf16)r2;
-    hs[i] = __builtin_bit_cast(unsigned short, hb);
-    ms[i] = __builtin_bit_cast(unsigned short, mb);
-    ls[i] = __builtin_bit_cast(unsigned short, lb);
+    hh[i] = (_Float16)x[i];
+    ll[i] = (_Float16)(x[i] - (float)hh[i]);
   }
-  h = make_uint2((uint32_t)hs[0] | ((uint32_t)hs[1] << 16), (uint32_t)hs[2] | ((uint32_t)hs[3] << 16));
-  m = make_uint2((uint32_t)ms[0] | ((uint32_t)ms[1] << 16), (uint32_t)ms[2] | ((uint32_t)ms[3] << 16));
-  l = make_uint2((uint32_t)ls[0] | ((uint32_t)ls[1] << 16), (uint32_t)ls[2] | ((uint32_t)ls[3] << 16));
+  const f16x2v h0 = {hh[0], hh[1]}, h1 = {hh[2], hh[3]}, l0 = {ll[0], ll[1]}, l1 = {ll[2], ll[3]};
+  h = make_uint2(__builtin_bit_cast(uint32_t, h0), __builtin_bit_cast(uint32_t, h1));
+  l = make_uint2(__builtin_bit_cast(uint32_t, l0), __builtin_bit_cast(uint32_t, l1));
+}
+
+// The largest magnitude of an operand tensor ("amax") travels as the bit pattern of |x| (non-negative floats order like their
+// bits; a NaN outranks everything and an Inf every finite value, so a poisoned tensor is seen as such) in a SLOT of 64 u64
+// words {generation << 32 | bits}: producers (k_absmax, the Winograd transforms) atomicMax their block's maximum into word
+// blockIdx % 64, consumers take the maximum over the words whose generation is theirs.  The host hands out (slot, generation)
+// per call with a strictly increasing generation, so a slot never needs clearing: whatever an earlier call left loses
+// against the first atomicMax of this one.  The slots live in a __device__ array of the code object (misc.hip).
+struct VcgAmax {
+  const unsigned long long* slot;     // 64 words written in THIS call sequence, or null:
+  const uint32_t* stored;             //   the amax bits as an earlier call stored them (a weight pack's header, a kept V), or null:
+  uint32_t gen, bits;                 //   `bits` as given by the host
+  int shift;                          // the tensor the kernel reads is bounded by 2^shift * amax (Winograd transforms of a tensor)
+};
+struct VcgAmaxOut { unsigned long long* slot; uint32_t gen; };
+VcgAmaxOut vcg_amax_new(hipStream_t st);                                // a fresh (slot, generation) on the current device
+static inline VcgAmax vcg_amax_in(const VcgAmaxOut& o, int shift = 0) { VcgAmax a; a.slot = o.slot; a.stored = nullptr; a.gen = o.gen; a.bits = 0; a.shift = shift; return a; }
+static inline VcgAmax vcg_amax_stored(const void* bits_ptr, int shift = 0) { VcgAmax a; a.slot = nullptr; a.stored = (const uint32_t*)bits_ptr; a.gen = 0; a.bits = 0; a.shift = shift; return a; }
+static inline VcgAmax vcg_amax_const(uint32_t bits, int shift = 0) { VcgAmax a; a.slot = nullptr; a.stored = nullptr; a.gen = 0; a.bits = bits; a.shift = shift; return a; }
+int vcg_absmax_launch(const float* t, size_t n, const VcgAmaxOut& out, hipStream_t st);      // t 16-byte aligned
+
+#ifdef __HIPCC__
+// block-wide: every thread contributes the bit pattern of a magnitude; one atomicMax per block.  `red` = 4+ words of LDS.
+__device__ __forceinline__ void vcg_amax_publish(uint32_t mybits, unsigned long long* slot, uint32_t gen, uint32_t* red) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const uint32_t other = (uint32_t)__shfl_xor((int)mybits, o, 64);
+    mybits = other > mybits ? other : mybits;
+  }
+  const int wid = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  if ((threadIdx.x & 63) == 0) red[wid] = mybits;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t m = red[0];
+    for (int w = 1; w < nw; ++w) m = red[w] > m ? red[w] : m;
+    atomicMax(slot + (blockIdx.x & 63), ((unsigned long long)gen << 32) | m);
+  }
+}
+__device__ __forceinline__ uint32_t vcg_abs_bits(float v) { return __float_as_uint(v) & 0x7FFFFFFFu; }
+__device__ __forceinline__ uint32_t vcg_abs_bits4(const float4& v) {
+  const uint32_t a = vcg_abs_bits(v.x), b = vcg_abs_bits(v.y), c = vcg_abs_bits(v.z), d = vcg_abs_bits(v.w);
+  const uint32_t ab = a > b ? a : b, cd = c > d ? c : d;
+  return ab > cd ? ab : cd;
+}
+// every wave for itself (no LDS, no barrier): the amax bits of an operand
+__device__ __forceinline__ uint32_t vcg_amax_bits(const VcgAmax& a) {
+  if (!a.slot) return a.stored ? *a.stored : a.bits;
+  const unsigned long long w = a.slot[threadIdx.x & 63];
+  uint32_t b = (uint32_t)(w >> 32) == a.gen ? (uint32_t)w : 0u;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const uint32_t other = (uint32_t)__shfl_xor((int)b, o, 64);
+    b = other > b ? other : b;
+  }
+  return b;
+}
+#endif
+// s = 2^(E - 14 + shift) for amax in [2^E, 2^(E+1)): amax / s lands in [2^14, 2^15).  A zero, subnormal, infinite or NaN amax
+// gives s = 2^shift (nothing to scale; a poisoned tensor stays poisoned through the fp16 conversion).
+__host__ __device__ static inline void vcg_scale_of(uint32_t amax_bits, int shift, float& s, float& inv) {
+  int e = (int)((amax_bits >> 23) & 0xFF);
+  int f = (e == 0 || e == 255) ? 127 + shift : e - 14 + shift;
+  f = f < 1 ? 1 : (f > 253 ? 253 : f);
+  const uint32_t sb = (uint32_t)f << 23, ib = (uint32_t)(254 - f) << 23;
+#ifdef __HIP_DEVICE_COMPILE__
+  s = __uint_as_float(sb); inv = __uint_as_float(ib);
+#else
+  memcpy(&s, &sb, 4); memcpy(&inv, &ib, 4);
+#endif
 }
 
 // InstanceNorm reductions (norm.hip): a workgroup sums one chunk of pixels for TC channel quads x TP pixel lanes; the chunk
@@ -182,9 +263,9 @@ bool vcg_wino_weight_ok(const ConvGeom& g);
 bool vcg_wino_fwd_ok(const ConvGeom& g);
 size_t vcg_wino_weight_floats(const ConvGeom& g);
 size_t vcg_wino_fwd_workspace(const ConvGeom& g);
-int vcg_wino_weight(const ConvGeom& g, const float* w_oihw, float* u, hipStream_t st);
-int vcg_wino_fwd(const ConvGeom& g, const float* x, const float* u, const float* bias, float* y, void* ws, size_t ws_bytes,
-                 hipStream_t st, double* in_part = nullptr, int* in_nchunk = nullptr, float* v_keep = nullptr);
+int vcg_wino_weight(const ConvGeom& g, const float* w_oihw, float* u, const VcgAmax& amax_w, hipStream_t st);
+int vcg_wino_fwd(const ConvGeom& g, const float* x, const float* u, const void* w_amax, const float* bias, float* y, void* ws,
+                 size_t ws_bytes, hipStream_t st, double* in_part = nullptr, int* in_nchunk = nullptr, float* v_keep = nullptr);
 size_t vcg_wino_saved_floats(const ConvGeom& g);
 size_t vcg_wino_fwd_stats_doubles(const ConvGeom& g);
 // Winograd weight gradient: transforms in conv_wino.hip, batched stream-K reduction + back-transform in conv_igemm.hip
@@ -194,21 +275,22 @@ int vcg_wino_wgrad(const ConvGeom& g, const float* x, const float* dy, float* gw
                    const float* v_saved = nullptr);
 size_t vcg_wino_wgrad_core_workspace(const ConvGeom& g, int T);
 int vcg_wino_wgrad_core(const ConvGeom& g, const float* V, const float* dM, int T, float* gw_oihw, void* ws, size_t ws_bytes,
-                        hipStream_t st);
+                        hipStream_t st, const VcgAmax& amax_v, const VcgAmax& amax_dm);
 bool vcg_wino_dgrad_ok(const ConvGeom& g);
 size_t vcg_wino_dgrad_workspace(const ConvGeom& g);
-int vcg_wino_weight_dgrad(const ConvGeom& g, const float* w_oihw, float* ud, hipStream_t st);
-int vcg_wino_dgrad(const ConvGeom& g, const float* dy, const float* ud, float* dx, void* ws, size_t ws_bytes, hipStream_t st);
+int vcg_wino_weight_dgrad(const ConvGeom& g, const float* w_oihw, float* ud, const VcgAmax& amax_w, hipStream_t st);
+int vcg_wino_dgrad(const ConvGeom& g, const float* dy, const float* ud, const void* w_amax, float* dx, void* ws, size_t ws_bytes,
+                   hipStream_t st);
 // conv_slab.hip: 3x3 / stride-1 layers with few channels on large maps — the input staged once per workgroup as an LDS slab
 bool vcg_slab_fwd_ok(const ConvGeom& g);
 bool vcg_slab_fwd_stats_ok(const ConvGeom& g);
 int vcg_slab_fwd_nchunk(const ConvGeom& g);
 bool vcg_slab_dgrad_ok(const ConvGeom& g);
 size_t vcg_slab_dgrad_workspace(const ConvGeom& g);
-int vcg_slab_fwd(const ConvGeom& g, const float* x, const void* wft_planes, size_t planes_bytes, const float* bias, float* y,
-                 double* in_part, int* in_nchunk, hipStream_t st);
-int vcg_slab_dgrad(const ConvGeom& g, const float* dy, const void* wfd_planes, size_t planes_bytes, float* dx, void* ws,
-                   size_t ws_bytes, hipStream_t st);
+int vcg_slab_fwd(const ConvGeom& g, const float* x, const void* wft_planes, size_t planes_bytes, const void* w_amax, const float* bias,
+                 float* y, double* in_part, int* in_nchunk, hipStream_t st);
+int vcg_slab_dgrad(const ConvGeom& g, const float* dy, const void* wfd_planes, size_t planes_bytes, const void* w_amax, float* dx,
+                   void* ws, size_t ws_bytes, hipStream_t st);
 // conv_ring.hip: weight gradients of U4 / head / stem with row-ring staging (the taps are address offsets of the fragment reads)
 bool vcg_ring_wgrad_ok(const ConvGeom& g);
 size_t vcg_ring_wgrad_workspace(const ConvGeom& g);
@@ -217,11 +299,12 @@ int vcg_ring_wgrad(const ConvGeom& g, const float* x, const float* dy, float* gw
 bool vcg_thin_fold_ok(const ConvGeom& g);
 size_t vcg_thin_fold_weight_floats(const ConvGeom& g);
 size_t vcg_thin_fold_workspace(const ConvGeom& g);
-int vcg_thin_fold_pack(const ConvGeom& g, const float* w_oihw, float* wk, hipStream_t st);
-int vcg_thin_fold_fwd(const ConvGeom& g, const float* x, const float* wk, const float* bias, float* y, void* ws, size_t ws_bytes,
-                      hipStream_t st);
+int vcg_thin_fold_pack(const ConvGeom& g, const float* w_oihw, float* wk, const VcgAmax& amax_w, hipStream_t st);
+int vcg_thin_fold_fwd(const ConvGeom& g, const float* x, const float* wk, const void* w_amax, const float* bias, float* y, void* ws,
+                      size_t ws_bytes, hipStream_t st);
 bool vcg_thin_fold_dgrad_ok(const ConvGeom& g);
 size_t vcg_thin_fold_dgrad_weight_floats(const ConvGeom& g);
 size_t vcg_thin_fold_dgrad_workspace(const ConvGeom& g);
-int vcg_thin_fold_dgrad_pack(const ConvGeom& g, const float* w_oihw, float* wk, hipStream_t st);
-int vcg_thin_fold_dgrad(const ConvGeom& g, const float* dy, const float* wkd, float* dx, void* ws, size_t ws_bytes, hipStream_t st);
+int vcg_thin_fold_dgrad_pack(const ConvGeom& g, const float* w_oihw, float* wk, const VcgAmax& amax_w, hipStream_t st);
+int vcg_thin_fold_dgrad(const ConvGeom& g, const float* dy, const float* wkd, const void* w_amax, float* dx, void* ws, size_t ws_bytes,
+                        hipStream_t st);
