@@ -28,10 +28,12 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 FP32_MFMA_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs @ 2.4 GHz
-# The GEMMs run on the bf16 matrix pipe with every fp32 operand split into three bf16 pieces and six cross products
-# accumulated in fp32 (csrc/gemm_split.hip): fp32-level results at 6 bf16 MFMAs per fp32 multiply-add.
-BF16_MFMA_PEAK_TFLOPS = 16 * FP32_MFMA_PEAK_TFLOPS          # same guide: BF16 dense = 16x the F32 MFMA rate (~2.5 PF)
-BF16X3_FP32_EQUIV_PEAK_TFLOPS = BF16_MFMA_PEAK_TFLOPS / 6   # 419.5: what that pipe can deliver in fp32-equivalent FLOPs
+# The GEMMs run on the 16-bit matrix pipe with every fp32 operand scaled by a per-tensor power of two and split into two fp16
+# pieces, three cross products accumulated in fp32 (csrc/vcg_common.h, csrc/gemm_split.hip): fp32-level results at 3 fp16 MFMAs
+# per fp32 multiply-add (rounds 1-2: three bf16 pieces, 6 MFMAs).
+BF16_MFMA_PEAK_TFLOPS = 16 * FP32_MFMA_PEAK_TFLOPS          # same guide: BF16 / FP16 dense = 16x the F32 MFMA rate (~2.5 PF)
+SPLIT_MFMAS_PER_PRODUCT = 3
+BF16X3_FP32_EQUIV_PEAK_TFLOPS = BF16_MFMA_PEAK_TFLOPS / SPLIT_MFMAS_PER_PRODUCT   # 838.9: what that pipe can deliver in fp32-equivalent FLOPs
 WORKLOADS = {
     "cyclevaegan": "cyclevaegan unpaired, 3x256x256 synthetic summer<->winter, per-GPU batch 8, latent 64 (BASELINE.json configs[3]/[4])",
     "vae": "vae latent 1024, 3x256x256 synthetic, batch 16 (BASELINE.json configs[2])",
@@ -160,8 +162,9 @@ def main():
         "value": round(images_per_s, 3), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "arithmetic": "fp32 in, fp32 out, fp32 accumulate; GEMM products as 3x bf16 split operands (6 bf16 MFMAs per fp32 MFMA), "
-                      "rounding error at or below PyTorch-CPU fp32 (profiles/r01_conv_accuracy.txt)",
+        "arithmetic": "fp32 in, fp32 out, fp32 accumulate; GEMM products as 2 x fp16 split operands scaled by a per-tensor power of two "
+                      "(3 fp16 MFMAs per fp32 multiply-add), rounding error 1.4-4e-7 against float64, at the level of PyTorch-CPU fp32 "
+                      "(profiles/r03_conv_accuracy.txt)",
         "config": {"workload": WORKLOADS[wl] if (S == 256) else f"{wl} {S}x{S} batch {B}", "per_gpu_batch": B, "global_batch": B * world,
                    "image_size": S, "latent_dim": latent, "parallelism": f"dp{world}", "init": "random (reference init statistics)"},
     }
@@ -198,7 +201,7 @@ def main():
         dist.destroy_process_group()
 
 
-PROFILE_ROUND = "r02"          # profiles/<round>_pmc_*.json: the committed PMC passes `traffic` and `mfma_pipe_util` are quoted from
+PROFILE_ROUND = "r03"          # profiles/<round>_pmc_*.json: the committed PMC passes `traffic` and `mfma_pipe_util` are quoted from
 
 
 def read_kernel_profile(lib):
@@ -280,9 +283,10 @@ def measure_roofline(pkg, model, pool, wl, B, S, latent, ms_per_step, rank=0):
     fach = ffl / fsec / 1e12
     roof = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 2), "peak": round(pipe_peak(dom), 1), "unit": "TFLOP/s",
             "frac": round(ach / pipe_peak(dom), 4),
-            "peak_is": "dense bf16 MFMA peak (2516.8 TFLOP/s, v_mfma_f32_32x32x16_bf16) / 6: the pipe this kernel executes on, in "
-                       "fp32-equivalent FLOPs — every fp32 product is six bf16 MFMAs (3-way operand split, fp32 accumulate, "
-                       "fp32-level rounding)" if pipe_peak(dom) != FP32_MFMA_PEAK_TFLOPS else "fp32 MFMA (v_mfma_f32_32x32x2_f32)",
+            "peak_is": "dense fp16 MFMA peak (2516.8 TFLOP/s, v_mfma_f32_32x32x16_f16) / 3: the pipe this kernel executes on, in "
+                       "fp32-equivalent FLOPs — every fp32 product is three fp16 MFMAs (2-way operand split with a per-tensor "
+                       "power-of-two scale, fp32 accumulate, fp32-level rounding; rounds 1-2 issued six bf16 MFMAs per product, "
+                       "peak 419.5)" if pipe_peak(dom) != FP32_MFMA_PEAK_TFLOPS else "fp32 MFMA (v_mfma_f32_32x32x2_f32)",
             "flops_counted": "the FLOPs the launch executes: 2*M*N*K of its GEMM (for a Winograd layer the 16 transformed GEMMs, "
                              "2.25x fewer than the direct convolution's)",
             "launches": cnt // nsteps, "avg_launch_ms": round(sec / cnt * 1e3, 4),
@@ -297,7 +301,7 @@ def measure_roofline(pkg, model, pool, wl, B, S, latent, ms_per_step, rank=0):
             "family": {"kernel": famdom, "achieved_algorithmic_tflops": round(fach, 2),
                        "is": "the C-ABI call family with the most time (one call = several device kernels: transforms, GEMM, reduces); "
                              "FLOPs = the direct convolution's 2*M*Cout*K per call, the layer's algorithmic work",
-                       "frac_of_bf16x3_peak": round(fach / BF16X3_FP32_EQUIV_PEAK_TFLOPS, 4),
+                       "frac_of_split_pipe_peak": round(fach / BF16X3_FP32_EQUIV_PEAK_TFLOPS, 4),
                        "frac_vs_fp32_mfma_target": round(fach / FP32_MFMA_PEAK_TFLOPS, 4),
                        "launches": fn // nsteps, "avg_launch_ms": round(fsec / fn * 1e3, 4)}}
     if traffic is not None:

@@ -27,7 +27,23 @@
 extern "C" {
 #endif
 
-#define VCG_ABI_VERSION 2   /* round 2: vcg_adam_step takes 1 - beta; vcg_conv_fwd_in, vcg_conv_wgrad_saved, input transforms, profiling */
+#define VCG_ABI_VERSION 3   /* round 3: packed weights and kept forward state carry fp16 x 2 planes + amax words (sizes changed);
+                               vcg_amax_hint / vcg_amax_last.  round 2: vcg_adam_step takes 1 - beta; vcg_conv_fwd_in,
+                               vcg_conv_wgrad_saved, input transforms, profiling */
+
+/* Operand magnitudes (round 3) ------------------------------------------------
+ * The MFMA kernels compute fp32 products as three fp16 MFMAs: every operand is scaled by a power of two taken from the
+ * largest magnitude ("amax") of its tensor and split into two fp16 pieces (csrc/vcg_common.h).  An entry point that reads
+ * a tensor whose amax it does not know measures it with one pass over the tensor.  The entry points that WRITE activations
+ * and gradients (vcg_in_apply, vcg_in_bwd, vcg_act_bwd) publish the amax of what they wrote as a by-product:
+ *   vcg_amax_last()        handle of the amax of the tensor the last such call on this thread wrote (0: none); reading resets it;
+ *   vcg_amax_hint(x, dy)   handles for the x / dy operands of the NEXT vcg_conv_fwd / _fwd_in / _dgrad / _wgrad(_saved) call
+ *                          on this thread (0 = unknown: measured); consumed by that call.
+ * A handle names device-side state of the library's code object; it stays valid for ~15 000 later library calls on the device
+ * (a training step makes ~1 000) and is refused — the tensor is measured — once it is older.  Passing a handle that belongs to
+ * another tensor scales that operand wrongly: hand over only what vcg_amax_last returned for exactly that tensor. */
+void vcg_amax_hint(uint64_t x_amax, uint64_t dy_amax);
+uint64_t vcg_amax_last(void);
 
 /* conv descriptor: int32[16] ------------------------------------------------ */
 enum {

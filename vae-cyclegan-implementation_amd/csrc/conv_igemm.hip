@@ -63,6 +63,8 @@ struct ConvP {
   int in_nchunk;
   // fp16 x 2 split-operand kernels (vcg_common.h): the largest magnitude of the tensor behind `a` and of the one behind `b`
   VcgAmax amax_a, amax_b;
+  // batched Winograd weight gradient: `a` (the kept V) is pre-split planes [batch][T][K / 32][2][32] (k_wino_in_planes), not fp32
+  int a_planes;
 };
 
 #define BK 32
@@ -154,6 +156,7 @@ __device__ __forceinline__ void mma_ktile(f32x16 (&acc)[MI][NI], FA ldA, FB ldB,
 // offset >= num_records returns zeros — so rows past M, K-tail columns and zero-padding taps need no
 // predication, no zero-initialised staging registers and no 64-bit address arithmetic.
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 #define VCG_OOB 0x80000000u   // > any tensor we accept (host checks extents < 2 GiB)
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_srd(const float* ptr, uint32_t bytes) {
   return __builtin_amdgcn_make_buffer_rsrc((void*)ptr, 0, (int)bytes, 0x00020000);
@@ -1395,7 +1398,21 @@ __global__ __launch_bounds__(256, 2) void k_conv_wgrad_split(ConvP p) {
   }
 
   auto load_tiles = [&](int /*kt: tiles are visited strictly in order*/) {
-    if (row_aligned) {
+    if (p.a_planes) {
+      // the batched 1x1 geometry of the Winograd path (N = 1, H = 1, W = T, Cin = K): pixel = tile index sow, row quad c = R.
+      // The quad's two pieces sit 64 bytes apart in its 128-byte (tile, 32-k block) group; they travel as the two halves of va
+      const uint32_t cblk = (uint32_t)(R >> 5) * VCG_PBYTES + (uint32_t)(R & 31) * 2u;
+      const uint32_t rowb = (uint32_t)(p.K >> 5) * VCG_PBYTES;
+#pragma unroll
+      for (int a = 0; a < AP; ++a) {
+        const bool ok = rv && sm[a] < (uint32_t)p.M;
+        const uint32_t off = ok ? sm[a] * rowb + cblk : VCG_OOB;
+        const u32x2 h = __builtin_amdgcn_raw_buffer_load_b64(ra, (int)off, 0, 0);
+        const u32x2 l = __builtin_amdgcn_raw_buffer_load_b64(ra, (int)(ok ? off + 64u : VCG_OOB), 0, 0);
+        va[a] = make_float4(__uint_as_float(h.x), __uint_as_float(h.y), __uint_as_float(l.x), __uint_as_float(l.y));
+        sm[a] += BK;
+      }
+    } else if (row_aligned) {
       const int n = sn[0], oh = soh[0];
       int ih = oh * p.stride - p.pad + kh;
       bool okr = rv && sm[0] < (uint32_t)p.M;            // M % 32 == 0 here, so all slots agree
@@ -1455,7 +1472,12 @@ __global__ __launch_bounds__(256, 2) void k_conv_wgrad_split(ConvP p) {
 #pragma unroll
     for (int a = 0; a < AP; ++a) {
       uint2 h, l;
-      split4h(va[a], sc.inv_a, h, l);
+      if (p.a_planes) {
+        h = make_uint2(__float_as_uint(va[a].x), __float_as_uint(va[a].y));
+        l = make_uint2(__float_as_uint(va[a].z), __float_as_uint(va[a].w));
+      } else {
+        split4h(va[a], sc.inv_a, h, l);
+      }
       const uint32_t o = tr_off<BM>(ps + PS * a, rq * 4);
       *reinterpret_cast<uint2*>(&Xs[0][o]) = h;
       *reinterpret_cast<uint2*>(&Xs[1][o]) = l;
@@ -1937,6 +1959,7 @@ static void fill_params(const ConvGeom& g, ConvP& p) {
   p.bias = nullptr;
   p.in_part = nullptr; p.in_nchunk = 0;
   p.amax_a = p.amax_b = vcg_amax_const(0);      // scale 1 (the fp32-MFMA kernels never look)
+  p.a_planes = 0;
 }
 
 // Tile and K-slice choice.  The 256 CUs want >= 512 workgroups.  If the largest tile that reaches that
@@ -2188,15 +2211,17 @@ static bool fwd_tile_stats_ok(const ConvGeom& g) {
 // can: Winograd, or fwd_tile_stats_ok) and report the chunk count per image.
 static int conv_fwd_impl(const float* x, const float* wf, const float* bias, float* y, const int32_t* cd, void* ws,
                          size_t ws_bytes, void* stream, double* in_part, int* in_nchunk, float* saved = nullptr) {
+  const uint64_t x_handle = vcg_take_hint_x();              // vcg_amax_hint: who wrote x left its largest magnitude (or 0)
+  (void)vcg_take_hint_dy();
   ConvGeom g;
   if (vcg_conv_geom(cd, &g, "vcg_conv_fwd")) return -1;
   VCG_CHECK_ARG(x && wf && y, "vcg_conv_fwd: null pointer");
-  if (vcg_thin_fold_ok(g)) return vcg_thin_fold_fwd(g, x, wf + wf_floats(g), vcg_pack_amax(g, wf), bias, y, ws, ws_bytes, (hipStream_t)stream);
+  if (vcg_thin_fold_ok(g)) return vcg_thin_fold_fwd(g, x, wf + wf_floats(g), vcg_pack_amax(g, wf), bias, y, ws, ws_bytes, (hipStream_t)stream, x_handle);
   if (vcg_thin_fwd_ok(g)) return vcg_thin_fwd(g, x, wf, bias, y, (hipStream_t)stream);
   if (vcg_wino_fwd_ok(g))
     return vcg_wino_fwd(g, x, wf + wf_floats(g), vcg_pack_amax(g, wf), bias, y, ws, ws_bytes, (hipStream_t)stream, in_part, in_nchunk, saved);
   if (fwd_slab_ok(g))
-    return vcg_slab_fwd(g, x, wf + wft_offset(g), wft_floats(g) * 4, vcg_pack_amax(g, wf), bias, y, in_part, in_nchunk, (hipStream_t)stream);
+    return vcg_slab_fwd(g, x, wf + wft_offset(g), wft_floats(g) * 4, vcg_pack_amax(g, wf), bias, y, in_part, in_nchunk, (hipStream_t)stream, x_handle);
   ConvP p; fill_params(g, p);
   if (in_part) {
     p.in_part = in_part;
@@ -2220,9 +2245,8 @@ static int conv_fwd_impl(const float* x, const float* wf, const float* bias, flo
   if (bm == 128 && bn >= 64 && wft_wanted(g)) {          // split-operand fp16 kernel, B^T from the pre-split WFT planes of the pack
     p.b = wf + wft_offset(g);
     p.b_bytes = (uint32_t)(wft_floats(g) * 4);
-    const VcgAmaxOut ax = vcg_amax_new(st);              // the input's largest magnitude: its scale (vcg_common.h)
-    if (vcg_absmax_launch(x, (size_t)g.N * g.H * g.W * g.Cin, ax, st)) return -2;
-    p.amax_a = vcg_amax_in(ax);
+    // the input's largest magnitude (its scale, vcg_common.h): from its writer's handle, else measured
+    if (vcg_operand_amax(x, (size_t)g.N * g.H * g.W * g.Cin, x_handle, 0, st, &p.amax_a)) return -2;
     p.amax_b = vcg_amax_stored(vcg_pack_amax(g, wf));
     VcgProfScope prof(bn == 128 ? "k_conv_fwd_split<128>" : "k_conv_fwd_split<64>", gemm_flops, st);
     if (bn == 128) hipLaunchKernelGGL((k_conv_fwd_split<128>), grid, dim3(256), 0, st, p);
@@ -2325,17 +2349,19 @@ extern "C" size_t vcg_conv_dgrad_workspace(const int32_t* cd) {
 
 extern "C" int vcg_conv_dgrad(const float* dy, const float* wf, float* dx, const int32_t* cd, void* ws,
                               size_t ws_bytes, void* stream) {
+  (void)vcg_take_hint_x();
+  const uint64_t dy_handle = vcg_take_hint_dy();            // vcg_amax_hint
   ConvGeom g;
   if (vcg_conv_geom(cd, &g, "vcg_conv_dgrad")) return -1;
   VCG_CHECK_ARG(dy && wf && dx, "vcg_conv_dgrad: null pointer");
   VCG_CHECK_ARG(g.Hl % g.stride == 0 && g.Wl % g.stride == 0, "vcg_conv_dgrad: input %dx%d not divisible by stride", g.Hl, g.Wl);
   VCG_CHECK_ARG(g.stride == 1 || g.ups == 1, "vcg_conv_dgrad: stride 2 with ups 2 unsupported");
-  if (vcg_thin_fold_dgrad_ok(g)) return vcg_thin_fold_dgrad(g, dy, wf + wkd_offset(g), vcg_pack_amax(g, wf), dx, ws, ws_bytes, (hipStream_t)stream);
+  if (vcg_thin_fold_dgrad_ok(g)) return vcg_thin_fold_dgrad(g, dy, wf + wkd_offset(g), vcg_pack_amax(g, wf), dx, ws, ws_bytes, (hipStream_t)stream, dy_handle);
   if (vcg_thin_dgrad_ok(g)) return vcg_thin_dgrad(g, dy, wf, dx, ws, ws_bytes, (hipStream_t)stream);
   if (vcg_wino_dgrad_ok(g))
     return vcg_wino_dgrad(g, dy, wf + wf_floats(g) + wino_u_floats(g), vcg_pack_amax(g, wf), dx, ws, ws_bytes, (hipStream_t)stream);
   if (dgrad_slab_ok(g))
-    return vcg_slab_dgrad(g, dy, wf + wfd_offset(g), wfd_floats(g) * 4, vcg_pack_amax(g, wf), dx, ws, ws_bytes, (hipStream_t)stream);
+    return vcg_slab_dgrad(g, dy, wf + wfd_offset(g), wfd_floats(g) * 4, vcg_pack_amax(g, wf), dx, ws, ws_bytes, (hipStream_t)stream, dy_handle);
   ConvP p; fill_params(g, p);
   p.a = dy; p.b = wf; p.out = dx;
   {
@@ -2364,11 +2390,9 @@ extern "C" int vcg_conv_dgrad(const float* dy, const float* wf, float* dx, const
     const bool nopl64 = !planes && bm == 128 && bn == 64 && g.Cout % 4 == 0;
     const bool split = planes || bn == 32 || nopl64;
     if (split) {                                            // fp16 x 2 kernels: the operands' largest magnitudes (vcg_common.h)
-      const VcgAmaxOut ad = vcg_amax_new(st);
-      if (vcg_absmax_launch(dy, (size_t)g.M * g.Cout, ad, st)) return -2;
       // the kernel ADDS the sources that reflect padding folds onto a pixel before it splits the sum: up to 4 of them (9 on maps
       // so small that a pixel has mirrors on both sides) — the operand is bounded by 2^4 x dy's largest magnitude, not by it
-      p.amax_a = vcg_amax_in(ad, g.reflect ? 4 : 0);
+      if (vcg_operand_amax(dy, (size_t)g.M * g.Cout, dy_handle, g.reflect ? 4 : 0, st, &p.amax_a)) return -2;
       p.amax_b = vcg_amax_stored(vcg_pack_amax(g, wf));
     }
     VcgProfScope prof(!split ? "k_conv_dgrad<fp32 MFMA>" : bn == 128 ? "k_conv_dgrad_split<128, 2>" : bn == 64 ? "k_conv_dgrad_split<64, 2>"
@@ -2470,7 +2494,7 @@ size_t vcg_wino_wgrad_core_workspace(const ConvGeom& g, int T) {
   return (size_t)wp.parts * 16 * q.K * q.Cout * sizeof(float) + 256;
 }
 int vcg_wino_wgrad_core(const ConvGeom& g, const float* V, const float* dM, int T, float* gw_oihw, void* ws, size_t ws_bytes,
-                        hipStream_t st, const VcgAmax& amax_v, const VcgAmax& amax_dm) {
+                        hipStream_t st, const VcgAmax& amax_v, const VcgAmax& amax_dm, bool v_planes) {
   const ConvGeom q = wino_gemm_geom(g, T);
   const WgradPlan wp = wgrad_plan(q, 16);
   VCG_CHECK_ARG(wp.grid > 0, "vcg_conv_wgrad: no launch plan for the Winograd path");
@@ -2478,6 +2502,8 @@ int vcg_wino_wgrad_core(const ConvGeom& g, const float* V, const float* dM, int 
   ConvP p; fill_params(q, p);
   p.a = V; p.b = dM; p.out = (float*)ws;
   p.amax_a = amax_v; p.amax_b = amax_dm;
+  p.a_planes = v_planes ? 1 : 0;
+  VCG_CHECK_ARG(!v_planes || (wp.bm == 128 && q.K % 32 == 0), "vcg_conv_wgrad: pre-split V needs the split-operand tile");
   p.a_bytes = (uint32_t)((size_t)T * q.K * 4); p.b_bytes = (uint32_t)((size_t)T * q.Cout * 4);
   p.nbatch = 16; p.a_bstride = (uint32_t)((size_t)T * q.K); p.b_bstride = (uint32_t)((size_t)T * q.Cout);
   p.ktiles_total = wp.total; p.sk_len = wp.len; p.sk_units = wp.ntr * wp.ntn * wp.total; p.sk_ntn = wp.ntn;
@@ -2549,6 +2575,7 @@ extern "C" int vcg_conv_wgrad(const float* x, const float* dy, float* gw_oihw, f
 // `saved`: what vcg_conv_fwd_in left for this very (x, cd) in its `saved` buffer (vcg_conv_saved_floats), or null
 extern "C" int vcg_conv_wgrad_saved(const float* x, const float* dy, float* gw_oihw, float* gbias, const float* saved,
                                     const int32_t* cd, void* ws, size_t ws_bytes, void* stream) {
+  const uint64_t x_handle = vcg_take_hint_x(), dy_handle = vcg_take_hint_dy();      // vcg_amax_hint
   ConvGeom g;
   if (vcg_conv_geom(cd, &g, "vcg_conv_wgrad")) return -1;
   VCG_CHECK_ARG(x && dy && gw_oihw && ws, "vcg_conv_wgrad: null pointer");
@@ -2562,7 +2589,7 @@ extern "C" int vcg_conv_wgrad_saved(const float* x, const float* dy, float* gw_o
   }
   if (wgrad_ring_ok(g)) {
     const size_t rbytes = vcg_ring_wgrad_workspace(g);
-    if (vcg_ring_wgrad(g, x, dy, gw_oihw, ws, rbytes, (hipStream_t)stream)) return -2;
+    if (vcg_ring_wgrad(g, x, dy, gw_oihw, ws, rbytes, (hipStream_t)stream, x_handle, dy_handle)) return -2;
     if (gbias) return launch_colsum(g, dy, gbias, (float*)((char*)ws + ((rbytes + 255) / 256) * 256), (hipStream_t)stream);
     return 0;
   }
@@ -2587,10 +2614,10 @@ extern "C" int vcg_conv_wgrad_saved(const float* x, const float* dy, float* gw_o
   dim3 grid(wp.grid);
   hipStream_t st = (hipStream_t)stream;
   if (bm == 128) {                                          // fp16 x 2 kernel: both operands are activations, scaled by their own amax
-    const VcgAmaxOut aa = vcg_amax_new(st), ab = vcg_amax_new(st);
-    if (vcg_absmax_launch(p.a, (size_t)p.a_bytes / 4, aa, st) || vcg_absmax_launch(p.b, (size_t)p.b_bytes / 4, ab, st)) return -2;
-    // swapped roles: the rows are gathered from dy through the adjoint of the padding, i.e. as sums of up to 4 (9) sources
-    p.amax_a = vcg_amax_in(aa, (swapped && gorig.reflect) ? 4 : 0); p.amax_b = vcg_amax_in(ab);
+    // swapped roles (a = dy, b = x): the rows are gathered from dy through the adjoint of the padding, i.e. as sums of up to 4 (9) sources
+    if (vcg_operand_amax(p.a, (size_t)p.a_bytes / 4, swapped ? dy_handle : x_handle, (swapped && gorig.reflect) ? 4 : 0, st, &p.amax_a) ||
+        vcg_operand_amax(p.b, (size_t)p.b_bytes / 4, swapped ? x_handle : dy_handle, 0, st, &p.amax_b))
+      return -2;
   }
   {
     VcgProfScope prof(bm == 128 ? (bn == 128 ? "k_conv_wgrad_split<128>" : "k_conv_wgrad_split<64>") : "k_conv_wgrad<fp32 MFMA>",

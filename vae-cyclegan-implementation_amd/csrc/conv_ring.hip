@@ -352,7 +352,8 @@ size_t vcg_ring_wgrad_workspace(const ConvGeom& g) {
   return (sub * pl.nwg + sub * pl.G) * pl.NR * 64 * sizeof(float) + 256;
 }
 
-int vcg_ring_wgrad(const ConvGeom& g, const float* x, const float* dy, float* gw_oihw, void* ws, size_t ws_bytes, hipStream_t st) {
+int vcg_ring_wgrad(const ConvGeom& g, const float* x, const float* dy, float* gw_oihw, void* ws, size_t ws_bytes, hipStream_t st,
+                   uint64_t x_handle, uint64_t dy_handle) {
   const int mode = ring_mode(g);
   VCG_CHECK_ARG(mode >= 0, "vcg_conv_wgrad(ring): unsupported layer");
   VCG_CHECK_ARG(ws && ws_bytes >= vcg_ring_wgrad_workspace(g), "vcg_conv_wgrad(ring): workspace too small");
@@ -376,11 +377,10 @@ int vcg_ring_wgrad(const ConvGeom& g, const float* x, const float* dy, float* gw
     p.w_reflect = 0; p.w_off = 0;
   }
   p.r_ups = mode == 0 ? g.ups : 1; p.r_gpp = mode == 0 ? g.Cin / 32 : 1;
-  {
-    const VcgAmaxOut ar = vcg_amax_new(st), aw = vcg_amax_new(st);
-    if (vcg_absmax_launch(p.ring, (size_t)p.ring_bytes / 4, ar, st) || vcg_absmax_launch(p.wide, (size_t)p.wide_bytes / 4, aw, st)) return -2;
-    p.amax_r = vcg_amax_in(ar); p.amax_w = vcg_amax_in(aw);
-  }
+  // the operands' largest magnitudes: from the handles of whoever wrote x / dy, else measured (mode 2: dy is the ring)
+  if (vcg_operand_amax(p.ring, (size_t)p.ring_bytes / 4, mode == 2 ? dy_handle : x_handle, 0, st, &p.amax_r) ||
+      vcg_operand_amax(p.wide, (size_t)p.wide_bytes / 4, mode == 2 ? x_handle : dy_handle, 0, st, &p.amax_w))
+    return -2;
   p.nseg = pl.nseg; p.nrs = pl.nrs; p.rows_per_band = pl.rows;
   p.slabs = (float*)ws;
   const dim3 grid(pl.nwg, pl.ntiles, pl.ngroups);

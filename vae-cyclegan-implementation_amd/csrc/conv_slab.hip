@@ -274,13 +274,10 @@ bool vcg_slab_dgrad_ok(const ConvGeom& g) {
 size_t vcg_slab_dgrad_workspace(const ConvGeom& g) { return (size_t)g.N * (g.H + 2) * (g.W + 2) * g.Cin * sizeof(float) + 256; }
 
 int vcg_slab_fwd(const ConvGeom& g, const float* x, const void* wft_planes, size_t planes_bytes, const void* w_amax, const float* bias,
-                 float* y, double* in_part, int* in_nchunk, hipStream_t st) {
+                 float* y, double* in_part, int* in_nchunk, hipStream_t st, uint64_t x_handle) {
   SlabP p = {};
-  {
-    const VcgAmaxOut ax = vcg_amax_new(st);
-    if (vcg_absmax_launch(x, (size_t)g.N * g.H * g.W * g.Cin, ax, st)) return -2;
-    p.amax_a = vcg_amax_in(ax); p.amax_b = vcg_amax_stored(w_amax);
-  }
+  if (vcg_operand_amax(x, (size_t)g.N * g.H * g.W * g.Cin, x_handle, 0, st, &p.amax_a)) return -2;
+  p.amax_b = vcg_amax_stored(w_amax);
   p.in = x; p.planes = wft_planes; p.bias = bias; p.out = y; p.in_part = in_part;
   p.N = g.N; p.H = g.H; p.W = g.W; p.C = g.Cin; p.Ho = g.Ho; p.Wo = g.Wo; p.Cout = g.Cout; p.cout_log = g.cout_log;
   p.pad = 1; p.reflect = g.reflect; p.act = g.act; p.tap_flip = 0; p.nchunks = g.Cin / 32;
@@ -300,14 +297,11 @@ int vcg_slab_fwd(const ConvGeom& g, const float* x, const void* wft_planes, size
 }
 
 int vcg_slab_dgrad(const ConvGeom& g, const float* dy, const void* wfd_planes, size_t planes_bytes, const void* w_amax, float* dx,
-                   void* ws, size_t ws_bytes, hipStream_t st) {
+                   void* ws, size_t ws_bytes, hipStream_t st, uint64_t dy_handle) {
   VCG_CHECK_ARG(ws && ws_bytes >= vcg_slab_dgrad_workspace(g), "vcg_conv_dgrad(slab): workspace too small");
   SlabP p = {};
-  {
-    const VcgAmaxOut ad = vcg_amax_new(st);
-    if (vcg_absmax_launch(dy, (size_t)g.N * g.Ho * g.Wo * g.Cout, ad, st)) return -2;
-    p.amax_a = vcg_amax_in(ad); p.amax_b = vcg_amax_stored(w_amax);
-  }
+  if (vcg_operand_amax(dy, (size_t)g.N * g.Ho * g.Wo * g.Cout, dy_handle, 0, st, &p.amax_a)) return -2;
+  p.amax_b = vcg_amax_stored(w_amax);
   p.in = dy; p.planes = wfd_planes; p.bias = nullptr; p.out = (float*)ws; p.in_part = nullptr;
   p.N = g.N; p.H = g.Ho; p.W = g.Wo; p.C = g.Cout; p.Ho = g.H + 2; p.Wo = g.W + 2; p.Cout = g.Cin; p.cout_log = g.Cin;
   p.pad = 2; p.reflect = 0; p.act = VCG_ACT_NONE; p.tap_flip = 1; p.nchunks = g.Cout / 32;
@@ -337,14 +331,11 @@ int vcg_slab_dgrad(const ConvGeom& g, const float* dy, const void* wfd_planes, s
 // column taps being part of N, a padded column pc simply reads input column reflect(pc - pad)).
 bool vcg_slab_col_ok(int KH, int C) { return KH == 7 && C % 32 == 0 && C <= 128; }
 int vcg_slab_col(const float* x, const void* planes, size_t planes_bytes, const void* w_amax, float* P, int N, int H, int W, int C,
-                 int Ho, int Wo, int KH, int pad, int reflect, hipStream_t st) {
+                 int Ho, int Wo, int KH, int pad, int reflect, hipStream_t st, uint64_t x_handle) {
   VCG_CHECK_ARG(vcg_slab_col_ok(KH, C), "vcg_conv(kw-fold slab): unsupported KH=%d C=%d", KH, C);
   SlabP p = {};
-  {
-    const VcgAmaxOut ax = vcg_amax_new(st);
-    if (vcg_absmax_launch(x, (size_t)N * H * W * C, ax, st)) return -2;
-    p.amax_a = vcg_amax_in(ax); p.amax_b = vcg_amax_stored(w_amax);
-  }
+  if (vcg_operand_amax(x, (size_t)N * H * W * C, x_handle, 0, st, &p.amax_a)) return -2;
+  p.amax_b = vcg_amax_stored(w_amax);
   p.in = x; p.planes = planes; p.bias = nullptr; p.out = P; p.in_part = nullptr;
   p.N = N; p.H = H; p.W = W; p.C = C; p.Ho = Ho; p.Wo = Wo; p.Cout = 32; p.cout_log = 32;
   p.pad = pad; p.reflect = reflect; p.act = VCG_ACT_NONE; p.tap_flip = 0; p.nchunks = C / 32;

@@ -148,7 +148,7 @@ int vcg_fwd_launch(const ConvGeom& g, const float* x, const float* wf, float* y,
 // conv_slab.hip: the same (KH x 1) convolution on the split-operand bf16 pipe, the input rows staged once per workgroup
 bool vcg_slab_col_ok(int KH, int C);
 int vcg_slab_col(const float* x, const void* planes, size_t planes_bytes, const void* w_amax, float* P, int N, int H, int W, int C, int Ho, int Wo,
-                 int KH, int pad, int reflect, hipStream_t st);
+                 int KH, int pad, int reflect, hipStream_t st, uint64_t x_handle);
 // Wk / Wkd are followed by their pre-split planes [32 rows (kw, co)][KH C / 32][VCG_NP pieces][32 k] when that kernel can take the layer
 static size_t fold_planes_floats(int KH, int C) { return vcg_slab_col_ok(KH, C) ? (size_t)KH * C * VCG_PFLOATS : 0; }
 // planes of a packed fold matrix wk[(kh, c)][32] (fp32): one thread per (row n, 4 consecutive k)
@@ -264,14 +264,14 @@ __global__ __launch_bounds__(256) void k_kwfold_sum(const float* __restrict__ P,
   }
 }
 int vcg_thin_fold_fwd(const ConvGeom& g, const float* x, const float* wk, const void* w_amax, const float* bias, float* y, void* ws,
-                      size_t ws_bytes, hipStream_t st) {
+                      size_t ws_bytes, hipStream_t st, uint64_t x_handle) {
   VCG_CHECK_ARG(ws && ws_bytes >= vcg_thin_fold_workspace(g), "vcg_conv_fwd: workspace too small for the kw-folded path");
   ConvGeom q = g;                                 // the (KH x 1) convolution over every padded column
   q.KW = 1; q.Cout = 32; q.cout_log = g.KW * 4; q.act = VCG_ACT_NONE;
   q.Wo = g.W + 2 * g.pad; q.Ho = g.Ho; q.M = g.N * q.Ho * q.Wo; q.taps = g.KH; q.K = g.KH * g.Cin;
   if (fold_planes_floats(g.KH, g.Cin)) {
     if (vcg_slab_col(x, wk + (size_t)g.KH * g.Cin * 32, fold_planes_floats(g.KH, g.Cin) * 4, w_amax, (float*)ws, g.N, g.H, g.W, g.Cin, q.Ho,
-                     q.Wo, g.KH, g.pad, g.reflect, st))
+                     q.Wo, g.KH, g.pad, g.reflect, st, x_handle))
       return -2;
   } else if (vcg_fwd_launch(q, x, wk, (float*)ws, st)) {
     return -2;
@@ -301,12 +301,12 @@ int vcg_thin_fwd(const ConvGeom& g, const float* x, const float* wf, const float
 }
 
 int vcg_thin_fold_dgrad(const ConvGeom& g, const float* dy, const float* wkd, const void* w_amax, float* dx, void* ws, size_t ws_bytes,
-                        hipStream_t st) {
+                        hipStream_t st, uint64_t dy_handle) {
   VCG_CHECK_ARG(ws && ws_bytes >= vcg_thin_fold_dgrad_workspace(g), "vcg_conv_dgrad(kw-fold): workspace too small");
   const ConvGeom f = thin_dgrad_as_fwd(g);
   float* dxp = (float*)ws;
   char* ws2 = (char*)ws + ((vcg_thin_dgrad_workspace(g) + 255) / 256) * 256;
-  if (vcg_thin_fold_fwd(f, dy, wkd, w_amax, nullptr, dxp, ws2, ws_bytes - (size_t)(ws2 - (char*)ws), st)) return -2;
+  if (vcg_thin_fold_fwd(f, dy, wkd, w_amax, nullptr, dxp, ws2, ws_bytes - (size_t)(ws2 - (char*)ws), st, dy_handle)) return -2;
   size_t total = (size_t)g.N * g.H * g.W;
   int blocks = (int)((total + 255) / 256);
   if (blocks > 2048) blocks = 2048;

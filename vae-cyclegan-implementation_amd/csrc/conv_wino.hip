@@ -30,6 +30,10 @@ struct WinoP {
   FastDiv fd_k4, fd_tw, fd_thtw, fd_c4, fd_co4;
   unsigned long long* amax_slot;   // k_wino_in / k_wino_dy: where the largest magnitude of what they write goes (vcg_common.h), or null
   uint32_t amax_gen;
+  // k_wino_in, planes mode (vplanes != null): V is written already split — fp16 planes [xi][t][Kc / 32][2][32] of V / s, the A
+  // operand of the GEMM as a pure copy — with s from the INPUT's amax: |B^T d B| <= 4 max|d|, so its scale is known before V is
+  VcgAmax amax_x;
+  unsigned short* vplanes;
 };
 
 __device__ __forceinline__ float4 f4sub(const float4& a, const float4& b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
@@ -92,6 +96,66 @@ __global__ __launch_bounds__(256) void k_wino_in(WinoP p) {
     }
   }
   if (p.amax_slot) vcg_amax_publish(amax, p.amax_slot, p.amax_gen, amax_red);     // uniform: the GEMM that reads V scales by it
+}
+// the same transform, V written as pre-split planes (WinoP::vplanes)
+__global__ __launch_bounds__(256) void k_wino_in_planes(WinoP p) {
+  float sc, inv;
+  vcg_scale_of(vcg_amax_bits(p.amax_x), p.amax_x.shift, sc, inv);
+  const uint32_t k4n = (uint32_t)p.Kc / 4;
+  const size_t total = (size_t)p.T * k4n;
+  const size_t KB = (size_t)p.Kc / 32;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    const uint32_t t = (uint32_t)(idx / k4n);
+    const uint32_t k4 = (uint32_t)(idx - (size_t)t * k4n);
+    const uint32_t ph = fd_div(k4, p.fd_c4);
+    const int c = (int)(k4 - ph * (uint32_t)(p.Cin / 4)) * 4;
+    const int pi = (int)(ph >> 1), pj = (int)(ph & 1);
+    const uint32_t n = fd_div(t, p.fd_thtw);
+    const uint32_t rem = t - n * (uint32_t)(p.th * p.tw);
+    const uint32_t ty = fd_div(rem, p.fd_tw);
+    const int tx = (int)(rem - ty * (uint32_t)p.tw);
+    const float* xn = p.x + (size_t)n * p.H * p.W * p.Cin;
+    float4 d[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      int ih = 2 * (int)ty - p.off + r;
+      bool okh = true;
+      if (p.reflect) ih = reflect_idx(ih, p.Hl);
+      else okh = ih >= 0 && ih < p.Hl;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        int iw = 2 * tx - p.off + s;
+        bool ok = okh;
+        if (p.reflect) iw = reflect_idx(iw, p.Wl);
+        else ok = ok && iw >= 0 && iw < p.Wl;
+        d[r][s] = ok ? *reinterpret_cast<const float4*>(xn + ((size_t)(ih * p.ups + pi) * p.W + (iw * p.ups + pj)) * p.Cin + c)
+                     : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+    float4 e[4][4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      e[0][s] = f4sub(d[0][s], d[2][s]);
+      e[1][s] = f4sum(d[1][s], d[2][s]);
+      e[2][s] = f4sub(d[2][s], d[1][s]);
+      e[3][s] = f4sub(d[1][s], d[3][s]);
+    }
+    const uint32_t k = k4 * 4;
+    unsigned short* vb = p.vplanes + ((size_t)t * KB + k / 32) * VCG_PBLK + (k & 31);
+    const size_t plane = (size_t)p.T * KB * VCG_PBLK;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      const float4 o[4] = {f4sub(e[a][0], e[a][2]), f4sum(e[a][1], e[a][2]), f4sub(e[a][2], e[a][1]), f4sub(e[a][1], e[a][3])};
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        uint2 h, l;
+        split4h(o[b], inv, h, l);
+        unsigned short* q = vb + (size_t)(a * 4 + b) * plane;
+        *reinterpret_cast<uint2*>(q) = h;
+        *reinterpret_cast<uint2*>(q + 32) = l;
+      }
+    }
+  }
 }
 
 // one thread: one tile x 4 output channels; y = A^T m A, A^T = [[1, 1, 1, 0], [0, 1, -1, -1]]

@@ -40,7 +40,9 @@ __device__ __forceinline__ float4 gs_bload4(__amdgpu_buffer_rsrc_t r, uint32_t o
 }
 #define GS_OOB 0x80000000u
 
-template <int BN>
+// APL: A comes pre-split too (k_wino_in_planes: fp16 planes [rows][K / 32][2][32] of A / sA) — both operands are staged with
+// plain 16-byte copies and the K loop has no conversion arithmetic at all.
+template <int BN, bool APL = false>
 __global__ __launch_bounds__(256, 2) void k_gemm_split(GemmSplitP p) {
   constexpr int BM = 128, NI = BN / 64, MI = 2, AR = BM / 32;
   // [piece][row][32 fp16] as raw bytes: 64 B per row
@@ -68,7 +70,9 @@ __global__ __launch_bounds__(256, 2) void k_gemm_split(GemmSplitP p) {
     nt = (int)(l - (uint32_t)mt * gridDim.y);
   }
   const int m0 = mt * BM, n0 = nt * BN;
-  const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)(p.a + (size_t)zb * p.a_bstride), 0, (int)p.a_bytes, 0x00020000),
+  const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(
+                                   APL ? (void*)((const unsigned short*)p.a + (size_t)zb * p.a_bstride) : (void*)(p.a + (size_t)zb * p.a_bstride), 0,
+                                   (int)p.a_bytes, 0x00020000),
                                rb = __builtin_amdgcn_make_buffer_rsrc((void*)((const unsigned short*)p.bt + (size_t)zb * p.b_bstride), 0, (int)p.b_bytes, 0x00020000);
   const int s_row = tid >> 3, s_u = tid & 7;                    // staging: row (+32 i), k quad
   uint32_t aoff[AR];
@@ -103,22 +107,42 @@ __global__ __launch_bounds__(256, 2) void k_gemm_split(GemmSplitP p) {
       for (int e = 0; e < 16; ++e) acc[i][j][e] = lo[i][j][e] = 0.f;
 
   float4 va[AR];
-  u32x4g vb[BP];
+  u32x4g vb[BP], vap[2 * VCG_NP];
+  // A planes: the B pattern on the 128 rows of the M tile (rows past the matrix read as zeros)
+  uint32_t apoff[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int r = m0 + b_r + 64 * h;
+    apoff[h] = r < p.rows ? (uint32_t)(((size_t)r * KB) * VCG_PBYTES + b_q * 16) : GS_OOB;
+  }
+  (void)vap; (void)apoff;
   const int nkt = KB;                                           // K % 32 == 0 (the planes' block size)
   auto load_tiles = [&](int kt) {
+    if constexpr (APL) {
 #pragma unroll
-    for (int i = 0; i < AR; ++i) va[i] = gs_bload4(ra, aoff[i] != GS_OOB ? aoff[i] + (uint32_t)kt * 128u : GS_OOB);
+      for (int j = 0; j < 2 * VCG_NP; ++j)
+        vap[j] = __builtin_amdgcn_raw_buffer_load_b128(
+            ra, (int)(apoff[j / VCG_NP] != GS_OOB ? apoff[j / VCG_NP] + (uint32_t)(j % VCG_NP) * 64u + (uint32_t)kt * VCG_PBYTES : GS_OOB), 0, 0);
+    } else {
+#pragma unroll
+      for (int i = 0; i < AR; ++i) va[i] = gs_bload4(ra, aoff[i] != GS_OOB ? aoff[i] + (uint32_t)kt * 128u : GS_OOB);
+    }
 #pragma unroll
     for (int j = 0; j < BP; ++j)
       vb[j] = __builtin_amdgcn_raw_buffer_load_b128(rb, (int)(boff0 + (uint32_t)(j / VCG_NP) * bhalf + (uint32_t)(j % VCG_NP) * 64u + (uint32_t)kt * VCG_PBYTES), 0, 0);
   };
   auto store_tiles = [&]() {
+    if constexpr (APL) {
 #pragma unroll
-    for (int i = 0; i < AR; ++i) {
-      uint2 h, l;
-      split4h(va[i], inv_a, h, l);
-      *reinterpret_cast<uint2*>(&As[0][soff[i]]) = h;
-      *reinterpret_cast<uint2*>(&As[1][soff[i]]) = l;
+      for (int j = 0; j < 2 * VCG_NP; ++j) *reinterpret_cast<u32x4g*>(&As[j % VCG_NP][bsoff0 + 4096 * (j / VCG_NP)]) = vap[j];
+    } else {
+#pragma unroll
+      for (int i = 0; i < AR; ++i) {
+        uint2 h, l;
+        split4h(va[i], inv_a, h, l);
+        *reinterpret_cast<uint2*>(&As[0][soff[i]]) = h;
+        *reinterpret_cast<uint2*>(&As[1][soff[i]]) = l;
+      }
     }
 #pragma unroll
     for (int j = 0; j < BP; ++j) *reinterpret_cast<u32x4g*>(&Bs[j % VCG_NP][bsoff0 + 4096 * (j / VCG_NP)]) = vb[j];
@@ -206,6 +230,30 @@ int vcg_split_planes(const float* x, void* bp, size_t rows, int K, const VcgAmax
   return 0;
 }
 
+// both operands as blocked planes (A from k_wino_in_planes: [batch][rows][K / 32][2][32]); K % 32 == 0, N % 64 == 0
+int vcg_gemm_planes_batched(const void* APlanes, const void* BtPlanes, float* C, int rows, int K, int N, int batches, const VcgAmax& amax_a,
+                            const VcgAmax& amax_b, hipStream_t st, uint32_t* amax_a_keep) {
+  VCG_CHECK_ARG(K % 32 == 0 && N % 64 == 0 && rows > 0, "vcg_gemm_planes_batched: bad shape rows=%d K=%d N=%d", rows, K, N);
+  VCG_CHECK_ARG((unsigned long long)rows * K * 2 * VCG_NP < (1ull << 31) && (unsigned long long)N * K * 2 * VCG_NP < (1ull << 31),
+                "vcg_gemm_planes_batched: operand extents must stay below 2 GiB per batch");
+  VCG_CHECK_ARG((unsigned long long)rows * K * VCG_NP * (unsigned long long)batches < (1ull << 32) &&
+                    (unsigned long long)N * K * VCG_NP * (unsigned long long)batches < (1ull << 32),
+                "vcg_gemm_planes_batched: batch stride overflow");
+  GemmSplitP p;
+  p.a = (const float*)APlanes; p.bt = (const float*)BtPlanes; p.c = C; p.rows = rows; p.K = K; p.N = N;
+  p.a_bytes = (uint32_t)((size_t)rows * K * 2 * VCG_NP); p.b_bytes = (uint32_t)((size_t)N * K * 2 * VCG_NP);
+  p.a_bstride = (uint32_t)((size_t)rows * K * VCG_NP); p.b_bstride = (uint32_t)((size_t)N * K * VCG_NP);
+  p.c_bstride = (size_t)rows * N;
+  p.amax_a = amax_a; p.amax_b = amax_b; p.amax_a_keep = amax_a_keep;
+  const int bn = (N % 128 == 0) ? 128 : 64;
+  dim3 grid((rows + 127) / 128, N / bn, batches);
+  VcgProfScope prof(bn == 128 ? "k_gemm_split<128, planes>" : "k_gemm_split<64, planes>", 2.0 * rows * (double)K * N * batches, st);
+  if (bn == 128) hipLaunchKernelGGL((k_gemm_split<128, true>), grid, dim3(256), 0, st, p);
+  else hipLaunchKernelGGL((k_gemm_split<64, true>), grid, dim3(256), 0, st, p);
+  VCG_LAUNCH_CHECK("vcg_gemm_planes_batched");
+  return 0;
+}
+
 // rows x K (fp32) times (N x K)^T (blocked planes) per batch; K % 32 == 0, N % 64 == 0
 int vcg_gemm_split_batched(const float* A, const void* BtPlanes, float* C, int rows, int K, int N, int batches, const VcgAmax& amax_a,
                            const VcgAmax& amax_b, hipStream_t st, uint32_t* amax_a_keep) {
@@ -225,8 +273,8 @@ int vcg_gemm_split_batched(const float* A, const void* BtPlanes, float* C, int r
   const int bn = (N % 128 == 0) ? 128 : 64;
   dim3 grid((rows + 127) / 128, N / bn, batches);
   VcgProfScope prof(bn == 128 ? "k_gemm_split<128>" : "k_gemm_split<64>", 2.0 * rows * (double)K * N * batches, st);
-  if (bn == 128) hipLaunchKernelGGL(k_gemm_split<128>, grid, dim3(256), 0, st, p);
-  else hipLaunchKernelGGL(k_gemm_split<64>, grid, dim3(256), 0, st, p);
+  if (bn == 128) hipLaunchKernelGGL((k_gemm_split<128, false>), grid, dim3(256), 0, st, p);
+  else hipLaunchKernelGGL((k_gemm_split<64, false>), grid, dim3(256), 0, st, p);
   VCG_LAUNCH_CHECK("vcg_gemm_split_batched");
   return 0;
 }

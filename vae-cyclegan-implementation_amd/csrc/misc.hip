@@ -80,28 +80,74 @@ static int ew_blocks(size_t work) {
 }
 
 // ---------------------------------------------------------------- operand magnitudes for the fp16 x 2 kernels (vcg_common.h)
-// 4096 slots of 64 {generation, amax bits} words, zero at load; a slot is reused every 4096 calls, long after its last reader
-// (a stream runs a call's kernels in order, and a call's slot is read only by that call's own kernels).
-#define VCG_AMAX_SLOTS 4096
+// 16384 slots of 64 {generation, amax bits} words (8 MB), zero at load; a slot is reused every 16384 calls — a training step of the
+// largest model makes about a thousand — and a handle that old is refused (vcg_operand_amax), so no reader ever meets a reused slot.
+#define VCG_AMAX_SLOTS 16384
 __device__ unsigned long long g_vcg_amax_slots[VCG_AMAX_SLOTS * 64];
 #include <atomic>
-static std::atomic<uint32_t> g_amax_gen{0};
+static std::atomic<uint64_t> g_amax_gen{0};       // the slot words carry its low 32 bits; the high bits count wrap-arounds
+static unsigned long long* amax_base(int dev);
 VcgAmaxOut vcg_amax_new(hipStream_t) {
-  static thread_local unsigned long long* base[64] = {};
   int dev = 0;
   (void)hipGetDevice(&dev);
-  if (dev < 0 || dev >= 64) dev = 0;
+  unsigned long long* base = amax_base(dev);
+  VcgAmaxOut o;
+  uint64_t g64 = ++g_amax_gen;
+  if ((uint32_t)g64 == 0) g64 = ++g_amax_gen;    // generation 0 is "never written"
+  // after 2^32 generations (days of training) the 32-bit tags start over and would lose every atomicMax against what the
+  // previous round left: the first call of a round on a device waits for the device and clears its slots
+  static thread_local uint64_t round_seen[64] = {};
+  if (base && dev >= 0 && dev < 64 && round_seen[dev] != (g64 >> 32)) {
+    if (round_seen[dev] != 0 || (g64 >> 32) != 0) {
+      (void)hipDeviceSynchronize();
+      (void)hipMemset(base, 0, sizeof(unsigned long long) * VCG_AMAX_SLOTS * 64);
+    }
+    round_seen[dev] = g64 >> 32;
+  }
+  const uint32_t g = (uint32_t)g64;
+  o.gen = g;
+  o.slot = base ? base + (size_t)(g % VCG_AMAX_SLOTS) * 64 : nullptr;
+  return o;
+}
+static unsigned long long* amax_base(int dev) {
+  static thread_local unsigned long long* base[64] = {};
+  if (dev < 0 || dev >= 64) return nullptr;
   if (!base[dev]) {
     void* p = nullptr;
     if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_vcg_amax_slots)) != hipSuccess) p = nullptr;
     base[dev] = (unsigned long long*)p;
   }
-  VcgAmaxOut o;
-  uint32_t g = ++g_amax_gen;
-  if (g == 0) g = ++g_amax_gen;                  // generation 0 is "never written"
-  o.gen = g;
-  o.slot = base[dev] ? base[dev] + (size_t)(g % VCG_AMAX_SLOTS) * 64 : nullptr;
-  return o;
+  return base[dev];
+}
+#define VCG_HANDLE_MAGIC 0xA5ull
+uint64_t vcg_amax_handle(const VcgAmaxOut& o) {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  return o.slot ? (VCG_HANDLE_MAGIC << 56) | ((uint64_t)(dev & 0xFF) << 40) | o.gen : 0;
+}
+static thread_local uint64_t t_hint_x = 0, t_hint_dy = 0, t_last_amax = 0;
+uint64_t vcg_take_hint_x() { const uint64_t h = t_hint_x; t_hint_x = 0; return h; }
+uint64_t vcg_take_hint_dy() { const uint64_t h = t_hint_dy; t_hint_dy = 0; return h; }
+void vcg_set_last_amax(uint64_t h) { t_last_amax = h; }
+extern "C" void vcg_amax_hint(uint64_t x_amax, uint64_t dy_amax) { t_hint_x = x_amax; t_hint_dy = dy_amax; }
+extern "C" uint64_t vcg_amax_last(void) { const uint64_t h = t_last_amax; t_last_amax = 0; return h; }
+int vcg_operand_amax(const float* t, size_t n, uint64_t handle, int shift, hipStream_t st, VcgAmax* out) {
+  if ((handle >> 56) == VCG_HANDLE_MAGIC) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const uint32_t gen = (uint32_t)handle;
+    const uint32_t age = (uint32_t)g_amax_gen.load() - gen;
+    unsigned long long* base = amax_base(dev);
+    if (base && (int)((handle >> 40) & 0xFF) == (dev & 0xFF) && gen != 0 && age < VCG_AMAX_SLOTS - 1024) {
+      VcgAmaxOut o; o.gen = gen; o.slot = base + (size_t)(gen % VCG_AMAX_SLOTS) * 64;
+      *out = vcg_amax_in(o, shift);
+      return 0;
+    }
+  }
+  const VcgAmaxOut o = vcg_amax_new(st);
+  if (vcg_absmax_launch(t, n, o, st)) return -2;
+  *out = vcg_amax_in(o, shift);
+  return 0;
 }
 __global__ __launch_bounds__(256) void k_absmax(const float* __restrict__ tf, size_t n, unsigned long long* __restrict__ slot, uint32_t gen) {
   __shared__ uint32_t red[4];

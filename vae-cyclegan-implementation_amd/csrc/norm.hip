@@ -137,10 +137,14 @@ __global__ void k_in_final(const double* __restrict__ part, float* __restrict__ 
   }
 }
 
+// (every kernel below that writes an activation or a gradient also publishes its largest magnitude — vcg_common.h: the
+// convolution that reads the tensor scales it by that instead of measuring it with a pass of its own)
 __global__ __launch_bounds__(256) void k_in_apply(const float* __restrict__ t, const float* __restrict__ mean,
                                                   const float* __restrict__ rstd, const float* __restrict__ residual,
                                                   float* __restrict__ out, int N, int H, int W, int C, int post_act,
-                                                  int shuffle) {
+                                                  int shuffle, unsigned long long* amax_slot, uint32_t amax_gen) {
+  __shared__ uint32_t amax_red[4];
+  uint32_t amax = 0;
   const int C4 = C / 4;
   const size_t total = (size_t)N * H * W * C4;
   for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
@@ -160,6 +164,7 @@ __global__ __launch_bounds__(256) void k_in_apply(const float* __restrict__ t, c
       float4 r = *reinterpret_cast<const float4*>(residual + pixg * C + c4 * 4);
       o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
     }
+    amax = max(amax, vcg_abs_bits4(o));
     if (shuffle) {
       const int pix = (int)(pixg - (size_t)n * H * W);
       const int h = pix / W, w = pix - h * W;
@@ -172,13 +177,17 @@ __global__ __launch_bounds__(256) void k_in_apply(const float* __restrict__ t, c
       *reinterpret_cast<float4*>(out + pixg * C + c4 * 4) = o;
     }
   }
+  if (amax_slot) vcg_amax_publish(amax, amax_slot, amax_gen, amax_red);
 }
 
 // dt = epi'(t) * rstd * (g' - s1 - xhat * s2)
 __global__ __launch_bounds__(256) void k_in_bwd_apply(const float* __restrict__ g, const float* __restrict__ t,
                                                       const float* __restrict__ mean, const float* __restrict__ rstd,
                                                       const float* __restrict__ s12, float* __restrict__ dt, int N,
-                                                      int H, int W, int C, int epi_act, int post_act, int shuffle) {
+                                                      int H, int W, int C, int epi_act, int post_act, int shuffle,
+                                                      unsigned long long* amax_slot, uint32_t amax_gen) {
+  __shared__ uint32_t amax_red[4];
+  uint32_t amax = 0;
   const int C4 = C / 4;
   const size_t total = (size_t)N * H * W * C4;
   for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
@@ -213,11 +222,16 @@ __global__ __launch_bounds__(256) void k_in_bwd_apply(const float* __restrict__ 
     xh = (v.w - mu.w) * rs.w; gg = gv.w * act_grad_from_in(xh, post_act);
     o.w = act_grad_from_out(v.w, epi_act) * rs.w * (gg - sp[6] - xh * sp[7]);
     *reinterpret_cast<float4*>(dt + pixg * C + c4 * 4) = o;
+    amax = max(amax, vcg_abs_bits4(o));
   }
+  if (amax_slot) vcg_amax_publish(amax, amax_slot, amax_gen, amax_red);
 }
 
 __global__ __launch_bounds__(256) void k_act_bwd(const float* __restrict__ g, const float* __restrict__ t,
-                                                 float* __restrict__ dt, size_t n4, int act) {
+                                                 float* __restrict__ dt, size_t n4, int act, unsigned long long* amax_slot,
+                                                 uint32_t amax_gen) {
+  __shared__ uint32_t amax_red[4];
+  uint32_t amax = 0;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
     float4 gv = reinterpret_cast<const float4*>(g)[i];
     float4 tv = reinterpret_cast<const float4*>(t)[i];
@@ -227,7 +241,9 @@ __global__ __launch_bounds__(256) void k_act_bwd(const float* __restrict__ g, co
     o.z = gv.z * act_grad_from_out(tv.z, act);
     o.w = gv.w * act_grad_from_out(tv.w, act);
     reinterpret_cast<float4*>(dt)[i] = o;
+    amax = max(amax, vcg_abs_bits4(o));
   }
+  if (amax_slot) vcg_amax_publish(amax, amax_slot, amax_gen, amax_red);
 }
 
 static int ew_blocks(size_t work) {
@@ -272,9 +288,11 @@ extern "C" int vcg_in_apply(const float* t, const float* mean, const float* rstd
   VCG_CHECK_ARG(!(shuffle && residual), "vcg_in_apply: shuffle with residual unsupported");
   VCG_CHECK_ARG(!shuffle || C % 16 == 0, "vcg_in_apply: pixel shuffle needs C %% 16 == 0 (channel pitch stays a multiple of 4)");
   size_t total = (size_t)N * H * W * (C / 4);
+  const VcgAmaxOut ao = vcg_amax_new((hipStream_t)stream);
   hipLaunchKernelGGL(k_in_apply, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, t, mean, rstd, residual,
-                     out, N, H, W, C, post_act, shuffle);
+                     out, N, H, W, C, post_act, shuffle, ao.slot, ao.gen);
   VCG_LAUNCH_CHECK("vcg_in_apply");
+  vcg_set_last_amax(vcg_amax_handle(ao));               // vcg_amax_last(): the largest magnitude of `out`
   return 0;
 }
 
@@ -295,17 +313,21 @@ extern "C" int vcg_in_bwd(const float* g, const float* t, const float* mean, con
   hipLaunchKernelGGL(k_in_final<1>, dim3((N * C + 31) / 32), dim3(256), 0, st, (const double*)part, s12,
                      (float*)nullptr, N, HW, C, pl.nchunk, 0.f);
   size_t total = (size_t)N * HW * (C / 4);
+  const VcgAmaxOut ao = vcg_amax_new(st);
   hipLaunchKernelGGL(k_in_bwd_apply, dim3(ew_blocks(total)), dim3(256), 0, st, g, t, mean, rstd, (const float*)s12,
-                     dt, N, H, W, C, epi_act, post_act, shuffle);
+                     dt, N, H, W, C, epi_act, post_act, shuffle, ao.slot, ao.gen);
   VCG_LAUNCH_CHECK("vcg_in_bwd");
+  vcg_set_last_amax(vcg_amax_handle(ao));               // vcg_amax_last(): the largest magnitude of `dt`
   return 0;
 }
 
 extern "C" int vcg_act_bwd(const float* g, const float* t, float* dt, size_t n, int act, void* stream) {
   VCG_CHECK_ARG(g && t && dt, "vcg_act_bwd: null pointer");
   VCG_CHECK_ARG(n % 4 == 0, "vcg_act_bwd: n must be a multiple of 4");
-  hipLaunchKernelGGL(k_act_bwd, dim3(ew_blocks(n / 4)), dim3(256), 0, (hipStream_t)stream, g, t, dt, n / 4, act);
+  const VcgAmaxOut ao = vcg_amax_new((hipStream_t)stream);
+  hipLaunchKernelGGL(k_act_bwd, dim3(ew_blocks(n / 4)), dim3(256), 0, (hipStream_t)stream, g, t, dt, n / 4, act, ao.slot, ao.gen);
   VCG_LAUNCH_CHECK("vcg_act_bwd");
+  vcg_set_last_amax(vcg_amax_handle(ao));
   return 0;
 }
 

@@ -165,6 +165,17 @@ static inline VcgAmax vcg_amax_in(const VcgAmaxOut& o, int shift = 0) { VcgAmax 
 static inline VcgAmax vcg_amax_stored(const void* bits_ptr, int shift = 0) { VcgAmax a; a.slot = nullptr; a.stored = (const uint32_t*)bits_ptr; a.gen = 0; a.bits = 0; a.shift = shift; return a; }
 static inline VcgAmax vcg_amax_const(uint32_t bits, int shift = 0) { VcgAmax a; a.slot = nullptr; a.stored = nullptr; a.gen = 0; a.bits = bits; a.shift = shift; return a; }
 int vcg_absmax_launch(const float* t, size_t n, const VcgAmaxOut& out, hipStream_t st);      // t 16-byte aligned
+// A HANDLE names a published amax across C-ABI calls (include/vcg.h, vcg_amax_hint / vcg_amax_last): the kernels that write an
+// activation or a gradient (InstanceNorm apply / backward, activation backward) publish its largest magnitude as a by-product,
+// and the convolution that reads the tensor — in the same forward, or many calls later in the backward — takes the handle
+// instead of measuring the tensor again.  A handle goes stale when its slot is about to be reused (the generation counter has
+// moved on by nearly the slot count): the consumer then measures, as it does for a tensor without a handle.
+uint64_t vcg_amax_handle(const VcgAmaxOut& o);
+// the operand's amax: from `handle` when it is still valid, else from a pass over the tensor (t, n)
+int vcg_operand_amax(const float* t, size_t n, uint64_t handle, int shift, hipStream_t st, VcgAmax* out);
+uint64_t vcg_take_hint_x();          // the handles the caller announced for the NEXT conv call on this thread (consumed)
+uint64_t vcg_take_hint_dy();
+void vcg_set_last_amax(uint64_t h);  // what vcg_amax_last() returns
 
 #ifdef __HIPCC__
 // block-wide: every thread contributes the bit pattern of a magnitude; one atomicMax per block.  `red` = 4+ words of LDS.
@@ -275,7 +286,7 @@ int vcg_wino_wgrad(const ConvGeom& g, const float* x, const float* dy, float* gw
                    const float* v_saved = nullptr);
 size_t vcg_wino_wgrad_core_workspace(const ConvGeom& g, int T);
 int vcg_wino_wgrad_core(const ConvGeom& g, const float* V, const float* dM, int T, float* gw_oihw, void* ws, size_t ws_bytes,
-                        hipStream_t st, const VcgAmax& amax_v, const VcgAmax& amax_dm);
+                        hipStream_t st, const VcgAmax& amax_v, const VcgAmax& amax_dm, bool v_planes);
 bool vcg_wino_dgrad_ok(const ConvGeom& g);
 size_t vcg_wino_dgrad_workspace(const ConvGeom& g);
 int vcg_wino_weight_dgrad(const ConvGeom& g, const float* w_oihw, float* ud, const VcgAmax& amax_w, hipStream_t st);
@@ -288,23 +299,24 @@ int vcg_slab_fwd_nchunk(const ConvGeom& g);
 bool vcg_slab_dgrad_ok(const ConvGeom& g);
 size_t vcg_slab_dgrad_workspace(const ConvGeom& g);
 int vcg_slab_fwd(const ConvGeom& g, const float* x, const void* wft_planes, size_t planes_bytes, const void* w_amax, const float* bias,
-                 float* y, double* in_part, int* in_nchunk, hipStream_t st);
+                 float* y, double* in_part, int* in_nchunk, hipStream_t st, uint64_t x_handle = 0);
 int vcg_slab_dgrad(const ConvGeom& g, const float* dy, const void* wfd_planes, size_t planes_bytes, const void* w_amax, float* dx,
-                   void* ws, size_t ws_bytes, hipStream_t st);
+                   void* ws, size_t ws_bytes, hipStream_t st, uint64_t dy_handle = 0);
 // conv_ring.hip: weight gradients of U4 / head / stem with row-ring staging (the taps are address offsets of the fragment reads)
 bool vcg_ring_wgrad_ok(const ConvGeom& g);
 size_t vcg_ring_wgrad_workspace(const ConvGeom& g);
-int vcg_ring_wgrad(const ConvGeom& g, const float* x, const float* dy, float* gw_oihw, void* ws, size_t ws_bytes, hipStream_t st);
+int vcg_ring_wgrad(const ConvGeom& g, const float* x, const float* dy, float* gw_oihw, void* ws, size_t ws_bytes, hipStream_t st,
+                   uint64_t x_handle = 0, uint64_t dy_handle = 0);
 // conv_thin.hip: thin forward with kw folded into the GEMM's N (MFMA)
 bool vcg_thin_fold_ok(const ConvGeom& g);
 size_t vcg_thin_fold_weight_floats(const ConvGeom& g);
 size_t vcg_thin_fold_workspace(const ConvGeom& g);
 int vcg_thin_fold_pack(const ConvGeom& g, const float* w_oihw, float* wk, const VcgAmax& amax_w, hipStream_t st);
 int vcg_thin_fold_fwd(const ConvGeom& g, const float* x, const float* wk, const void* w_amax, const float* bias, float* y, void* ws,
-                      size_t ws_bytes, hipStream_t st);
+                      size_t ws_bytes, hipStream_t st, uint64_t x_handle = 0);
 bool vcg_thin_fold_dgrad_ok(const ConvGeom& g);
 size_t vcg_thin_fold_dgrad_weight_floats(const ConvGeom& g);
 size_t vcg_thin_fold_dgrad_workspace(const ConvGeom& g);
 int vcg_thin_fold_dgrad_pack(const ConvGeom& g, const float* w_oihw, float* wk, const VcgAmax& amax_w, hipStream_t st);
 int vcg_thin_fold_dgrad(const ConvGeom& g, const float* dy, const float* wkd, const void* w_amax, float* dx, void* ws, size_t ws_bytes,
-                        hipStream_t st);
+                        hipStream_t st, uint64_t dy_handle = 0);

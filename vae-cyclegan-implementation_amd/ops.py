@@ -293,6 +293,10 @@ def repack_async(params):
             sp.packed(w)
 
 
+# Hand the largest magnitude of an activation / gradient from the kernel that wrote it to the convolution that reads it
+# (include/vcg.h, vcg_amax_hint).  VCG_AMAX_HANDLES=0: every convolution measures its operands itself (A/B measurements).
+AMAX_HANDLES = os.environ.get("VCG_AMAX_HANDLES", "1") != "0"
+
 # Keep the forward's Winograd-transformed input for the weight gradient (VCG_KEEP_FORWARD_STATE=0: recompute it, as round 1 did)
 KEEP_FORWARD_STATE = os.environ.get("VCG_KEEP_FORWARD_STATE", "1") != "0"
 
@@ -367,6 +371,10 @@ class _ConvBlockFn(torch.autograd.Function):
         flops = 2.0 * n * ho * wo * spec.cout * spec.k * spec.k * spec.cin
         tag = f"{n}x{h}x{w}x{spec.cin_pitch}->{spec.cout_pitch} k{spec.k} s{spec.stride} u{spec.ups}"
         mean = rstd = saved = None
+        # operand magnitudes (include/vcg.h): the block that wrote x left a handle to its largest magnitude on the tensor; the
+        # kernels scale x by it instead of measuring x again (0: unknown, they measure)
+        x_amax = int(getattr(x, "_vcg_amax", 0)) if AMAX_HANDLES else 0
+        out_amax = 0
         # forward state the weight gradient can reuse (the Winograd-transformed input V: 4x the activation — HBM is 288 GB)
         # (grad mode is off inside Function.forward: needs_input_grad[1] says whether a backward for the weight will come)
         if wparam is not None and wparam.requires_grad and ctx.needs_input_grad[1] and KEEP_FORWARD_STATE:
@@ -381,6 +389,7 @@ class _ConvBlockFn(torch.autograd.Function):
             rstd = torch.empty((n, c), dtype=torch.float32, device=dev)
             with _timed("conv_fwd", flops, tag):
                 ws = workspace(lib.vcg_conv_fwd_in_workspace(cd), dev)
+                lib.vcg_amax_hint(x_amax, 0)
                 _native.check(lib.vcg_conv_fwd_in(_ptr(xp), _ptr(wf), _ptr(bias), _ptr(t), _ptr(mean), _ptr(rstd), IN_EPS,
                                                   _ptr(saved), cd, _ptr(ws), ws.numel() * 4, _stream()), "vcg_conv_fwd_in")
             resp = as_phys(residual) if residual is not None else None
@@ -393,11 +402,13 @@ class _ConvBlockFn(torch.autograd.Function):
             with _timed("in_fwd"):
                 _native.check(lib.vcg_in_apply(_ptr(t), _ptr(mean), _ptr(rstd), _ptr(resp), _ptr(outp), n, ho, wo, c,
                                                spec.post_act, int(spec.shuffle), _stream()), "vcg_in_apply")
+                out_amax = int(lib.vcg_amax_last())
         else:
             if residual is not None or spec.shuffle or spec.post_act:
                 raise RuntimeError("residual/shuffle/post_act need norm=True")
             with _timed("conv_fwd", flops, tag):
                 ws = workspace(lib.vcg_conv_fwd_workspace(cd), dev)
+                lib.vcg_amax_hint(x_amax, 0)
                 _native.check(lib.vcg_conv_fwd_in(_ptr(xp), _ptr(wf), _ptr(bias), _ptr(t), None, None, IN_EPS, _ptr(saved), cd,
                                                   _ptr(ws), ws.numel() * 4, _stream()), "vcg_conv_fwd_in")
             outp, cout_log = t, spec.cout
@@ -405,8 +416,12 @@ class _ConvBlockFn(torch.autograd.Function):
         ctx.wparam, ctx.bparam = wparam, bparam
         ctx.has_res = residual is not None
         ctx.saved_state = saved
+        ctx.x_amax = x_amax
         ctx.save_for_backward(xp, t, mean, rstd, wf)
-        return logical_of(outp, cout_log)
+        out = logical_of(outp, cout_log)
+        if out_amax:
+            out._vcg_amax = out_amax          # for the block that consumes this very tensor object
+        return out
 
     @staticmethod
     def backward(ctx, g):
@@ -426,11 +441,14 @@ class _ConvBlockFn(torch.autograd.Function):
                 _native.check(lib.vcg_in_bwd(_ptr(gp), _ptr(t), _ptr(mean), _ptr(rstd), _ptr(dt), n, ho, wo, c,
                                              spec.epi_act, spec.post_act, int(spec.shuffle), _ptr(ws), ws.numel() * 4,
                                              _stream()), "vcg_in_bwd")
+            dt_amax = int(lib.vcg_amax_last()) if AMAX_HANDLES else 0
         elif spec.epi_act != ACT_NONE:
             dt = torch.empty_like(t)
             _native.check(lib.vcg_act_bwd(_ptr(gp), _ptr(t), _ptr(dt), t.numel(), spec.epi_act, _stream()), "vcg_act_bwd")
+            dt_amax = int(lib.vcg_amax_last()) if AMAX_HANDLES else 0
         else:
             dt = gp
+            dt_amax = 0
         wparam, bparam = ctx.wparam, ctx.bparam
         saved = ctx.saved_state
         if wparam is not None and wparam.requires_grad and id(wparam) not in _NO_WGRAD:
@@ -449,6 +467,7 @@ class _ConvBlockFn(torch.autograd.Function):
             def run_wgrad():
                 ws = workspace(wsb, dev)
                 with _timed("conv_wgrad", ctx.flops, ctx.tag):
+                    lib.vcg_amax_hint(ctx.x_amax, dt_amax)
                     _native.check(lib.vcg_conv_wgrad_saved(_ptr(xp), _ptr(dt), _ptr(gw), _ptr(gb), _ptr(saved), cd, _ptr(ws),
                                                            ws.numel() * 4, _stream()), "vcg_conv_wgrad")
             if _OVERLAP[0]:
@@ -471,6 +490,7 @@ class _ConvBlockFn(torch.autograd.Function):
             dxp = torch.empty_like(xp)
             with _timed("conv_dgrad", ctx.flops, ctx.tag):
                 ws = workspace(lib.vcg_conv_dgrad_workspace(cd), dev)
+                lib.vcg_amax_hint(0, dt_amax)
                 _native.check(lib.vcg_conv_dgrad(_ptr(dt), _ptr(wf), _ptr(dxp), cd, _ptr(ws), ws.numel() * 4,
                                                  _stream()), "vcg_conv_dgrad")
             dx = logical_of(dxp, spec.cin_phys_log)
