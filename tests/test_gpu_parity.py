@@ -308,11 +308,114 @@ def test_conv_fwd_in_equals_conv_then_statistics(case, pkg, device):
                   "vcg_conv_wgrad_saved")
         grads.append((gw.clone(), gb.clone()))
     if nsv:
-        # the kept V, then a 16-float tail whose first word is the bit pattern of V's largest magnitude (the scale of the fp16 x 2
-        # GEMMs that read V: csrc/vcg_common.h)
-        assert torch.isfinite(saved[:nsv - 16]).all()
-        assert saved[nsv - 16:nsv - 15].view(torch.int32).item() == saved[:nsv - 16].abs().max().view(torch.int32).item()
+        # the kept V — pre-split fp16 planes of V / s — then a 16-float tail whose first word is the bit pattern of the largest
+        # magnitude of the conv INPUT: s is derived from it (|B^T d B| <= 4 max|d|, csrc/conv_wino.hip) and the weight gradient's
+        # GEMMs must scale V the same way
+        assert saved[nsv - 16:nsv - 15].view(torch.int32).item() == xp.abs().max().view(torch.int32).item()
         assert torch.equal(grads[0][0], grads[1][0]) and torch.equal(grads[0][1], grads[1][1])
+
+
+# ------------------------------------------------------------------ fp16 x 2 operand scaling (round 3; csrc/vcg_common.h)
+def _ref_conv_block(x, w, b, k, pad, ups):
+    """float64 reference of a bare reflect-padded conv (+ folded PixelUnshuffle) on NCHW tensors"""
+    xd = x.double().cpu()
+    if ups == 2:
+        xd = F.pixel_unshuffle(xd, 2)
+    return F.conv2d(F.pad(xd, (pad,) * 4, mode="reflect"), w.double().cpu(), b.double().cpu())
+
+
+@pytest.mark.parametrize("xscale,wscale", [(1.0, 1.0), (3e-21, 2e19), (7e17, 1e-16), (1e-30, 1.0)])
+@pytest.mark.parametrize("shape", [(2, 128, 128, 3, 1, 16), (2, 64, 128, 3, 2, 32), (1, 32, 64, 3, 1, 64), (2, 64, 3, 7, 1, 32)],
+                         ids=["wino128", "wino_unshuffle", "slab_ring", "head7"])
+def test_operand_scales_follow_the_tensors(shape, xscale, wscale, pkg, device):
+    """The MFMA kernels see every operand as two fp16 pieces of x / s with s a power of two from the tensor's largest magnitude:
+    the result must not depend on where in fp32's range the tensors sit.  Forward, data gradient and weight gradient of a conv
+    whose input / weights are 1e-21 ... 1e+18 apart in magnitude, against float64, relative to the result's own scale."""
+    n, cin, cout, k, ups, h = shape
+    ops = pkg.ops
+    pad = k // 2
+    spec = ops.ConvSpec(cin * (4 if ups == 2 else 1), cout, k, 1, pad, True, ups)
+    g = torch.Generator(device="cpu").manual_seed(5)
+    w = torch.nn.Parameter((torch.randn(cout, cin * (4 if ups == 2 else 1), k, k, generator=g) * wscale).to(device))
+    b = torch.nn.Parameter(torch.zeros(cout, device=device))
+    x0 = (torch.randn(n, cin, h, h, generator=g) * xscale).to(device)
+    x = ops.to_nhwc(x0).requires_grad_(True)
+    y = ops.conv_block(x, w, b, spec)
+    gy = torch.randn(tuple(y.shape), generator=g).to(device) * (1.0 / max(xscale * wscale, 1e-30)) * 1e-3
+    y.backward(ops.to_nhwc(gy))
+    xr = x0.double().cpu().requires_grad_(True)
+    wr = w.detach().double().cpu().requires_grad_(True)
+    xin = F.pixel_unshuffle(xr, 2) if ups == 2 else xr
+    yr = F.conv2d(F.pad(xin, (pad,) * 4, mode="reflect"), wr)
+    yr.backward(gy.double().cpu())
+    for what, got, ref in (("y", y, yr), ("dx", x.grad, xr.grad), ("dw", w.grad, wr.grad)):
+        got = got.detach().double().cpu()
+        assert torch.isfinite(got).all(), f"{what}: non-finite values at scales {xscale:g} x {wscale:g}"
+        err = ((got - ref.detach()).norm() / ref.detach().norm()).item()
+        assert err <= 2e-6, f"{what}: rel L2 error {err:.2e} at scales {xscale:g} x {wscale:g}"
+
+
+def test_equal_magnitude_gradients_fold_without_overflow(pkg, device):
+    """An L1 loss hands every element of dy the SAME magnitude; the data gradient of a reflect-padded conv adds up to four
+    sources that the padding folds onto a pixel next to a corner BEFORE it splits the sum — the operand of that kernel is
+    bounded by 4 x amax(dy), not by amax(dy) (found in round 3: an fp16 overflow at exactly those 58 pixels)."""
+    ops = pkg.ops
+    torch.manual_seed(0)
+    n, h = 2, 64
+    spec = ops.ConvSpec(64, 3, 7, 1, 3, True, 1)
+    w = torch.nn.Parameter(torch.randn(3, 64, 7, 7, device=device) * 0.117)
+    b = torch.nn.Parameter(torch.zeros(3, device=device))
+    x = ops.to_nhwc(torch.rand(n, 64, h, h, device=device)).requires_grad_(True)
+    y = ops.conv_block(x, w, b, spec)
+    gy = torch.sign(torch.randn(n, 3, h, h, device=device)) / (n * 3 * h * h)
+    y.backward(ops.to_nhwc(gy))
+    xr = x.detach().contiguous().double().cpu().requires_grad_(True)
+    yr = F.conv2d(F.pad(xr, (3, 3, 3, 3), mode="reflect"), w.detach().double().cpu())
+    yr.backward(gy.double().cpu())
+    assert torch.isfinite(x.grad).all()
+    assert ((x.grad.double().cpu() - xr.grad).norm() / xr.grad.norm()).item() <= 1e-6
+
+
+def test_amax_handles_change_no_bit_and_stale_ones_are_refused(pkg, device):
+    """include/vcg.h vcg_amax_hint / vcg_amax_last: a block's output carries the handle of its largest magnitude and the next
+    block scales by it instead of measuring — the measured value is the same number, so nothing may change; a handle that is not
+    (or no longer) valid must be ignored, not trusted."""
+    ops, lib = pkg.ops, pkg._native.lib()
+    torch.manual_seed(1)
+    spec1 = ops.ConvSpec(32, 64, 3, 1, 1, True, 1, ops.ACT_RELU, True)
+    spec2 = ops.ConvSpec(64, 64, 3, 1, 1, True, 1, ops.ACT_RELU, True)
+    w1 = torch.nn.Parameter(torch.randn(64, 32, 3, 3, device=device) * 0.1)
+    w2 = torch.nn.Parameter(torch.randn(64, 64, 3, 3, device=device) * 0.1)
+    b1 = torch.nn.Parameter(torch.zeros(64, device=device))
+    b2 = torch.nn.Parameter(torch.zeros(64, device=device))
+    x0 = torch.randn(2, 32, 64, 64, device=device)
+
+    def run(poison=None):
+        for p_ in (w1, w2, b1, b2):
+            p_.grad = None
+        x = ops.to_nhwc(x0).requires_grad_(True)
+        h1 = ops.conv_block(x, w1, b1, spec1)
+        if poison is not None:
+            h1._vcg_amax = poison
+        y = ops.conv_block(h1, w2, b2, spec2)
+        y.backward(ops.to_nhwc(torch.ones_like(y) * 1e-3))
+        return y.detach().clone(), x.grad.clone(), w1.grad.clone(), w2.grad.clone(), int(getattr(h1, "_vcg_amax", 0))
+
+    base = run()
+    assert base[4] != 0 and (base[4] >> 56) == 0xA5, "the block's output carries no amax handle"
+    saved = ops.AMAX_HANDLES
+    try:
+        ops.AMAX_HANDLES = False
+        off = run()
+    finally:
+        ops.AMAX_HANDLES = saved
+    for a, b_ in zip(base[:4], off[:4]):
+        assert torch.equal(a, b_), "handing the amax over instead of measuring it changed a result"
+    # a handle from ~2^31 generations ago, and plain garbage: both refused (the operand is measured), results unchanged
+    for bogus in ((0xA5 << 56) | ((base[4] & 0xFFFFFFFF) ^ 0x80000000), 0x1234567, (0x5A << 56) | 77):
+        got = run(poison=bogus)
+        for a, b_ in zip(base[:4], got[:4]):
+            assert torch.equal(a, b_), f"a stale / foreign handle ({bogus:#x}) was trusted"
 
 
 @pytest.mark.parametrize("activation,use_norm", [("Tanh", True), ("Tanh", False), ("Sigmoid", True), ("Sigmoid", False)])

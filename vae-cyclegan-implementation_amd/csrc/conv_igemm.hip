@@ -2219,7 +2219,7 @@ static int conv_fwd_impl(const float* x, const float* wf, const float* bias, flo
   if (vcg_thin_fold_ok(g)) return vcg_thin_fold_fwd(g, x, wf + wf_floats(g), vcg_pack_amax(g, wf), bias, y, ws, ws_bytes, (hipStream_t)stream, x_handle);
   if (vcg_thin_fwd_ok(g)) return vcg_thin_fwd(g, x, wf, bias, y, (hipStream_t)stream);
   if (vcg_wino_fwd_ok(g))
-    return vcg_wino_fwd(g, x, wf + wf_floats(g), vcg_pack_amax(g, wf), bias, y, ws, ws_bytes, (hipStream_t)stream, in_part, in_nchunk, saved);
+    return vcg_wino_fwd(g, x, wf + wf_floats(g), vcg_pack_amax(g, wf), bias, y, ws, ws_bytes, (hipStream_t)stream, in_part, in_nchunk, saved, x_handle);
   if (fwd_slab_ok(g))
     return vcg_slab_fwd(g, x, wf + wft_offset(g), wft_floats(g) * 4, vcg_pack_amax(g, wf), bias, y, in_part, in_nchunk, (hipStream_t)stream, x_handle);
   ConvP p; fill_params(g, p);
@@ -2359,7 +2359,7 @@ extern "C" int vcg_conv_dgrad(const float* dy, const float* wf, float* dx, const
   if (vcg_thin_fold_dgrad_ok(g)) return vcg_thin_fold_dgrad(g, dy, wf + wkd_offset(g), vcg_pack_amax(g, wf), dx, ws, ws_bytes, (hipStream_t)stream, dy_handle);
   if (vcg_thin_dgrad_ok(g)) return vcg_thin_dgrad(g, dy, wf, dx, ws, ws_bytes, (hipStream_t)stream);
   if (vcg_wino_dgrad_ok(g))
-    return vcg_wino_dgrad(g, dy, wf + wf_floats(g) + wino_u_floats(g), vcg_pack_amax(g, wf), dx, ws, ws_bytes, (hipStream_t)stream);
+    return vcg_wino_dgrad(g, dy, wf + wf_floats(g) + wino_u_floats(g), vcg_pack_amax(g, wf), dx, ws, ws_bytes, (hipStream_t)stream, dy_handle);
   if (dgrad_slab_ok(g))
     return vcg_slab_dgrad(g, dy, wf + wfd_offset(g), wfd_floats(g) * 4, vcg_pack_amax(g, wf), dx, ws, ws_bytes, (hipStream_t)stream, dy_handle);
   ConvP p; fill_params(g, p);
@@ -2583,7 +2583,7 @@ extern "C" int vcg_conv_wgrad_saved(const float* x, const float* dy, float* gw_o
   VCG_CHECK_ARG(ws_bytes >= need, "vcg_conv_wgrad: workspace %zu < %zu", ws_bytes, need);
   if (vcg_wino_wgrad_ok(g)) {
     const size_t wbytes = vcg_wino_wgrad_workspace(g);
-    if (vcg_wino_wgrad(g, x, dy, gw_oihw, ws, wbytes, (hipStream_t)stream, saved)) return -2;
+    if (vcg_wino_wgrad(g, x, dy, gw_oihw, ws, wbytes, (hipStream_t)stream, saved, x_handle)) return -2;
     if (gbias) return launch_colsum(g, dy, gbias, (float*)((char*)ws + ((wbytes + 255) / 256) * 256), (hipStream_t)stream);
     return 0;
   }

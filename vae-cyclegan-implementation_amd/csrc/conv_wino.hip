@@ -17,6 +17,17 @@ int vcg_gemm_split_batched(const float* A, const void* BtPlanes, float* C, int r
                            const VcgAmax& amax_b, hipStream_t st, uint32_t* amax_a_keep = nullptr);
 // |G g G^T| <= (1.5)^2 max|g|: the transformed kernels are bounded by 4 x the kernel's largest magnitude
 #define WINO_U_SHIFT 2
+// |B^T d B| <= 4 max|d| (two +-1 pairs): the transformed input is bounded by 4 x the input's largest magnitude
+#define WINO_V_SHIFT 2
+int vcg_gemm_planes_batched(const void* APlanes, const void* BtPlanes, float* C, int rows, int K, int N, int batches, const VcgAmax& amax_a,
+                            const VcgAmax& amax_b, hipStream_t st, uint32_t* amax_a_keep);
+// VCG_WINO_PLANES=0: V as fp32, split inside the GEMM (A/B measurements).  Default: k_wino_in writes V pre-split — the same bytes —
+// scaled by 4 x the input's amax, and the GEMMs (forward, data gradient, and the weight gradient that re-reads a kept V) stage it
+// with plain copies.
+static bool wino_planes_on() {
+  static const int on = [] { const char* e = getenv("VCG_WINO_PLANES"); return e ? atoi(e) : 1; }();
+  return on != 0;
+}
 
 struct WinoP {
   const float* x;
@@ -582,6 +593,7 @@ static WinoP wino_params(const ConvGeom& g) {
   p.fd_co4 = make_fastdiv((uint32_t)g.Cout / 4);
   p.off = 1;
   p.amax_slot = nullptr; p.amax_gen = 0;
+  p.amax_x = vcg_amax_const(0); p.vplanes = nullptr;
   return p;
 }
 
@@ -602,7 +614,7 @@ size_t vcg_wino_wgrad_workspace(const ConvGeom& g) {
 static size_t wino_v_floats(const ConvGeom& g) { return (size_t)16 * g.N * (g.Ho / 2) * (g.Wo / 2) * g.ups * g.ups * g.Cin; }
 size_t vcg_wino_saved_floats(const ConvGeom& g) { return vcg_wino_wgrad_ok(g) ? wino_v_floats(g) + 16 : 0; }
 int vcg_wino_wgrad(const ConvGeom& g, const float* x, const float* dy, float* gw_oihw, void* ws, size_t ws_bytes, hipStream_t st,
-                   const float* v_saved) {
+                   const float* v_saved, uint64_t x_handle) {
   VCG_CHECK_ARG(ws && ws_bytes >= vcg_wino_wgrad_workspace(g), "vcg_conv_wgrad: workspace too small for the Winograd path");
   WinoP p = wino_params(g);
   float* V = (float*)ws;
@@ -610,9 +622,15 @@ int vcg_wino_wgrad(const ConvGeom& g, const float* x, const float* dy, float* gw
   const size_t tbytes = vcg_wino_fwd_workspace(g);
   p.x = x; p.v = V;
   VcgAmax amax_v;
+  const bool planes = wino_planes_on();
   if (v_saved) {
+    // the forward's V: fp32 with its own amax behind it, or — planes mode — pre-split by 4 x the input's amax (the word behind it)
     V = const_cast<float*>(v_saved);
-    amax_v = vcg_amax_stored(v_saved + wino_v_floats(g));
+    amax_v = vcg_amax_stored(v_saved + wino_v_floats(g), planes ? WINO_V_SHIFT : 0);
+  } else if (planes) {
+    if (vcg_operand_amax(x, (size_t)g.N * g.H * g.W * g.Cin, x_handle, WINO_V_SHIFT, st, &amax_v)) return -2;
+    p.amax_x = amax_v; p.vplanes = (unsigned short*)V;
+    hipLaunchKernelGGL(k_wino_in_planes, dim3(wino_blocks((size_t)p.T * p.Kc / 4)), dim3(256), 0, st, p);
   } else {
     const VcgAmaxOut av = vcg_amax_new(st);
     p.amax_slot = av.slot; p.amax_gen = av.gen;
@@ -623,7 +641,7 @@ int vcg_wino_wgrad(const ConvGeom& g, const float* x, const float* dy, float* gw
   p.amax_slot = ad.slot; p.amax_gen = ad.gen;
   hipLaunchKernelGGL(k_wino_dy, dim3(wino_blocks((size_t)p.T * g.Cout / 4)), dim3(256), 0, st, dy, dM, p);
   VCG_LAUNCH_CHECK("vcg_conv_wgrad(winograd transforms)");
-  return vcg_wino_wgrad_core(g, V, dM, p.T, gw_oihw, (char*)ws + tbytes, ws_bytes - tbytes, st, amax_v, vcg_amax_in(ad));
+  return vcg_wino_wgrad_core(g, V, dM, p.T, gw_oihw, (char*)ws + tbytes, ws_bytes - tbytes, st, amax_v, vcg_amax_in(ad), planes);
 }
 
 // data gradient over the padded domain (see k_wino_weight_dgrad)
@@ -649,7 +667,7 @@ int vcg_wino_weight_dgrad(const ConvGeom& g, const float* w_oihw, float* ud, con
   return 0;
 }
 int vcg_wino_dgrad(const ConvGeom& g, const float* dy, const float* ud, const void* w_amax, float* dx, void* ws, size_t ws_bytes,
-                   hipStream_t st) {
+                   hipStream_t st, uint64_t dy_handle) {
   VCG_CHECK_ARG(ws && ws_bytes >= vcg_wino_dgrad_workspace(g), "vcg_conv_dgrad: workspace too small for the Winograd path");
   const int kc = g.ups * g.ups * g.Cin;
   // input transform of dy: a plain (N, Ho, Wo, Cout) image, zero extension, patch origin 2 * tile - 2
@@ -659,17 +677,27 @@ int vcg_wino_dgrad(const ConvGeom& g, const float* dy, const float* ud, const vo
   p.reflect = 0; p.act = VCG_ACT_NONE; p.cout_log = kc;
   p.th = g.Ho / 2 + 1; p.tw = g.Wo / 2 + 1; p.T = g.N * p.th * p.tw; p.Kc = g.Cout; p.off = 2;
   p.amax_slot = nullptr; p.amax_gen = 0;
+  p.amax_x = vcg_amax_const(0); p.vplanes = nullptr;
   p.fd_k4 = make_fastdiv((uint32_t)p.Kc / 4); p.fd_tw = make_fastdiv((uint32_t)p.tw);
   p.fd_thtw = make_fastdiv((uint32_t)(p.th * p.tw)); p.fd_c4 = make_fastdiv((uint32_t)p.Cin / 4);
   p.fd_co4 = make_fastdiv((uint32_t)kc / 4);
   float* V = (float*)ws;
   float* M = V + (((size_t)16 * p.T * g.Cout + 63) / 64) * 64;
   p.v = V; p.m = M;
-  const VcgAmaxOut av = vcg_amax_new(st);
-  p.amax_slot = av.slot; p.amax_gen = av.gen;
-  hipLaunchKernelGGL(k_wino_in, dim3(wino_blocks((size_t)p.T * g.Cout / 4)), dim3(256), 0, st, p);
-  VCG_LAUNCH_CHECK("vcg_conv_dgrad(winograd input transform)");
-  if (vcg_gemm_split_batched(V, ud, M, p.T, g.Cout, kc, 16, vcg_amax_in(av), vcg_amax_stored(w_amax, WINO_U_SHIFT), st)) return -2;
+  if (wino_planes_on()) {
+    VcgAmax ad;
+    if (vcg_operand_amax(dy, (size_t)g.N * g.Ho * g.Wo * g.Cout, dy_handle, WINO_V_SHIFT, st, &ad)) return -2;
+    p.amax_x = ad; p.vplanes = (unsigned short*)V;
+    hipLaunchKernelGGL(k_wino_in_planes, dim3(wino_blocks((size_t)p.T * g.Cout / 4)), dim3(256), 0, st, p);
+    VCG_LAUNCH_CHECK("vcg_conv_dgrad(winograd input transform)");
+    if (vcg_gemm_planes_batched(V, ud, M, p.T, g.Cout, kc, 16, ad, vcg_amax_stored(w_amax, WINO_U_SHIFT), st, nullptr)) return -2;
+  } else {
+    const VcgAmaxOut av = vcg_amax_new(st);
+    p.amax_slot = av.slot; p.amax_gen = av.gen;
+    hipLaunchKernelGGL(k_wino_in, dim3(wino_blocks((size_t)p.T * g.Cout / 4)), dim3(256), 0, st, p);
+    VCG_LAUNCH_CHECK("vcg_conv_dgrad(winograd input transform)");
+    if (vcg_gemm_split_batched(V, ud, M, p.T, g.Cout, kc, 16, vcg_amax_in(av), vcg_amax_stored(w_amax, WINO_U_SHIFT), st)) return -2;
+  }
   WinoP q = p;
   q.Kc = kc;                                      // the output side: k columns
   // output transform and fold in one pass: the padded image is never written
@@ -686,21 +714,29 @@ size_t vcg_wino_fwd_stats_doubles(const ConvGeom& g) {
 }
 // v_keep: where to leave V = B^T x B for the weight gradient (vcg_wino_saved_floats), instead of the workspace
 int vcg_wino_fwd(const ConvGeom& g, const float* x, const float* u, const void* w_amax, const float* bias, float* y, void* ws,
-                 size_t ws_bytes, hipStream_t st, double* in_part, int* in_nchunk, float* v_keep) {
+                 size_t ws_bytes, hipStream_t st, double* in_part, int* in_nchunk, float* v_keep, uint64_t x_handle) {
   VCG_CHECK_ARG(ws && ws_bytes >= vcg_wino_fwd_workspace(g), "vcg_conv_fwd: workspace too small for the Winograd path (%zu)",
                 ws_bytes);
   WinoP p = wino_params(g);
   float* V = v_keep ? v_keep : (float*)ws;
   float* M = (float*)ws + (((size_t)16 * p.T * p.Kc + 63) / 64) * 64;
   p.x = x; p.v = V; p.m = M; p.bias = bias; p.y = y;
-  const VcgAmaxOut av = vcg_amax_new(st);
-  p.amax_slot = av.slot; p.amax_gen = av.gen;
-  hipLaunchKernelGGL(k_wino_in, dim3(wino_blocks((size_t)p.T * p.Kc / 4)), dim3(256), 0, st, p);
-  VCG_LAUNCH_CHECK("vcg_conv_fwd(winograd input transform)");
-  // a kept V keeps its amax behind it (vcg_wino_saved_floats): the weight gradient's GEMMs will scale it the same way
-  if (vcg_gemm_split_batched(V, u, M, p.T, p.Kc, g.Cout, 16, vcg_amax_in(av), vcg_amax_stored(w_amax, WINO_U_SHIFT), st,
-                             v_keep ? reinterpret_cast<uint32_t*>(v_keep + wino_v_floats(g)) : nullptr))
-    return -2;
+  uint32_t* const keep_word = v_keep ? reinterpret_cast<uint32_t*>(v_keep + wino_v_floats(g)) : nullptr;
+  if (wino_planes_on()) {
+    VcgAmax ax;
+    if (vcg_operand_amax(x, (size_t)g.N * g.H * g.W * g.Cin, x_handle, WINO_V_SHIFT, st, &ax)) return -2;
+    p.amax_x = ax; p.vplanes = (unsigned short*)V;
+    hipLaunchKernelGGL(k_wino_in_planes, dim3(wino_blocks((size_t)p.T * p.Kc / 4)), dim3(256), 0, st, p);
+    VCG_LAUNCH_CHECK("vcg_conv_fwd(winograd input transform)");
+    // a kept V keeps the word it was scaled by behind it (vcg_wino_saved_floats): the weight gradient's GEMMs need the same scale
+    if (vcg_gemm_planes_batched(V, u, M, p.T, p.Kc, g.Cout, 16, ax, vcg_amax_stored(w_amax, WINO_U_SHIFT), st, keep_word)) return -2;
+  } else {
+    const VcgAmaxOut av = vcg_amax_new(st);
+    p.amax_slot = av.slot; p.amax_gen = av.gen;
+    hipLaunchKernelGGL(k_wino_in, dim3(wino_blocks((size_t)p.T * p.Kc / 4)), dim3(256), 0, st, p);
+    VCG_LAUNCH_CHECK("vcg_conv_fwd(winograd input transform)");
+    if (vcg_gemm_split_batched(V, u, M, p.T, p.Kc, g.Cout, 16, vcg_amax_in(av), vcg_amax_stored(w_amax, WINO_U_SHIFT), st, keep_word)) return -2;
+  }
   if (in_part) {
     const NormPlan pl = vcg_norm_plan(g.N, p.th * p.tw, g.Cout);
     hipLaunchKernelGGL(k_wino_out_stats, dim3(pl.nchunk, g.N, pl.cgroups), dim3(256), 0, st, p, in_part, pl);

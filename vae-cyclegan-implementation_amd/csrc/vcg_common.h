@@ -276,14 +276,15 @@ size_t vcg_wino_weight_floats(const ConvGeom& g);
 size_t vcg_wino_fwd_workspace(const ConvGeom& g);
 int vcg_wino_weight(const ConvGeom& g, const float* w_oihw, float* u, const VcgAmax& amax_w, hipStream_t st);
 int vcg_wino_fwd(const ConvGeom& g, const float* x, const float* u, const void* w_amax, const float* bias, float* y, void* ws,
-                 size_t ws_bytes, hipStream_t st, double* in_part = nullptr, int* in_nchunk = nullptr, float* v_keep = nullptr);
+                 size_t ws_bytes, hipStream_t st, double* in_part = nullptr, int* in_nchunk = nullptr, float* v_keep = nullptr,
+                 uint64_t x_handle = 0);
 size_t vcg_wino_saved_floats(const ConvGeom& g);
 size_t vcg_wino_fwd_stats_doubles(const ConvGeom& g);
 // Winograd weight gradient: transforms in conv_wino.hip, batched stream-K reduction + back-transform in conv_igemm.hip
 bool vcg_wino_wgrad_ok(const ConvGeom& g);
 size_t vcg_wino_wgrad_workspace(const ConvGeom& g);
 int vcg_wino_wgrad(const ConvGeom& g, const float* x, const float* dy, float* gw_oihw, void* ws, size_t ws_bytes, hipStream_t st,
-                   const float* v_saved = nullptr);
+                   const float* v_saved = nullptr, uint64_t x_handle = 0);
 size_t vcg_wino_wgrad_core_workspace(const ConvGeom& g, int T);
 int vcg_wino_wgrad_core(const ConvGeom& g, const float* V, const float* dM, int T, float* gw_oihw, void* ws, size_t ws_bytes,
                         hipStream_t st, const VcgAmax& amax_v, const VcgAmax& amax_dm, bool v_planes);
@@ -291,7 +292,7 @@ bool vcg_wino_dgrad_ok(const ConvGeom& g);
 size_t vcg_wino_dgrad_workspace(const ConvGeom& g);
 int vcg_wino_weight_dgrad(const ConvGeom& g, const float* w_oihw, float* ud, const VcgAmax& amax_w, hipStream_t st);
 int vcg_wino_dgrad(const ConvGeom& g, const float* dy, const float* ud, const void* w_amax, float* dx, void* ws, size_t ws_bytes,
-                   hipStream_t st);
+                   hipStream_t st, uint64_t dy_handle = 0);
 // conv_slab.hip: 3x3 / stride-1 layers with few channels on large maps — the input staged once per workgroup as an LDS slab
 bool vcg_slab_fwd_ok(const ConvGeom& g);
 bool vcg_slab_fwd_stats_ok(const ConvGeom& g);
