@@ -61,6 +61,7 @@ struct ConvP {
   // channel, as chunk `(m0 % HoWo) / 128` of image `m0 / HoWo` in the [N][nchunk][Cout][2] double partials of norm.hip
   double* in_part;
   int in_nchunk;
+  VcgInTail in_tail;             // ... and the last tile of an (image, column tile) combines them into mean / rstd (vcg_common.h)
   // fp16 x 2 split-operand kernels (vcg_common.h): the largest magnitude of the tensor behind `a` and of the one behind `b`
   VcgAmax amax_a, amax_b;
   // batched Winograd weight gradient: `a` (the kept V) is pre-split planes [batch][T][K / 32][2][32] (k_wino_in_planes), not fp32
@@ -650,8 +651,14 @@ __global__ __launch_bounds__(256, 2) void k_conv_fwd_split(ConvP p) {
       const uint32_t n = fd_div((uint32_t)m0, p.fd_howo);
       const uint32_t chunk = ((uint32_t)m0 - n * (uint32_t)(p.Ho * p.Wo)) / BM;
       double* o = p.in_part + (((size_t)n * p.in_nchunk + chunk) * p.Cout + n0 + tid) * 2;
-      o[0] = (double)red[tid * 2] + (double)red[(BN + tid) * 2];
-      o[1] = (double)red[tid * 2 + 1] + (double)red[(BN + tid) * 2 + 1];
+      vcg_store_sc1(o, (double)red[tid * 2] + (double)red[(BN + tid) * 2]);
+      vcg_store_sc1(o + 1, (double)red[tid * 2 + 1] + (double)red[(BN + tid) * 2 + 1]);
+    }
+    if (p.in_tail.out1) {
+      const uint32_t n = fd_div((uint32_t)m0, p.fd_howo);
+      __syncthreads();                // `red` (As) has been read
+      vcg_in_tail_run<0>(p.in_tail, p.in_part, (int)n, n0, BN, p.Cout, p.in_nchunk, p.in_tail.counters + n * gridDim.y + nt,
+                         (uint32_t)p.in_nchunk, reinterpret_cast<double*>(&As[0][0]));
     }
   }
   VCG_STAMP_AT(3);
@@ -1846,9 +1853,13 @@ __global__ __launch_bounds__(256) void k_pack_planes(const float* __restrict__ w
 
 // gbias[co] += sum_m dy[m][co]: per-chunk partials then a fixed-order final sum
 // float4 per lane (TC channel quads x TP row lanes per block), 4 independent rows in flight per lane
+// The last chunk block of a channel group (arrival counter `ctr`, vcg_common.h / VcgInTail) sums the group's chunk partials
+// in a fixed order and adds them to gbias: no separate finalize launch.  ctr == null: the caller runs k_colsum_final.
 __global__ __launch_bounds__(256) void k_colsum_partial(const float* __restrict__ dy, float* __restrict__ part,
-                                                        int M, int C, int rows_per_chunk, int TC) {
+                                                        int M, int C, int rows_per_chunk, int TC, uint32_t* ctr,
+                                                        float* __restrict__ gbias, int c_log) {
   __shared__ float4 red[256];
+  __shared__ int last;
   const int TP = 256 / TC;
   const int tc = threadIdx.x % TC, tp = threadIdx.x / TC;
   const int c4 = blockIdx.x * TC + tc;
@@ -1871,7 +1882,36 @@ __global__ __launch_bounds__(256) void k_colsum_partial(const float* __restrict_
   __syncthreads();
   if (tp == 0 && c4 * 4 < C) {
     for (int k = 1; k < TP; ++k) f4add(s, red[k * TC + tc]);
-    *reinterpret_cast<float4*>(part + (size_t)blockIdx.y * C + c4 * 4) = s;
+    float* o = part + (size_t)blockIdx.y * C + c4 * 4;
+    vcg_store_sc1_f2(o, s.x, s.y);
+    vcg_store_sc1_f2(o + 2, s.z, s.w);
+  }
+  if (!ctr) return;
+  if (!vcg_last_arrival(ctr + blockIdx.x, gridDim.y, &last)) return;
+  // thread (tc, tp): channel quad tc, chunks tp, tp + TP, ... — four loads in flight — then the TP lanes in order
+  const int nchunk = (int)gridDim.y;
+  float4 t0 = f4zero(), t1 = t0, t2 = t0, t3 = t0;
+  if (c4 * 4 < C) {
+    const float* base = part + (size_t)c4 * 4;
+    int k = tp;
+    auto ld = [](const float* q) { const float2 lo = vcg_load_sc1_f2(q), hi = vcg_load_sc1_f2(q + 2); return make_float4(lo.x, lo.y, hi.x, hi.y); };
+    for (; k + 3 * TP < nchunk; k += 4 * TP) {
+      const float4 v0 = ld(base + (size_t)k * C), v1 = ld(base + (size_t)(k + TP) * C);
+      const float4 v2 = ld(base + (size_t)(k + 2 * TP) * C), v3 = ld(base + (size_t)(k + 3 * TP) * C);
+      f4add(t0, v0); f4add(t1, v1); f4add(t2, v2); f4add(t3, v3);
+    }
+    for (; k < nchunk; k += TP) f4add(t0, ld(base + (size_t)k * C));
+    f4add(t0, t1); f4add(t2, t3); f4add(t0, t2);
+  }
+  red[threadIdx.x] = t0;
+  __syncthreads();
+  if (tp == 0 && c4 * 4 < C) {
+    for (int k = 1; k < TP; ++k) f4add(t0, red[k * TC + tc]);
+    const int c = c4 * 4;
+    if (c + 0 < c_log) gbias[c + 0] += t0.x;
+    if (c + 1 < c_log) gbias[c + 1] += t0.y;
+    if (c + 2 < c_log) gbias[c + 2] += t0.z;
+    if (c + 3 < c_log) gbias[c + 3] += t0.w;
   }
 }
 // 8 channels x 32 chunk lanes per block: the loop over chunk partials is a dependent chain of L2 round trips
@@ -1957,7 +1997,7 @@ static void fill_params(const ConvGeom& g, ConvP& p) {
   p.ksplit = 1; p.kt_per = 0; p.slab = nullptr; p.adjoint = 0; p.src_pitch = g.Cout;
   p.a_bytes = p.b_bytes = 0; p.dbl_mirror = 0;
   p.bias = nullptr;
-  p.in_part = nullptr; p.in_nchunk = 0;
+  p.in_part = nullptr; p.in_nchunk = 0; p.in_tail = vcg_in_tail_none();
   p.amax_a = p.amax_b = vcg_amax_const(0);      // scale 1 (the fp32-MFMA kernels never look)
   p.a_planes = 0;
 }
@@ -2053,11 +2093,11 @@ static size_t wf_floats(const ConvGeom& g) { return (((size_t)g.K * g.Cout + 63)
 // gets the planes for it)
 static bool wino_takes_fwd(const ConvGeom& g) {
   const long long kc = (long long)g.ups * g.ups * g.Cin;
-  return vcg_wino_weight_ok(g) && kc * g.Cout >= 64 * (kc + g.Cout);
+  return vcg_wino_weight_ok(g) && kc * g.Cout >= vcg_wino_gate_fwd() * (kc + g.Cout);
 }
 static bool wino_takes_dgrad(const ConvGeom& g) {
   const long long kc = (long long)g.ups * g.ups * g.Cin;
-  return vcg_wino_weight_ok(g) && kc * g.Cout >= 80 * (kc + g.Cout);
+  return vcg_wino_weight_ok(g) && kc * g.Cout >= vcg_wino_gate_dgrad() * (kc + g.Cout);
 }
 // floats of the Winograd copies a layer keeps: U if some map can take the forward (and with it the weight gradient), Ud if
 // some map can take the data gradient
@@ -2210,7 +2250,7 @@ static bool fwd_tile_stats_ok(const ConvGeom& g) {
 // in_part != nullptr: also leave the InstanceNorm chunk partials of y there (the caller checked that this launch plan
 // can: Winograd, or fwd_tile_stats_ok) and report the chunk count per image.
 static int conv_fwd_impl(const float* x, const float* wf, const float* bias, float* y, const int32_t* cd, void* ws,
-                         size_t ws_bytes, void* stream, double* in_part, int* in_nchunk, float* saved = nullptr) {
+                         size_t ws_bytes, void* stream, double* in_part, const VcgInTail* tail_req, float* saved = nullptr) {
   const uint64_t x_handle = vcg_take_hint_x();              // vcg_amax_hint: who wrote x left its largest magnitude (or 0)
   (void)vcg_take_hint_dy();
   ConvGeom g;
@@ -2219,13 +2259,13 @@ static int conv_fwd_impl(const float* x, const float* wf, const float* bias, flo
   if (vcg_thin_fold_ok(g)) return vcg_thin_fold_fwd(g, x, wf + wf_floats(g), vcg_pack_amax(g, wf), bias, y, ws, ws_bytes, (hipStream_t)stream, x_handle);
   if (vcg_thin_fwd_ok(g)) return vcg_thin_fwd(g, x, wf, bias, y, (hipStream_t)stream);
   if (vcg_wino_fwd_ok(g))
-    return vcg_wino_fwd(g, x, wf + wf_floats(g), vcg_pack_amax(g, wf), bias, y, ws, ws_bytes, (hipStream_t)stream, in_part, in_nchunk, saved, x_handle);
+    return vcg_wino_fwd(g, x, wf + wf_floats(g), vcg_pack_amax(g, wf), bias, y, ws, ws_bytes, (hipStream_t)stream, in_part, tail_req, saved, x_handle);
   if (fwd_slab_ok(g))
-    return vcg_slab_fwd(g, x, wf + wft_offset(g), wft_floats(g) * 4, vcg_pack_amax(g, wf), bias, y, in_part, in_nchunk, (hipStream_t)stream, x_handle);
+    return vcg_slab_fwd(g, x, wf + wft_offset(g), wft_floats(g) * 4, vcg_pack_amax(g, wf), bias, y, in_part, tail_req, (hipStream_t)stream, x_handle);
   ConvP p; fill_params(g, p);
   if (in_part) {
     p.in_part = in_part;
-    p.in_nchunk = *in_nchunk = g.Ho * g.Wo / 128;
+    p.in_nchunk = g.Ho * g.Wo / 128;
   }
   p.a = x; p.b = wf; p.bias = bias; p.out = y;
   {
@@ -2248,6 +2288,7 @@ static int conv_fwd_impl(const float* x, const float* wf, const float* bias, flo
     // the input's largest magnitude (its scale, vcg_common.h): from its writer's handle, else measured
     if (vcg_operand_amax(x, (size_t)g.N * g.H * g.W * g.Cin, x_handle, 0, st, &p.amax_a)) return -2;
     p.amax_b = vcg_amax_stored(vcg_pack_amax(g, wf));
+    if (in_part) p.in_tail = vcg_in_tail_make(tail_req->out1, tail_req->out2, g.N * (int)grid.y, tail_req->HW, tail_req->eps);
     VcgProfScope prof(bn == 128 ? "k_conv_fwd_split<128>" : "k_conv_fwd_split<64>", gemm_flops, st);
     if (bn == 128) hipLaunchKernelGGL((k_conv_fwd_split<128>), grid, dim3(256), 0, st, p);
     else hipLaunchKernelGGL((k_conv_fwd_split<64>), grid, dim3(256), 0, st, p);
@@ -2260,6 +2301,8 @@ static int conv_fwd_impl(const float* x, const float* wf, const float* bias, flo
     hipLaunchKernelGGL(k_splitk_finish, dim3(ew_grid((size_t)g.M * g.Cout / 4)), dim3(256), 0, st, (const float*)ws, bias,
                        y, (size_t)g.M, g.Cout, nsplit, g.cout_log, g.act);
   VCG_LAUNCH_CHECK("vcg_conv_fwd");
+  if (in_part && !p.in_tail.out1)
+    return vcg_in_finalize(in_part, tail_req->out1, tail_req->out2, g.N, tail_req->HW, g.Cout, p.in_nchunk, tail_req->eps, st);
   return 0;
 }
 
@@ -2308,9 +2351,11 @@ extern "C" int vcg_conv_fwd_in(const float* x, const float* wf, const float* bia
   const size_t cws = fwd_in_conv_ws(cd);
   double* part = reinterpret_cast<double*>(static_cast<char*>(ws) + cws);
   const bool fused = vcg_wino_fwd_ok(g) || (fwd_slab_ok(g) && vcg_slab_fwd_stats_ok(g)) || fwd_tile_stats_ok(g);
-  int nchunk = 0;
-  if (conv_fwd_impl(x, wf, bias, y, cd, ws, cws, stream, fused ? part : nullptr, &nchunk, saved)) return -1;
-  if (fused) return vcg_in_finalize(part, mean, rstd, g.N, g.Ho * g.Wo, g.Cout, nchunk, eps, (hipStream_t)stream);
+  // fused: the conv's epilogue leaves the partials and its last block per (image, channel range) finalizes them
+  VcgInTail req = vcg_in_tail_none();
+  req.out1 = mean; req.out2 = rstd; req.HW = g.Ho * g.Wo; req.eps = eps;
+  if (conv_fwd_impl(x, wf, bias, y, cd, ws, cws, stream, fused ? part : nullptr, &req, saved)) return -1;
+  if (fused) return 0;
   return vcg_in_stats_pass(y, mean, rstd, g.N, g.Ho * g.Wo, g.Cout, eps, part, ws_bytes - cws, (hipStream_t)stream);
 }
 
@@ -2464,7 +2509,8 @@ static const int kMaxDirectSlabs = 24;
 static void colsum_plan(const ConvGeom& g, int& tc, int& cgroups, int& rows, int& nchunk) {
   int c4 = g.Cout / 4;
   tc = 1;
-  while (tc * 2 <= c4 && tc * 2 <= 256) tc *= 2;
+  const int cap = vcg_in_tail_enabled() ? 16 : 256;    // tails on: <= 64 channels per workgroup, so the finalizing workgroup has >= 16 chunk lanes per quad
+  while (tc * 2 <= c4 && tc * 2 <= cap) tc *= 2;
   cgroups = (c4 + tc - 1) / tc;
   int tp = 256 / tc;
   long long want = 512 / cgroups;
@@ -2559,9 +2605,12 @@ static ConvGeom swapped_geom(const ConvGeom& g) {
 static int launch_colsum(const ConvGeom& gorig, const float* dy, float* gbias, float* part, hipStream_t st) {
   int tc, cgroups, rows, nchunk;
   colsum_plan(gorig, tc, cgroups, rows, nchunk);
-  hipLaunchKernelGGL(k_colsum_partial, dim3(cgroups, nchunk), dim3(256), 0, st, dy, part, gorig.M, gorig.Cout, rows, tc);
-  hipLaunchKernelGGL(k_colsum_final, dim3((gorig.cout_log + 7) / 8), dim3(256), 0, st, (const float*)part, gbias,
-                     gorig.Cout, nchunk, gorig.cout_log);
+  uint32_t* ctr = vcg_in_tail_enabled() ? vcg_tail_counters(cgroups) : nullptr;
+  hipLaunchKernelGGL(k_colsum_partial, dim3(cgroups, nchunk), dim3(256), 0, st, dy, part, gorig.M, gorig.Cout, rows, tc, ctr, gbias,
+                     gorig.cout_log);
+  if (!ctr)
+    hipLaunchKernelGGL(k_colsum_final, dim3((gorig.cout_log + 7) / 8), dim3(256), 0, st, (const float*)part, gbias,
+                       gorig.Cout, nchunk, gorig.cout_log);
   VCG_LAUNCH_CHECK("vcg_conv_wgrad(bias)");
   return 0;
 }

@@ -25,6 +25,7 @@ struct SlabP {
   const float* bias;
   float* out;               // (N, Ho, Wo, Cout)
   double* in_part;          // InstanceNorm chunk partials [N][nchunk][Cout][2], or null
+  VcgInTail in_tail;        // the last pixel block of an (image, column tile) combines them (vcg_common.h)
   int N, H, W, C, Ho, Wo, Cout, cout_log;
   int pad, reflect, act, tap_flip, nchunks, in_nchunk;
   int nbx, nby;             // pixel blocks per image
@@ -219,8 +220,13 @@ __global__ __launch_bounds__(256, 2) void k_conv_slab(SlabP p) {
         t2 += (double)red[(w * BN + tid) * 2 + 1];
       }
       double* o = p.in_part + (((size_t)n * p.in_nchunk + blk) * p.Cout + n0 + tid) * 2;
-      o[0] = t1;
-      o[1] = t2;
+      vcg_store_sc1(o, t1);
+      vcg_store_sc1(o + 1, t2);
+    }
+    if (p.in_tail.out1) {
+      __syncthreads();                // `red` (As) has been read
+      vcg_in_tail_run<0>(p.in_tail, p.in_part, n, n0, BN, p.Cout, p.in_nchunk, p.in_tail.counters + n * gridDim.y + blockIdx.y,
+                         (uint32_t)p.in_nchunk, reinterpret_cast<double*>(&As[0][0]));
     }
   }
 }
@@ -274,7 +280,7 @@ bool vcg_slab_dgrad_ok(const ConvGeom& g) {
 size_t vcg_slab_dgrad_workspace(const ConvGeom& g) { return (size_t)g.N * (g.H + 2) * (g.W + 2) * g.Cin * sizeof(float) + 256; }
 
 int vcg_slab_fwd(const ConvGeom& g, const float* x, const void* wft_planes, size_t planes_bytes, const void* w_amax, const float* bias,
-                 float* y, double* in_part, int* in_nchunk, hipStream_t st, uint64_t x_handle) {
+                 float* y, double* in_part, const VcgInTail* tail_req, hipStream_t st, uint64_t x_handle) {
   SlabP p = {};
   if (vcg_operand_amax(x, (size_t)g.N * g.H * g.W * g.Cin, x_handle, 0, st, &p.amax_a)) return -2;
   p.amax_b = vcg_amax_stored(w_amax);
@@ -283,7 +289,7 @@ int vcg_slab_fwd(const ConvGeom& g, const float* x, const void* wft_planes, size
   p.pad = 1; p.reflect = g.reflect; p.act = g.act; p.tap_flip = 0; p.nchunks = g.Cin / 32;
   p.nbx = (g.Wo + 15) / 16; p.nby = (g.Ho + 7) / 8;
   p.in_nchunk = p.nbx * p.nby;
-  if (in_nchunk) *in_nchunk = p.in_nchunk;
+  p.in_tail = in_part ? vcg_in_tail_make(tail_req->out1, tail_req->out2, g.N * (g.Cout / 64), tail_req->HW, tail_req->eps) : vcg_in_tail_none();
   const unsigned long long ab = (unsigned long long)g.N * g.H * g.W * g.Cin * 4;
   VCG_CHECK_ARG(ab < (1ull << 31) && planes_bytes < (1ull << 31), "vcg_conv_fwd: tensor extents must stay below 2 GiB");
   p.in_bytes = (uint32_t)ab; p.b_bytes = (uint32_t)planes_bytes;
@@ -293,6 +299,8 @@ int vcg_slab_fwd(const ConvGeom& g, const float* x, const void* wft_planes, size
     hipLaunchKernelGGL((k_conv_slab<2, 2, 3, 3>), dim3(g.N * p.nbx * p.nby, g.Cout / 64), dim3(256), 0, st, p);
   }
   VCG_LAUNCH_CHECK("vcg_conv_fwd(slab)");
+  if (in_part && !p.in_tail.out1)
+    return vcg_in_finalize(in_part, tail_req->out1, tail_req->out2, g.N, tail_req->HW, g.Cout, p.in_nchunk, tail_req->eps, st);
   return 0;
 }
 

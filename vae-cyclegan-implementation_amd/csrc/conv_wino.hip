@@ -24,6 +24,16 @@ int vcg_gemm_planes_batched(const void* APlanes, const void* BtPlanes, float* C,
 // VCG_WINO_PLANES=0: V as fp32, split inside the GEMM (A/B measurements).  Default: k_wino_in writes V pre-split — the same bytes —
 // scaled by 4 x the input's amax, and the GEMMs (forward, data gradient, and the weight gradient that re-reads a kept V) stage it
 // with plain copies.
+// Gates of the three directions on Kc Cout / (Kc + Cout) (what the GEMMs save per float the transforms move); VCG_WINO_GATE_F / _D / _W
+// override them for A/B measurements (tools/conv_bench.py).  Round 3 (three fp16 MFMAs per product instead of six bf16 ones: the
+// direct kernels' matrix time halved, the transforms' traffic did not): re-measured per layer at batch 8 — forward D1 (85) 458 us
+// Winograd vs 360 direct, U2 (85) 109 vs 84, U1 / D2 (171) 79 / 267 vs 93 / 293: the forward gate moved from 64 to 100; data
+// gradient D1 476 vs 521, U2 118 vs 139: stays at 80; weight gradient D1 / U2 (85): the ring kernel as before
+// (profiles/r03_wino_gates.txt)
+static long long wino_gate_env(const char* name, long long dflt) { const char* e = getenv(name); return e ? atoll(e) : dflt; }
+long long vcg_wino_gate_fwd() { static const long long v = wino_gate_env("VCG_WINO_GATE_F", 100); return v; }
+long long vcg_wino_gate_dgrad() { static const long long v = wino_gate_env("VCG_WINO_GATE_D", 80); return v; }
+long long vcg_wino_gate_wgrad() { static const long long v = wino_gate_env("VCG_WINO_GATE_W", 128); return v; }
 static bool wino_planes_on() {
   static const int on = [] { const char* e = getenv("VCG_WINO_PLANES"); return e ? atoi(e) : 1; }();
   return on != 0;
@@ -222,7 +232,7 @@ __global__ __launch_bounds__(256) void k_wino_out(WinoP p) {
 // The same output transform for a layer whose output goes into an InstanceNorm: it also leaves the statistics' chunk
 // partials (sum and sum of squares per (image, channel), in double: norm.hip) so that no extra pass has to re-read y.
 // Grid (chunk of tiles, image, channel-quad group); thread = (channel quad, tile lane), as in k_in_partial.
-__global__ __launch_bounds__(256) void k_wino_out_stats(WinoP p, double* __restrict__ part, NormPlan pl) {
+__global__ __launch_bounds__(256) void k_wino_out_stats(WinoP p, double* __restrict__ part, NormPlan pl, VcgInTail tail) {
   __shared__ double r1[256 * 4];
   __shared__ double r2[256 * 4];
   const int tc = threadIdx.x % pl.TC, tp = threadIdx.x / pl.TC;
@@ -294,9 +304,14 @@ __global__ __launch_bounds__(256) void k_wino_out_stats(WinoP p, double* __restr
     double* o = part + (((size_t)n * pl.nchunk + blockIdx.x) * p.Cout + c4 * 4) * 2;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      o[2 * e] = s1[e];
-      o[2 * e + 1] = s2[e];
+      vcg_store_sc1(o + 2 * e, s1[e]);
+      vcg_store_sc1(o + 2 * e + 1, s2[e]);
     }
+  }
+  if (tail.out1) {                    // the last chunk block of this (image, channel group) writes mean / rstd (vcg_common.h)
+    __syncthreads();                  // r1 / r2 are free again
+    vcg_in_tail_run<0>(tail, part, n, blockIdx.z * pl.TC * 4, pl.TC * 4, p.Cout, pl.nchunk, tail.counters + n * pl.cgroups + blockIdx.z,
+                       (uint32_t)pl.nchunk, r1);
   }
 }
 
@@ -553,17 +568,21 @@ bool vcg_wino_weight_ok(const ConvGeom& g) {
   return g.KH == 3 && g.KW == 3 && g.stride == 1 && g.pad == 1 && g.ups * g.ups * g.Cin >= 128 && g.Cout >= 64 &&
          g.Cin % 4 == 0 && g.Cout % 64 == 0 && (g.ups * g.ups * g.Cin) % 64 == 0;     // N of both GEMMs in 64-column tiles
 }
-bool vcg_wino_fwd_ok(const ConvGeom& g) {
+// a map Winograd can take at all (whatever the direction's gate says)
+static bool wino_map_ok(const ConvGeom& g) {
   if (!vcg_wino_weight_ok(g)) return false;
 #ifdef VCG_STAMP
   if (getenv("VCG_NO_WINOGRAD")) return false;     // A/B timing in the diagnostic build only
 #endif
-  if (g.Ho < 4 || g.Wo < 4 || (g.Ho & 1) || (g.Wo & 1)) return false;
+  return !(g.Ho < 4 || g.Wo < 4 || (g.Ho & 1) || (g.Wo & 1));
+}
+bool vcg_wino_fwd_ok(const ConvGeom& g) {
+  if (!wino_map_ok(g)) return false;
   const unsigned long long T = (unsigned long long)g.N * (g.Ho / 2) * (g.Wo / 2);
   const unsigned long long Kc = (unsigned long long)g.ups * g.ups * g.Cin;
   // the transforms move 16 T (Kc + Cout) floats each way while the GEMMs save ~ T Kc Cout multiplications: the forward
-  // pays from Kc Cout / (Kc + Cout) ~ 64 on (85 -> 1.29x; the 1024 -> 64 latent convs at 60 -> 0.7x)
-  if (Kc * g.Cout < 64ull * (Kc + g.Cout)) return false;
+  // pays from Kc Cout / (Kc + Cout) ~ 100 on (vcg_wino_gate_fwd above)
+  if (Kc * g.Cout < (unsigned long long)vcg_wino_gate_fwd() * (Kc + g.Cout)) return false;
   return T * Kc * 4 < (1ull << 31) && T * g.Cout * 4 < (1ull << 31) && T * Kc * 16 < (1ull << 32);
 }
 // one transformed copy of the kernel as fp16 blocked planes: VCG_NP pieces x 2 bytes per value
@@ -604,7 +623,7 @@ bool vcg_wino_wgrad_ok(const ConvGeom& g) {
   // the transforms move 16 T (Kc + Cout) floats each way while the GEMMs save ~ T Kc Cout multiplications: it pays
   // from Kc Cout / (Kc + Cout) ~ 128 on (measured: 171 -> 1.46x, 85 -> 0.9x)
   const long long kc = (long long)g.ups * g.ups * g.Cin;
-  return vcg_wino_fwd_ok(g) && kc % 128 == 0 && kc * g.Cout >= 128 * (kc + g.Cout);
+  return vcg_wino_fwd_ok(g) && kc % 128 == 0 && kc * g.Cout >= vcg_wino_gate_wgrad() * (kc + g.Cout);
 }
 size_t vcg_wino_wgrad_workspace(const ConvGeom& g) {
   const int T = g.N * (g.Ho / 2) * (g.Wo / 2);
@@ -646,9 +665,9 @@ int vcg_wino_wgrad(const ConvGeom& g, const float* x, const float* dy, float* gw
 
 // data gradient over the padded domain (see k_wino_weight_dgrad)
 bool vcg_wino_dgrad_ok(const ConvGeom& g) {
-  if (!vcg_wino_fwd_ok(g)) return false;
+  if (!wino_map_ok(g)) return false;               // its own gate below: the forward's (higher since round 3) says nothing about it
   const long long kc = (long long)g.ups * g.ups * g.Cin;
-  if (kc * g.Cout < 80 * (kc + g.Cout)) return false;             // measured: 85 -> 1.22..1.25x (D1, U2), 171 -> 1.3..1.5x
+  if (kc * g.Cout < vcg_wino_gate_dgrad() * (kc + g.Cout)) return false;             // measured: 85 -> 1.22..1.25x (D1, U2), 171 -> 1.3..1.5x
   const unsigned long long Tp = (unsigned long long)g.N * (g.Ho / 2 + 1) * (g.Wo / 2 + 1);
   return Tp * kc * 4 < (1ull << 31) && Tp * g.Cout * 4 < (1ull << 31) && Tp * g.Cout * 16 < (1ull << 32);
 }
@@ -714,7 +733,7 @@ size_t vcg_wino_fwd_stats_doubles(const ConvGeom& g) {
 }
 // v_keep: where to leave V = B^T x B for the weight gradient (vcg_wino_saved_floats), instead of the workspace
 int vcg_wino_fwd(const ConvGeom& g, const float* x, const float* u, const void* w_amax, const float* bias, float* y, void* ws,
-                 size_t ws_bytes, hipStream_t st, double* in_part, int* in_nchunk, float* v_keep, uint64_t x_handle) {
+                 size_t ws_bytes, hipStream_t st, double* in_part, const VcgInTail* tail_req, float* v_keep, uint64_t x_handle) {
   VCG_CHECK_ARG(ws && ws_bytes >= vcg_wino_fwd_workspace(g), "vcg_conv_fwd: workspace too small for the Winograd path (%zu)",
                 ws_bytes);
   WinoP p = wino_params(g);
@@ -738,9 +757,12 @@ int vcg_wino_fwd(const ConvGeom& g, const float* x, const float* u, const void* 
     if (vcg_gemm_split_batched(V, u, M, p.T, p.Kc, g.Cout, 16, vcg_amax_in(av), vcg_amax_stored(w_amax, WINO_U_SHIFT), st, keep_word)) return -2;
   }
   if (in_part) {
+    // statistics of y for the InstanceNorm that follows: chunk partials from this epilogue, combined by its last block
     const NormPlan pl = vcg_norm_plan(g.N, p.th * p.tw, g.Cout);
-    hipLaunchKernelGGL(k_wino_out_stats, dim3(pl.nchunk, g.N, pl.cgroups), dim3(256), 0, st, p, in_part, pl);
-    *in_nchunk = pl.nchunk;
+    VcgInTail tail = vcg_in_tail_make(tail_req->out1, tail_req->out2, g.N * pl.cgroups, tail_req->HW, tail_req->eps);
+    hipLaunchKernelGGL(k_wino_out_stats, dim3(pl.nchunk, g.N, pl.cgroups), dim3(256), 0, st, p, in_part, pl, tail);
+    VCG_LAUNCH_CHECK("vcg_conv_fwd(winograd output transform)");
+    return tail.out1 ? 0 : vcg_in_finalize(in_part, tail_req->out1, tail_req->out2, g.N, tail_req->HW, g.Cout, pl.nchunk, tail_req->eps, st);
   } else {
     hipLaunchKernelGGL(k_wino_out, dim3(wino_blocks((size_t)p.T * g.Cout / 4)), dim3(256), 0, st, p);
   }

@@ -19,6 +19,7 @@
 // LDS images: per piece [rows][32] fp16, 64-byte rows, the four 16-byte chunks of a row XOR-swizzled by (row >> 2) & 3
 // so that the ds_read_b128 fragment reads (lane = row, 16 consecutive rows per LDS cycle) are conflict-free.
 #include "vcg_common.h"
+#include <stdlib.h>
 
 typedef unsigned int u32x4g __attribute__((ext_vector_type(4)));
 
@@ -207,6 +208,168 @@ __global__ __launch_bounds__(256, 2) void k_gemm_split(GemmSplitP p) {
   }
 }
 
+// ---- round 3: the same GEMM with LDS-DMA staging (both operands pre-split planes) ------------------------------------------------
+// k_gemm_split<.., planes> moves 32 KB per 128 x 128 x 32 tile step through registers (8 buffer loads + 8 ds_write_b128 per
+// thread and K-step, two barriers) and sits at ~7 TB/s of L2 -> LDS traffic with its matrix pipe a third busy.  Here ONE 8-wave
+// workgroup per CU owns a 256 x 128 tile (a quarter fewer staged bytes per product), the planes go global -> LDS directly
+// (buffer_load_dwordx4 ... lds: 1 KB per wave-instruction, no VGPRs, no ds_write; the XOR swizzle of the LDS image is applied on
+// the SOURCE address, the destination of an LDS-DMA being lane-linear), into a ring of three stages with the loads two K-steps
+// ahead, ONE raw barrier per K-step: at step kt a wave waits for its own DMAs of stage kt (counted vmcnt, the next stage's stay
+// in flight), the barrier publishes everybody's, and the stage read at step kt - 1 is handed to the DMAs of step kt + 2.
+// The DMA is inline asm (through the builtin hipcc drains vmcnt(0) in front of every fragment read: tools/mfma_probe.hip).
+struct GdSrd { uint32_t x, y, z, w; };
+typedef uint32_t gd_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ gd_u32x4 gd_srd(const void* ptr, uint32_t bytes) {
+  const uint64_t a = (uint64_t)ptr;
+  gd_u32x4 r;
+  r.x = __builtin_amdgcn_readfirstlane((uint32_t)a);
+  r.y = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32) & 0xFFFFu);
+  r.z = __builtin_amdgcn_readfirstlane(bytes);
+  r.w = 0x00020000u;
+  return r;
+}
+// 16 bytes per lane, global (buffer offset voff; out of range: zeros) -> LDS at lds_dst + 16 * lane (lds_dst wave-uniform)
+__device__ __forceinline__ void gd_dma16(gd_u32x4 srd, uint32_t lds_dst, uint32_t voff) {
+  uint32_t keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(voff), "s"(lds_dst), "s"(srd) : "memory");
+}
+// raw workgroup barrier: this wave's LDS reads have returned; outstanding DMAs stay in flight (a __syncthreads() would drain them)
+__device__ __forceinline__ void gd_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+constexpr int GD_BM = 256, GD_BN = 128;
+constexpr int GD_A_BYTES = GD_BM * VCG_PBYTES, GD_B_BYTES = GD_BN * VCG_PBYTES;     // one stage: [row][128 B] images, 32 KB + 16 KB
+constexpr int GD_STAGE = GD_A_BYTES + GD_B_BYTES;
+constexpr int GD_STAGES = 3;
+// LDS image of an operand: 128 bytes per row — the row's K block exactly as it lies in memory, piece h (4 x 16 B) then piece l —
+// with the eight 16-byte slots XOR-swizzled by (row >> 1) & 7: a ds_read_b128 fragment read (lane = row, one logical slot) then
+// touches 16 different bank groups per 16-lane group, and one DMA wave-instruction moves 8 rows x 128 B = eight FULL cache lines
+// (the [piece][row][64 B] images of k_gemm_split fetch every line twice, half a line per instruction).
+__global__ __launch_bounds__(512, 1) void k_gemm_planes_dma(GemmSplitP p) {
+  constexpr int MI = 2, NI = 2;
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[GD_STAGES * GD_STAGE];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid >> 1, wn = wid & 1, l31 = lane & 31, lh = lane >> 5;
+  float sa_, inv_a, sb_, inv_b;
+  {
+    const uint32_t abits = vcg_amax_bits(p.amax_a);
+    vcg_scale_of(abits, p.amax_a.shift, sa_, inv_a);
+    vcg_scale_of(vcg_amax_bits(p.amax_b), p.amax_b.shift, sb_, inv_b);
+    if (p.amax_a_keep && tid == 0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) *p.amax_a_keep = abits;
+  }
+  int mt, nt, zb;
+  {
+    const uint32_t per = gridDim.x * gridDim.y, nwg = per * gridDim.z;
+    const uint32_t gid = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    const uint32_t q = nwg >> 3, r = nwg & 7, xcd = gid & 7;
+    const uint32_t swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (gid >> 3);
+    zb = (int)(swz / per);
+    const uint32_t l = swz - (uint32_t)zb * per;
+    mt = (int)(l / gridDim.y);
+    nt = (int)(l - (uint32_t)mt * gridDim.y);
+  }
+  const int m0 = mt * GD_BM, n0 = nt * GD_BN;
+  const gd_u32x4 ra = gd_srd((const unsigned short*)p.a + (size_t)zb * p.a_bstride, p.a_bytes),
+                 rb = gd_srd((const unsigned short*)p.bt + (size_t)zb * p.b_bstride, p.b_bytes);
+  const int KB = p.K / 32;
+  // one DMA wave-instruction = 8 rows x 128 B: lane -> (row l >> 3, physical slot l & 7), whose content is the logical slot
+  // (l & 7) ^ ((row >> 1) & 7) = byte 16 * that of the row's K block.  Wave w stages row groups w, w + 8, w + 16, w + 24 of A and
+  // w, w + 8 of B: six instructions per K-step.
+  const int drow = lane >> 3, dslot = lane & 7;
+  uint32_t aoff[4], boff[2];
+#pragma unroll
+  for (int h = 0; h < 4; ++h) {
+    const int rl = (wid + 8 * h) * 8 + drow;                 // row of the tile
+    const int r = m0 + rl;
+    aoff[h] = r < p.rows ? (uint32_t)((size_t)r * KB * VCG_PBYTES + ((dslot ^ ((rl >> 1) & 7)) << 4)) : GS_OOB;
+  }
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int rl = (wid + 8 * h) * 8 + drow;
+    boff[h] = (uint32_t)((size_t)(n0 + rl) * KB * VCG_PBYTES + ((dslot ^ ((rl >> 1) & 7)) << 4));      // N % 128 == 0: in range
+  }
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
+  auto issue = [&](int stage, int kt) {
+    const uint32_t sbase = __builtin_amdgcn_readfirstlane(lds0 + (uint32_t)stage * GD_STAGE);
+    const uint32_t ko = (uint32_t)kt * VCG_PBYTES;
+#pragma unroll
+    for (int h = 0; h < 4; ++h)
+      gd_dma16(ra, __builtin_amdgcn_readfirstlane(sbase + (uint32_t)((wid + 8 * h) * 1024)), aoff[h] != GS_OOB ? aoff[h] + ko : GS_OOB);
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+      gd_dma16(rb, __builtin_amdgcn_readfirstlane(sbase + (uint32_t)(GD_A_BYTES + (wid + 8 * h) * 1024)), boff[h] + ko);
+  };
+
+  f32x16 acc[MI][NI], lo[MI][NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = lo[i][j][e] = 0.f;
+  uint32_t fa[MI], fb[NI];
+  int sa[MI], sb[NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i) { const int r = wm * 64 + i * 32 + l31; fa[i] = (uint32_t)(r * VCG_PBYTES); sa[i] = (r >> 1) & 7; }
+#pragma unroll
+  for (int j = 0; j < NI; ++j) { const int r = wn * 64 + j * 32 + l31; fb[j] = (uint32_t)(GD_A_BYTES + r * VCG_PBYTES); sb[j] = (r >> 1) & 7; }
+
+  const int nkt = KB;
+  issue(0, 0);
+  if (nkt > 1) issue(1, 1);
+  for (int kt = 0; kt < nkt; ++kt) {
+    if (kt + 1 < nkt) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");      // my six DMAs of stage kt have landed; stage kt + 1's stay in flight
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    gd_barrier();                                                           // everybody's have; everybody is done with stage kt - 1
+    if (kt + 2 < nkt) issue((kt + 2) % GD_STAGES, kt + 2);
+    const unsigned char* st = smem + (kt % GD_STAGES) * GD_STAGE;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      f16x8 a[VCG_NP][MI], b[VCG_NP][NI];
+#pragma unroll
+      for (int pc = 0; pc < VCG_NP; ++pc) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+          a[pc][i] = *reinterpret_cast<const f16x8*>(st + fa[i] + (((pc * 4 + 2 * s + lh) ^ sa[i]) << 4));
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+          b[pc][j] = *reinterpret_cast<const f16x8*>(st + fb[j] + (((pc * 4 + 2 * s + lh) ^ sb[j]) << 4));
+      }
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+          f32x16 c = lo[i][j];
+          c = VCG_MFMA(a[1][i], b[0][j], c);
+          c = VCG_MFMA(a[0][i], b[1][j], c);
+          lo[i][j] = c;
+          acc[i][j] = VCG_MFMA(a[0][i], b[0][j], acc[i][j]);
+        }
+    }
+  }
+  float* const dst = p.c + (size_t)zb * p.c_bstride;
+  const float os = sa_ * sb_;
+#pragma unroll
+  for (int j = 0; j < NI; ++j) {
+    const int n = n0 + wn * 64 + j * 32 + l31;
+    if (n >= p.N) continue;
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = (e & 3) + 8 * (e >> 2) + 4 * lh;
+        const int m = m0 + wm * 64 + i * 32 + row;
+        if (m < p.rows) dst[(size_t)m * p.N + n] = (acc[i][j][e] + lo[i][j][e]) * os;
+      }
+  }
+}
+// VCG_GEMM_DMA=0: the register-staged 128 x 128 kernel for every shape (A/B measurements)
+static bool gemm_dma_on() {
+  static const int on = [] { const char* e = getenv("VCG_GEMM_DMA"); return e ? atoi(e) : 1; }();
+  return on != 0;
+}
+
 // X[rows][K] fp32 -> blocked planes of X / s (see the top of this file), s from `amax`; one thread per 4 consecutive k.  K % 32 == 0.
 __global__ __launch_bounds__(256) void k_split_planes(const float* __restrict__ x, unsigned short* __restrict__ bp, size_t quads, int K, VcgAmax amax) {
   float s, inv;
@@ -246,6 +409,13 @@ int vcg_gemm_planes_batched(const void* APlanes, const void* BtPlanes, float* C,
   p.c_bstride = (size_t)rows * N;
   p.amax_a = amax_a; p.amax_b = amax_b; p.amax_a_keep = amax_a_keep;
   const int bn = (N % 128 == 0) ? 128 : 64;
+  if (bn == 128 && rows >= 256 && K >= 64 && gemm_dma_on()) {
+    dim3 grid((rows + GD_BM - 1) / GD_BM, N / GD_BN, batches);
+    VcgProfScope prof("k_gemm_planes_dma", 2.0 * rows * (double)K * N * batches, st);
+    hipLaunchKernelGGL(k_gemm_planes_dma, grid, dim3(512), 0, st, p);
+    VCG_LAUNCH_CHECK("vcg_gemm_planes_batched(dma)");
+    return 0;
+  }
   dim3 grid((rows + 127) / 128, N / bn, batches);
   VcgProfScope prof(bn == 128 ? "k_gemm_split<128, planes>" : "k_gemm_split<64, planes>", 2.0 * rows * (double)K * N * batches, st);
   if (bn == 128) hipLaunchKernelGGL((k_gemm_split<128, true>), grid, dim3(256), 0, st, p);

@@ -6,6 +6,7 @@
 #include <stdarg.h>
 #include <string.h>
 #include "vcg_common.h"
+#include <stdlib.h>
 
 // ---------------------------------------------------------------- error plumbing
 static thread_local char g_err[512] = "";
@@ -118,6 +119,35 @@ static unsigned long long* amax_base(int dev) {
     base[dev] = (unsigned long long*)p;
   }
   return base[dev];
+}
+// ---------------------------------------------------------------- arrival counters of the finalize-in-the-producer kernels
+// (vcg_common.h, VcgInTail): a ring of 2^18 zero words; a launch takes the next `count` of them.  A counter returns to zero by
+// itself (atomicInc wraps on the last arrival), and the ring is far longer than the launches of several training steps, so
+// two kernels in flight never share a word.
+#define VCG_TAIL_COUNTERS (1 << 18)
+__device__ uint32_t g_vcg_tail_counters[VCG_TAIL_COUNTERS];
+#include <mutex>
+static std::mutex g_tail_mutex;
+static size_t g_tail_cursor = 0;
+bool vcg_in_tail_enabled() {
+  static const int on = [] { const char* e = getenv("VCG_IN_TAIL"); return e ? atoi(e) : 0; }();
+  return on != 0;
+}
+uint32_t* vcg_tail_counters(int count) {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  static thread_local uint32_t* base[64] = {};
+  if (dev < 0 || dev >= 64 || count <= 0 || count > VCG_TAIL_COUNTERS / 4) return nullptr;
+  if (!base[dev]) {
+    void* p = nullptr;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_vcg_tail_counters)) != hipSuccess) return nullptr;
+    base[dev] = (uint32_t*)p;
+  }
+  std::lock_guard<std::mutex> lock(g_tail_mutex);
+  if (g_tail_cursor + (size_t)count > VCG_TAIL_COUNTERS) g_tail_cursor = 0;       // a run of counters never straddles the end
+  uint32_t* out = base[dev] + g_tail_cursor;
+  g_tail_cursor += (size_t)count;
+  return out;
 }
 #define VCG_HANDLE_MAGIC 0xA5ull
 uint64_t vcg_amax_handle(const VcgAmaxOut& o) {

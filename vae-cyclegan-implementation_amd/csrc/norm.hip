@@ -16,11 +16,11 @@ static NormPlan make_plan(int N, int HW, int C) { return vcg_norm_plan(N, HW, C)
 // ---- stage 1 of every per-(n,c) reduction -------------------------------------------
 // MODE 0: (sum t, sum t^2)
 // MODE 1: (sum g', sum g' * xhat)  with xhat=(t-mean)*rstd, g' = g * post_act'(xhat)
-template <int MODE>
+template <int MODE, bool TAIL>
 __global__ __launch_bounds__(256) void k_in_partial(const float* __restrict__ t, const float* __restrict__ g,
                                                     const float* __restrict__ mean, const float* __restrict__ rstd,
                                                     double* __restrict__ part, int H, int W, int C, NormPlan pl,
-                                                    int post_act, int shuffle) {
+                                                    int post_act, int shuffle, VcgInTail tail) {
   // fp64 accumulators: these sums cancel (var = E[x^2] - mean^2 for channels with |mean| >> std;
   // sum g' and sum g'*xhat in the backward), and torch's CPU kernel — the reference's numerics —
   // accumulates them in double too.  The kernel is HBM-bound, the extra fp64 adds are free.
@@ -94,9 +94,20 @@ __global__ __launch_bounds__(256) void k_in_partial(const float* __restrict__ t,
     double* o = part + (((size_t)n * pl.nchunk + blockIdx.x) * C + c4 * 4) * 2;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      o[2 * e] = s1[e];
-      o[2 * e + 1] = s2[e];
+      if (TAIL) {
+        vcg_store_sc1(o + 2 * e, s1[e]);
+        vcg_store_sc1(o + 2 * e + 1, s2[e]);
+      } else {
+        o[2 * e] = s1[e];
+        o[2 * e + 1] = s2[e];
+      }
     }
+  }
+  // the last of this (image, channel group)'s chunk blocks combines them (vcg_common.h; VCG_IN_TAIL=1)
+  if (TAIL) {
+    __syncthreads();                  // r1 / r2 are free again
+    vcg_in_tail_run<MODE>(tail, part, n, blockIdx.z * pl.TC * 4, pl.TC * 4, C, pl.nchunk, tail.counters + n * pl.cgroups + blockIdx.z,
+                          (uint32_t)pl.nchunk, r1);
   }
 }
 
@@ -271,10 +282,15 @@ int vcg_in_stats_pass(const float* t, float* mean, float* rstd, int N, int HW, i
   VCG_CHECK_ARG(ws_bytes >= vcg_in_workspace(N, HW, C), "vcg_in_stats: workspace too small");
   NormPlan pl = make_plan(N, HW, C);
   double* part = (double*)ws;
-  hipLaunchKernelGGL(k_in_partial<0>, dim3(pl.nchunk, N, pl.cgroups), dim3(256), 0, st, t, (const float*)nullptr,
-                     (const float*)nullptr, (const float*)nullptr, part, HW, 1, C, pl, 0, 0);
+  VcgInTail tail = vcg_in_tail_make(mean, rstd, N * pl.cgroups, HW, eps);
+  if (tail.out1)
+    hipLaunchKernelGGL((k_in_partial<0, true>), dim3(pl.nchunk, N, pl.cgroups), dim3(256), 0, st, t, (const float*)nullptr,
+                       (const float*)nullptr, (const float*)nullptr, part, HW, 1, C, pl, 0, 0, tail);
+  else
+    hipLaunchKernelGGL((k_in_partial<0, false>), dim3(pl.nchunk, N, pl.cgroups), dim3(256), 0, st, t, (const float*)nullptr,
+                       (const float*)nullptr, (const float*)nullptr, part, HW, 1, C, pl, 0, 0, tail);
   VCG_LAUNCH_CHECK("vcg_in_stats");
-  return vcg_in_finalize(part, mean, rstd, N, HW, C, pl.nchunk, eps, st);
+  return tail.out1 ? 0 : vcg_in_finalize(part, mean, rstd, N, HW, C, pl.nchunk, eps, st);
 }
 extern "C" int vcg_in_stats(const float* t, float* mean, float* rstd, int N, int HW, int C, float eps,
                             void* ws, size_t ws_bytes, void* stream) {
@@ -308,10 +324,16 @@ extern "C" int vcg_in_bwd(const float* g, const float* t, const float* mean, con
   hipStream_t st = (hipStream_t)stream;
   double* part = (double*)ws;
   float* s12 = (float*)(part + (size_t)N * pl.nchunk * C * 2);
-  hipLaunchKernelGGL(k_in_partial<1>, dim3(pl.nchunk, N, pl.cgroups), dim3(256), 0, st, t, g, mean, rstd, part, H, W,
-                     C, pl, post_act, shuffle);
-  hipLaunchKernelGGL(k_in_final<1>, dim3((N * C + 31) / 32), dim3(256), 0, st, (const double*)part, s12,
-                     (float*)nullptr, N, HW, C, pl.nchunk, 0.f);
+  VcgInTail tail = vcg_in_tail_make(s12, nullptr, N * pl.cgroups, HW, 0.f);
+  if (tail.out1)
+    hipLaunchKernelGGL((k_in_partial<1, true>), dim3(pl.nchunk, N, pl.cgroups), dim3(256), 0, st, t, g, mean, rstd, part, H, W,
+                       C, pl, post_act, shuffle, tail);
+  else
+    hipLaunchKernelGGL((k_in_partial<1, false>), dim3(pl.nchunk, N, pl.cgroups), dim3(256), 0, st, t, g, mean, rstd, part, H, W,
+                       C, pl, post_act, shuffle, tail);
+  if (!tail.out1)
+    hipLaunchKernelGGL(k_in_final<1>, dim3((N * C + 31) / 32), dim3(256), 0, st, (const double*)part, s12,
+                       (float*)nullptr, N, HW, C, pl.nchunk, 0.f);
   size_t total = (size_t)N * HW * (C / 4);
   const VcgAmaxOut ao = vcg_amax_new(st);
   hipLaunchKernelGGL(k_in_bwd_apply, dim3(ew_blocks(total)), dim3(256), 0, st, g, t, mean, rstd, (const float*)s12,
