@@ -175,6 +175,13 @@ ORACLE_CONV_CASES = [
     ("D", (32, 64), {}, (1, 32, 128, 144)),           # 3x3 mode through a folded PixelUnshuffle: four channel groups = the four phases
     ("CaSb", (3, 64, 7), {}, (1, 3, 72, 64)),         # stem: x (3 channels) is the ring operand, read through the reflect padding
     ("CaSb", (64, 3, 7), {"activation": "Identity", "use_norm": False}, (2, 64, 64, 80)),   # head: dy is the ring, ragged segments (86 = 2.7 x 32)
+    # round 3: the LDS-DMA GEMM of the Winograd layers (gemm_split.hip, k_gemm_planes_dma: from 256 tile rows on) — forward 256 rows
+    # = one whole 256 x 128 tile per column tile, data gradient 289 rows over the padded domain = a second tile with 33 valid rows
+    ("S", (256, 256), {}, (1, 256, 32, 32)),
+    # ... and the weight gradient of the D4 shape class as a planes GEMM over transposed operands (conv_wino.hip, k_wino_in_tr /
+    # k_wino_dy_tr: Kc = 2048): 32 tiles = ONE K-step of that GEMM, 64 tiles = two
+    ("D", (512, 1024), {}, (2, 512, 16, 16)),
+    ("D", (512, 1024), {}, (4, 512, 16, 16)),
 ]
 
 
@@ -1156,7 +1163,12 @@ def test_two_rank_step_equals_the_big_batch_step(pkg, device, tmp_path):
             # the shards take other launch plans than the batch of two (M halves), so roundings and a few ReLU masks differ:
             # the flip allowance of the step tests; a wiring error (no 1/world, a slice not exchanged, a slice reduced while
             # a stream still wrote into it) is O(1) on that slice
-            gtol = 3e-2 if step_i == 0 else 0.3
+            # (round 3: 6e-2, from 3e-2 — part (a) above allows each of the two results 4 x the reference's own fp32-vs-fp64 error
+            # per tensor, ~4e-2 on the generators' tensors of this GAN step, so two correct results may sit further apart than 3e-2:
+            # measured 2.3e-2 with the D1 / U2 forward on the Winograd kernels and 4.8e-2 on the direct ones, the same build
+            # otherwise.  A slice that was not exchanged is half its size off: a ninth of the parameters (one bucket) shows as 0.17)
+            gtol = 6e-2 if step_i == 0 else 0.3
+            print(f"two-rank vs big batch, step {step_i}, optimizer_{name}: {err:.3e}")
             assert err <= gtol, f"step {step_i} optimizer_{name}: averaged shard gradients differ from the big-batch gradient by {err:.2e}"
             dp = (two["param" + name] - opt.flat_param.cpu()).abs().max().item()
             assert dp <= 2.5 * LR * (step_i + 1), f"step {step_i} optimizer_{name}: parameters differ by {dp:.2e}"

@@ -2572,6 +2572,19 @@ int vcg_wino_wgrad_core(const ConvGeom& g, const float* V, const float* dM, int 
   return 0;
 }
 
+// the back-transform of a dU that is already whole (vcg_wino_wgrad's transposed-operand GEMM): k_wino_wgrad_reduce over one part
+int vcg_wino_wgrad_reduce_one(const ConvGeom& g, const float* dU, float* gw_oihw, hipStream_t st) {
+  const ConvGeom q = wino_gemm_geom(g, 32);
+  ConvP p; fill_params(q, p);
+  p.nbatch = 16;
+  p.ktiles_total = 1; p.sk_len = 1; p.sk_ntn = 1; p.sk_bm_shift = 30; p.sk_bn_shift = 30;      // sk_parts() == 1 everywhere
+  p.fd_sklen = make_fastdiv(1u);
+  hipLaunchKernelGGL(k_wino_wgrad_reduce, dim3(g.Cout / 64, (g.Cin + 7) / 8, g.ups * g.ups), dim3(256), 0, st, dU, gw_oihw, p, g.Cin,
+                     g.ups, g.cin_log, g.cout_log);
+  VCG_LAUNCH_CHECK("vcg_conv_wgrad(winograd reduce)");
+  return 0;
+}
+
 extern "C" size_t vcg_conv_wgrad_workspace(const int32_t* cd) {
   ConvGeom g;
   if (vcg_conv_geom(cd, &g, "vcg_conv_wgrad_workspace")) return 0;
@@ -2632,7 +2645,7 @@ extern "C" int vcg_conv_wgrad_saved(const float* x, const float* dy, float* gw_o
   VCG_CHECK_ARG(ws_bytes >= need, "vcg_conv_wgrad: workspace %zu < %zu", ws_bytes, need);
   if (vcg_wino_wgrad_ok(g)) {
     const size_t wbytes = vcg_wino_wgrad_workspace(g);
-    if (vcg_wino_wgrad(g, x, dy, gw_oihw, ws, wbytes, (hipStream_t)stream, saved, x_handle)) return -2;
+    if (vcg_wino_wgrad(g, x, dy, gw_oihw, ws, wbytes, (hipStream_t)stream, saved, x_handle, dy_handle)) return -2;
     if (gbias) return launch_colsum(g, dy, gbias, (float*)((char*)ws + ((wbytes + 255) / 256) * 256), (hipStream_t)stream);
     return 0;
   }

@@ -556,6 +556,140 @@ __global__ __launch_bounds__(256) void k_wino_dy(const float* __restrict__ dy, f
   if (p.amax_slot) vcg_amax_publish(amax, p.amax_slot, p.amax_gen, amax_red);
 }
 
+// ---- round 3: the weight gradient of the deep layers as a plain planes GEMM ------------------------------------------------------
+// dU[xi] = V[xi]^T dM[xi] reduces over the TILES.  With few tiles and many channels (R blocks: 512 tiles, 1024 x 1024 channels; D4,
+// D3) the stream-K kernel of conv_igemm.hip has 16 K-steps per 128 x 128 output tile, leaves partial tiles in slabs and runs at a
+// third of the rate of the forward GEMM on the same FLOPs.  Here the two operands are written TRANSPOSED by their transforms —
+// Vt[xi][k][t], dMt[xi][co][t] as blocked planes along t (the reduction index contiguous, exactly the layout of a GEMM operand) —
+// and the 16 products are one launch of the forward's own GEMM (k_gemm_planes_dma: rows = Kc, N = Cout, K = T), whole tiles, no
+// slabs; k_wino_wgrad_reduce then reads ONE part.  The transposition happens in LDS inside the transform kernels: a block owns
+// 32 tiles x 32 channels, every thread one tile x 4 channels, and per four transform points the 4 x 2 x 32 rows (point, piece,
+// channel) of 32 tiles = 64 bytes go out as whole half-lines.
+constexpr int WT_PITCH = 34;                                    // fp16 elements per LDS row of 32 tiles (68 bytes: rows 4-byte aligned)
+__device__ __forceinline__ void wino_tr_store(unsigned short* __restrict__ sh, const float4* __restrict__ o4, float inv, int tl, int q,
+                                              unsigned short* __restrict__ dst, size_t xi_stride, size_t row0, int TB, int tb) {
+  // o4[4]: the values of four transform points for this thread's (tile tl, channels 4 q .. 4 q + 3); dst rows: [xi][channel][TB][2][32]
+#pragma unroll
+  for (int x = 0; x < 4; ++x) {
+    uint2 h, l;
+    split4h(o4[x], inv, h, l);
+    const unsigned short hv[4] = {(unsigned short)h.x, (unsigned short)(h.x >> 16), (unsigned short)h.y, (unsigned short)(h.y >> 16)};
+    const unsigned short lv[4] = {(unsigned short)l.x, (unsigned short)(l.x >> 16), (unsigned short)l.y, (unsigned short)(l.y >> 16)};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      sh[((x * 2 + 0) * 32 + 4 * q + e) * WT_PITCH + tl] = hv[e];
+      sh[((x * 2 + 1) * 32 + 4 * q + e) * WT_PITCH + tl] = lv[e];
+    }
+  }
+  __syncthreads();
+  {
+    // thread -> (point x, channel c, piece pc): its 32 tiles = 64 contiguous bytes; lanes 2 j, 2 j + 1 = the two pieces = one 128-byte line
+    const int pc = threadIdx.x & 1, c = (threadIdx.x >> 1) & 31, x = threadIdx.x >> 6;
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(sh + ((x * 2 + pc) * 32 + c) * WT_PITCH);
+    uint4 v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = make_uint4(src[4 * j], src[4 * j + 1], src[4 * j + 2], src[4 * j + 3]);
+    unsigned short* o = dst + (size_t)x * xi_stride + ((row0 + c) * TB + tb) * VCG_PBLK + pc * 32;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) *reinterpret_cast<uint4*>(o + 8 * j) = v[j];
+  }
+  __syncthreads();
+}
+// V = B^T d B of a block of 32 tiles x 32 channels: the forward's planes (WinoP::vplanes, may be null) and / or the transposed
+// planes vt[xi][k][T / 32][2][32].  Grid (T / 32, Kc / 32); T % 32 == 0, Kc % 32 == 0.
+__global__ __launch_bounds__(256) void k_wino_in_tr(WinoP p, unsigned short* __restrict__ vt) {
+  __shared__ __attribute__((aligned(16))) unsigned short sh[4 * 2 * 32 * WT_PITCH];
+  float sc, inv;
+  vcg_scale_of(vcg_amax_bits(p.amax_x), p.amax_x.shift, sc, inv);
+  const int tl = threadIdx.x >> 3, q = threadIdx.x & 7;
+  const uint32_t t = blockIdx.x * 32 + tl;
+  const uint32_t k4 = blockIdx.y * 8 + q;
+  const uint32_t ph = fd_div(k4, p.fd_c4);
+  const int c = (int)(k4 - ph * (uint32_t)(p.Cin / 4)) * 4;
+  const int pi = (int)(ph >> 1), pj = (int)(ph & 1);
+  const uint32_t n = fd_div(t, p.fd_thtw);
+  const uint32_t rem = t - n * (uint32_t)(p.th * p.tw);
+  const uint32_t ty = fd_div(rem, p.fd_tw);
+  const int tx = (int)(rem - ty * (uint32_t)p.tw);
+  const float* xn = p.x + (size_t)n * p.H * p.W * p.Cin;
+  float4 d[4][4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    int ih = 2 * (int)ty - p.off + r;
+    bool okh = true;
+    if (p.reflect) ih = reflect_idx(ih, p.Hl);
+    else okh = ih >= 0 && ih < p.Hl;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      int iw = 2 * tx - p.off + s;
+      bool ok = okh;
+      if (p.reflect) iw = reflect_idx(iw, p.Wl);
+      else ok = ok && iw >= 0 && iw < p.Wl;
+      d[r][s] = ok ? *reinterpret_cast<const float4*>(xn + ((size_t)(ih * p.ups + pi) * p.W + (iw * p.ups + pj)) * p.Cin + c)
+                   : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+  float4 e[4][4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    e[0][s] = f4sub(d[0][s], d[2][s]);
+    e[1][s] = f4sum(d[1][s], d[2][s]);
+    e[2][s] = f4sub(d[2][s], d[1][s]);
+    e[3][s] = f4sub(d[1][s], d[3][s]);
+  }
+  const uint32_t k = k4 * 4;
+  const size_t KB = (size_t)p.Kc / 32;
+  const int TB = p.T / 32;
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    const float4 o[4] = {f4sub(e[a][0], e[a][2]), f4sum(e[a][1], e[a][2]), f4sub(e[a][2], e[a][1]), f4sub(e[a][1], e[a][3])};
+    if (p.vplanes) {
+      unsigned short* vb = p.vplanes + ((size_t)t * KB + k / 32) * VCG_PBLK + (k & 31);
+      const size_t plane = (size_t)p.T * KB * VCG_PBLK;
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        uint2 h, l;
+        split4h(o[b], inv, h, l);
+        unsigned short* w = vb + (size_t)(a * 4 + b) * plane;
+        *reinterpret_cast<uint2*>(w) = h;
+        *reinterpret_cast<uint2*>(w + 32) = l;
+      }
+    }
+    if (vt) wino_tr_store(sh, o, inv, tl, q, vt + (size_t)(a * 4) * p.Kc * TB * VCG_PBLK, (size_t)p.Kc * TB * VCG_PBLK, (size_t)blockIdx.y * 32, TB, (int)blockIdx.x);
+  }
+}
+// dM = A dy A^T of a block of 32 tiles x 32 output channels, as transposed planes dmt[xi][co][T / 32][2][32] of dM / s, s from
+// 4 x the largest magnitude of dy (WinoP::amax_x).  Grid (T / 32, Cout / 32).
+__global__ __launch_bounds__(256) void k_wino_dy_tr(const float* __restrict__ dy, unsigned short* __restrict__ dmt, WinoP p) {
+  __shared__ __attribute__((aligned(16))) unsigned short sh[4 * 2 * 32 * WT_PITCH];
+  float sc, inv;
+  vcg_scale_of(vcg_amax_bits(p.amax_x), p.amax_x.shift, sc, inv);
+  const int tl = threadIdx.x >> 3, q = threadIdx.x & 7;
+  const uint32_t t = blockIdx.x * 32 + tl;
+  const int co = ((int)blockIdx.y * 8 + q) * 4;
+  const uint32_t n = fd_div(t, p.fd_thtw);
+  const uint32_t rem = t - n * (uint32_t)(p.th * p.tw);
+  const uint32_t ty = fd_div(rem, p.fd_tw);
+  const int tx = (int)(rem - ty * (uint32_t)p.tw);
+  const float* base = dy + (((size_t)n * p.Hl + 2 * ty) * p.Wl + 2 * tx) * p.Cout + co;
+  const float4 y00 = *reinterpret_cast<const float4*>(base);
+  const float4 y01 = *reinterpret_cast<const float4*>(base + p.Cout);
+  const float4 y10 = *reinterpret_cast<const float4*>(base + (size_t)p.Wl * p.Cout);
+  const float4 y11 = *reinterpret_cast<const float4*>(base + (size_t)p.Wl * p.Cout + p.Cout);
+  const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 z[4][2];
+  z[0][0] = y00;              z[0][1] = y01;
+  z[1][0] = f4sum(y00, y10);  z[1][1] = f4sum(y01, y11);
+  z[2][0] = f4sub(y00, y10);  z[2][1] = f4sub(y01, y11);
+  z[3][0] = f4sub(zero, y10); z[3][1] = f4sub(zero, y11);
+  const int TB = p.T / 32;
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    const float4 o[4] = {z[a][0], f4sum(z[a][0], z[a][1]), f4sub(z[a][0], z[a][1]), f4sub(zero, z[a][1])};
+    wino_tr_store(sh, o, inv, tl, q, dmt + (size_t)(a * 4) * p.Cout * TB * VCG_PBLK, (size_t)p.Cout * TB * VCG_PBLK, (size_t)blockIdx.y * 32, TB, (int)blockIdx.x);
+  }
+}
+
 // ------------------------------------------------------------------ host side
 static int wino_blocks(size_t work) {
   size_t b = (work + 255) / 256;
@@ -625,6 +759,23 @@ bool vcg_wino_wgrad_ok(const ConvGeom& g) {
   const long long kc = (long long)g.ups * g.ups * g.Cin;
   return vcg_wino_fwd_ok(g) && kc % 128 == 0 && kc * g.Cout >= vcg_wino_gate_wgrad() * (kc + g.Cout);
 }
+// VCG_WGRAD_TR=0: the stream-K reduction for every layer (A/B measurements)
+static bool wgrad_tr_on() {
+  static const int on = [] { const char* e = getenv("VCG_WGRAD_TR"); return e ? atoi(e) : 1; }();
+  return on != 0;
+}
+// the weight gradient as a plain planes GEMM over transposed operands (k_wino_in_tr / k_wino_dy_tr above): enough output tiles
+// of 256 x 128 to fill the chip, whole 32-tile blocks.  Measured per layer at batch 8 (profiles/r03_wgrad_tr.txt; the forward pays
+// for the second, transposed copy of V): R weight gradient 154 -> 144 us but forward 81 -> 91; D3 226 -> 182 but 178 -> 223 (V is
+// 134 MB there); D4 319 -> 280 against 138 -> 155 — the one layer where it nets (VCG_WGRAD_TR=2: every layer that qualifies)
+bool vcg_wino_wgrad_tr_ok(const ConvGeom& g) {
+  if (!wgrad_tr_on() || !vcg_wino_wgrad_ok(g)) return false;
+  const long long kc = (long long)g.ups * g.ups * g.Cin, T = (long long)g.N * (g.Ho / 2) * (g.Wo / 2);
+  static const int all = [] { const char* e = getenv("VCG_WGRAD_TR"); return e && atoi(e) == 2; }();
+  if (!all && !(kc >= 2048 && T <= 1024)) return false;
+  return T % 32 == 0 && kc % 32 == 0 && g.Cout % 128 == 0 && kc >= 256 && ((kc + 255) / 256) * (g.Cout / 128) * 16 >= 192 &&
+         16 * kc * T * VCG_NP < (1ll << 32) && 16 * (long long)g.Cout * T * VCG_NP < (1ll << 32);
+}
 size_t vcg_wino_wgrad_workspace(const ConvGeom& g) {
   const int T = g.N * (g.Ho / 2) * (g.Wo / 2);
   return vcg_wino_fwd_workspace(g) + vcg_wino_wgrad_core_workspace(g, T);
@@ -633,12 +784,35 @@ size_t vcg_wino_wgrad_workspace(const ConvGeom& g) {
 static size_t wino_v_floats(const ConvGeom& g) { return (size_t)16 * g.N * (g.Ho / 2) * (g.Wo / 2) * g.ups * g.ups * g.Cin; }
 size_t vcg_wino_saved_floats(const ConvGeom& g) { return vcg_wino_wgrad_ok(g) ? wino_v_floats(g) + 16 : 0; }
 int vcg_wino_wgrad(const ConvGeom& g, const float* x, const float* dy, float* gw_oihw, void* ws, size_t ws_bytes, hipStream_t st,
-                   const float* v_saved, uint64_t x_handle) {
+                   const float* v_saved, uint64_t x_handle, uint64_t dy_handle) {
   VCG_CHECK_ARG(ws && ws_bytes >= vcg_wino_wgrad_workspace(g), "vcg_conv_wgrad: workspace too small for the Winograd path");
   WinoP p = wino_params(g);
   float* V = (float*)ws;
   float* dM = V + (((size_t)16 * p.T * p.Kc + 63) / 64) * 64;
   const size_t tbytes = vcg_wino_fwd_workspace(g);
+  if (vcg_wino_wgrad_tr_ok(g)) {
+    // transposed operands -> one planes GEMM dU[xi] = Vt[xi] . dMt[xi]^T (rows Kc, N Cout, K = T) -> back-transform of ONE part
+    VcgAmax amax_v;
+    const unsigned short* Vt;
+    if (v_saved) {                     // the forward left Vt (vcg_wino_fwd) and, behind it, the word its scale came from
+      Vt = reinterpret_cast<const unsigned short*>(v_saved);
+      amax_v = vcg_amax_stored(v_saved + wino_v_floats(g), WINO_V_SHIFT);
+    } else {
+      if (vcg_operand_amax(x, (size_t)g.N * g.H * g.W * g.Cin, x_handle, WINO_V_SHIFT, st, &amax_v)) return -2;
+      p.x = x; p.amax_x = amax_v; p.vplanes = nullptr;
+      hipLaunchKernelGGL(k_wino_in_tr, dim3(p.T / 32, p.Kc / 32), dim3(256), 0, st, p, (unsigned short*)V);
+      Vt = reinterpret_cast<const unsigned short*>(V);
+    }
+    VcgAmax amax_d;
+    if (vcg_operand_amax(dy, (size_t)g.N * g.Ho * g.Wo * g.Cout, dy_handle, WINO_V_SHIFT, st, &amax_d)) return -2;   // |A dy A^T| <= 4 max|dy|
+    WinoP pd = p;
+    pd.amax_x = amax_d;
+    hipLaunchKernelGGL(k_wino_dy_tr, dim3(p.T / 32, g.Cout / 32), dim3(256), 0, st, dy, (unsigned short*)dM, pd);
+    VCG_LAUNCH_CHECK("vcg_conv_wgrad(winograd transforms, transposed)");
+    float* dU = reinterpret_cast<float*>((char*)ws + tbytes);
+    if (vcg_gemm_planes_batched(Vt, dM, dU, p.Kc, p.T, g.Cout, 16, amax_v, amax_d, st, nullptr)) return -2;
+    return vcg_wino_wgrad_reduce_one(g, dU, gw_oihw, st);
+  }
   p.x = x; p.v = V;
   VcgAmax amax_v;
   const bool planes = wino_planes_on();
@@ -741,7 +915,18 @@ int vcg_wino_fwd(const ConvGeom& g, const float* x, const float* u, const void* 
   float* M = (float*)ws + (((size_t)16 * p.T * p.Kc + 63) / 64) * 64;
   p.x = x; p.v = V; p.m = M; p.bias = bias; p.y = y;
   uint32_t* const keep_word = v_keep ? reinterpret_cast<uint32_t*>(v_keep + wino_v_floats(g)) : nullptr;
-  if (wino_planes_on()) {
+  if (v_keep && vcg_wino_wgrad_tr_ok(g)) {
+    // this layer's weight gradient wants V TRANSPOSED (vcg_wino_wgrad): one transform kernel writes the forward's planes into
+    // the workspace and the transposed ones into the caller's buffer
+    VCG_CHECK_ARG(wino_planes_on(), "VCG_WINO_PLANES=0 needs VCG_WGRAD_TR=0");
+    VcgAmax ax;
+    if (vcg_operand_amax(x, (size_t)g.N * g.H * g.W * g.Cin, x_handle, WINO_V_SHIFT, st, &ax)) return -2;
+    V = (float*)ws;
+    p.v = V; p.amax_x = ax; p.vplanes = (unsigned short*)V;
+    hipLaunchKernelGGL(k_wino_in_tr, dim3(p.T / 32, p.Kc / 32), dim3(256), 0, st, p, (unsigned short*)v_keep);
+    VCG_LAUNCH_CHECK("vcg_conv_fwd(winograd input transform, + transposed)");
+    if (vcg_gemm_planes_batched(V, u, M, p.T, p.Kc, g.Cout, 16, ax, vcg_amax_stored(w_amax, WINO_U_SHIFT), st, keep_word)) return -2;
+  } else if (wino_planes_on()) {
     VcgAmax ax;
     if (vcg_operand_amax(x, (size_t)g.N * g.H * g.W * g.Cin, x_handle, WINO_V_SHIFT, st, &ax)) return -2;
     p.amax_x = ax; p.vplanes = (unsigned short*)V;

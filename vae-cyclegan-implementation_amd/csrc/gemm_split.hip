@@ -409,7 +409,7 @@ int vcg_gemm_planes_batched(const void* APlanes, const void* BtPlanes, float* C,
   p.c_bstride = (size_t)rows * N;
   p.amax_a = amax_a; p.amax_b = amax_b; p.amax_a_keep = amax_a_keep;
   const int bn = (N % 128 == 0) ? 128 : 64;
-  if (bn == 128 && rows >= 256 && K >= 64 && gemm_dma_on()) {
+  if (bn == 128 && rows >= 256 && gemm_dma_on()) {
     dim3 grid((rows + GD_BM - 1) / GD_BM, N / GD_BN, batches);
     VcgProfScope prof("k_gemm_planes_dma", 2.0 * rows * (double)K * N * batches, st);
     hipLaunchKernelGGL(k_gemm_planes_dma, grid, dim3(512), 0, st, p);

@@ -404,7 +404,9 @@ size_t vcg_wino_fwd_stats_doubles(const ConvGeom& g);
 bool vcg_wino_wgrad_ok(const ConvGeom& g);
 size_t vcg_wino_wgrad_workspace(const ConvGeom& g);
 int vcg_wino_wgrad(const ConvGeom& g, const float* x, const float* dy, float* gw_oihw, void* ws, size_t ws_bytes, hipStream_t st,
-                   const float* v_saved = nullptr, uint64_t x_handle = 0);
+                   const float* v_saved = nullptr, uint64_t x_handle = 0, uint64_t dy_handle = 0);
+bool vcg_wino_wgrad_tr_ok(const ConvGeom& g);
+int vcg_wino_wgrad_reduce_one(const ConvGeom& g, const float* dU, float* gw_oihw, hipStream_t st);   // dU [16][Kc][Cout], one part
 size_t vcg_wino_wgrad_core_workspace(const ConvGeom& g, int T);
 int vcg_wino_wgrad_core(const ConvGeom& g, const float* V, const float* dM, int T, float* gw_oihw, void* ws, size_t ws_bytes,
                         hipStream_t st, const VcgAmax& amax_v, const VcgAmax& amax_dm, bool v_planes);
