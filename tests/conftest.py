@@ -166,11 +166,11 @@ def assert_checksum(t, ck, what, tol=RTOL):
         raise AssertionError(f"{what}: sampled elements differ by {err:.3e} = {err / ref:.2e} of their scale")
 
 
-# One ReLU-mask flip (below) in the smallest maps of the 64 x 64 fixtures — the R blocks at 4 x 4, batch 2: 32 768 activations,
-# half of the 65 536 the 1e-2 was calibrated on — moves that layer's weight gradient by 1.0e-2: seen on
-# dve64 / decoder_A.model.0.conv2.weight when round 3 moved the D1 / U2 forward from Winograd to the (more accurate) direct
-# kernel (1.7e-4 with either arithmetic upstream of the flip, 1.00e-2 with the other; gpurun_out of that round), and the
-# reference's own fp32 run sits at 1.38e-2 from its fp64 run on the same tensor of the sibling fixture dae64.  Hence 1.5e-2.
+# One ReLU-mask flip (below) moves the weight gradients of its layer and of everything upstream by 0.3..1.0e-2: seen on dve64 when
+# round 3 moved the D1 / U2 forward from the Winograd to the direct kernels — every tensor upstream of decoder_A's last ReLU went
+# from ~2e-4 to 3..8e-3 of its norm (decoder_A.model.0.conv2.weight: 1.00e-2), the untouched decoder_B stayed at 5e-5
+# (profiles/r03_grad_error.txt) — and the reference's own fp32 run sits at 1.38e-2 from its fp64 run on that tensor of the
+# sibling fixture dae64.  1e-2 was calibrated on one flip among 65 536 activations; the maps here go down to 32 768.  Hence 1.5e-2.
 FLIP_BUDGET = 1.5e-2
 
 # every deep-step gradient comparison is appended here as (fixture key, tensor, ours / ||g||, reference fp32 / ||g||,
@@ -231,7 +231,9 @@ def assert_param_after_step(t, ck, what, lr, nsteps=1, got=None, gck32=None, gck
     got = checksum(t) if got is None else got
     # after the first step the norm is pinned to 1e-3; later snapshots add what sign noise can do to it: every element may
     # have stepped lr the other way in each step (small bias vectors after two GAN steps differ by 1-3e-3 in norm)
-    slack = 0.0 if nsteps == 1 else 0.5 * nsteps * lr * np.sqrt(max(t2n(t).size, 1))
+    # (first step, round 3: a quarter of that — elements whose gradient is rounding noise step +-lr in either implementation, and a
+    # 64-element bias moved 1.8e-4 in norm (1.5e-3 of it) between two correct builds; the solid elements are pinned one by one below)
+    slack = (0.25 if nsteps == 1 else 0.5 * nsteps) * lr * np.sqrt(max(t2n(t).size, 1))
     if not abs(got[1] - ck[1]) <= 1e-3 * max(ck[1], 1e-30) + slack:
         raise AssertionError(f"{what}: L2 norm {got[1]:.6e} vs {ck[1]:.6e}")
     s0 = 2 + N_PROJ

@@ -1,9 +1,9 @@
 # Regenerates the committed profiles of a round on the GPU box:
-#   VCG_HEAD=$(git rev-parse --short HEAD) gpurun --timeout 1100 -- "VCG_HEAD=$VCG_HEAD R=r02 bash tools/final_profiles.sh"
+#   VCG_HEAD=$(git rev-parse --short HEAD) gpurun --timeout 1100 -- "VCG_HEAD=$VCG_HEAD R=r03 bash tools/final_profiles.sh"
 # (the box has no .git: the commit the passes were taken at travels in VCG_HEAD and ends up in every JSON's "head")
 set -x
 cd $GRAFT_REPO_ROOT
-R=${R:-r02}
+R=${R:-r03}
 O=$GRAFT_REPO_ROOT/gpurun_out
 export VCG_HEAD=${VCG_HEAD:-unknown}
 python bench.py --steps 10 --warmup 3 > $O/${R}_bench.json 2> $O/${R}_bench.err || exit 1
@@ -25,4 +25,10 @@ cp $(find $O/prof_se -name '*kernel_stats.csv' | head -1) $O/${R}_kernel_stats_s
 python bench.py --workload vae --steps 10 --warmup 3 --no-cpu-baseline > $O/${R}_bench_vae.json 2> $O/${R}_bench_vae.err || exit 9
 python bench.py --workload autoencoder --steps 10 --warmup 3 --no-cpu-baseline > $O/${R}_bench_ae.json 2> $O/${R}_bench_ae.err || exit 10
 python tools/conv_bench.py --layers stem,d1,d2,d3,d4,r,mu,vdb,u1,u2,u3,u4,head,disc1 > $O/${R}_conv_microbench.txt 2>&1 || exit 11
+python tools/conv_accuracy.py > $O/${R}_conv_accuracy.txt 2>&1 || exit 12
+VCG_BENCH_SHAPES=$O/${R}_step_shapes.txt python bench.py --steps 5 --warmup 2 --no-cpu-baseline > /dev/null 2>> $O/${R}_bench.err || exit 13
+: > $O/${R}_bench_other_archs.jsonl
+for w in cycleaegan cycleae cyclevae doubleae doublevae aegan vaegan; do
+  python bench.py --workload $w --steps 10 --warmup 3 --no-cpu-baseline >> $O/${R}_bench_other_archs.jsonl 2>> $O/${R}_bench.err || echo "FAILED $w"
+done
 echo ALL DONE

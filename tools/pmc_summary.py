@@ -55,9 +55,10 @@ def families(seq):
             nxt = [seq[j]["name"] for j in range(i + 1, min(i + 4, len(seq)))]
             fam[i] = "conv_wgrad" if nxt and nxt[0].startswith("k_wino_dy") else \
                      "conv_dgrad" if len(nxt) > 1 and nxt[1].startswith(("k_wino_out_pad", "k_wino_out_fold")) else "conv_fwd"
-        elif n.startswith("k_gemm_split"):
+        elif n.startswith(("k_gemm_split", "k_gemm_planes")):
             nxt = seq[i + 1]["name"] if i + 1 < len(seq) else ""
-            fam[i] = "conv_dgrad" if nxt.startswith(("k_wino_out_pad", "k_wino_out_fold")) else "conv_fwd"
+            fam[i] = "conv_dgrad" if nxt.startswith(("k_wino_out_pad", "k_wino_out_fold")) else \
+                     "conv_wgrad" if nxt.startswith("k_wino_wgrad_reduce") else "conv_fwd"
         elif n.startswith(("k_conv_slab", "k_kwfold")):        # data gradient when a fold of the padded image follows
             nxt = [seq[j]["name"] for j in range(i + 1, min(i + 3, len(seq)))]
             fam[i] = "conv_dgrad" if any(x.startswith("k_fold_pad") for x in nxt) else "conv_fwd"

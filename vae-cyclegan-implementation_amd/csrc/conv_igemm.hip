@@ -616,14 +616,18 @@ __global__ __launch_bounds__(256, 2) void k_conv_fwd_split(ConvP p) {
   // a K slice stores its raw partial tile instead (bias/activation happen in k_splitk_finish)
   float* const dst = p.ksplit > 1 ? p.slab + (size_t)blockIdx.z * p.M * p.Cout : p.out + (size_t)zb * p.out_bstride;
   const int act = p.ksplit > 1 ? VCG_ACT_NONE : p.act;
-  float* const red = reinterpret_cast<float*>(&As[0][0]);     // [wm][BN][2] floats; the K loop's last barrier freed As
+  // the statistics' sums are kept in double from the first element on, as norm.hip's own pass and the Winograd output
+  // transform do: var = E[x^2] - mean^2 cancels for channels whose mean dwarfs their spread, and 64 squares summed in fp32
+  // left mean / rstd ~1e-5 off there — which the InstanceNorm backward (rstd up to 316 on near-dead channels) turned into
+  // gradient errors of 4e-3 on the 64 x 64 fixtures once D1 and U2 took this path (round 3; 2e-4 with the sums in double)
+  double* const red = reinterpret_cast<double*>(&As[0][0]);   // [wm][BN][2] doubles; the K loop's last barrier freed As
 #pragma unroll
   for (int j = 0; j < NI; ++j) {
     const int cl = wn * (BN / WN) + j * 32 + l31;
     const int co = n0 + cl;
     const bool cv = co < p.Cout;
     const float bv = (cv && p.ksplit <= 1 && p.bias && co < p.cout_log) ? p.bias[co] : 0.f;
-    float s1 = 0.f, s2 = 0.f;
+    double s1 = 0.0, s2 = 0.0;
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
 #pragma unroll
@@ -632,8 +636,10 @@ __global__ __launch_bounds__(256, 2) void k_conv_fwd_split(ConvP p) {
         const int m = m0 + wm * (BM / WM) + i * 32 + row;
         const float v = act_apply(acc[i][j][e] * sc.out + bv, act);
         if (cv && m < p.M) dst[(size_t)m * p.Cout + co] = v;
-        s1 += v;
-        s2 += v * v;
+        if (p.in_part) {
+          s1 += (double)v;
+          s2 += (double)v * (double)v;
+        }
       }
     }
     if (p.in_part) {                    // uniform; the host only sets it when every tile row is a valid pixel of ONE image
@@ -651,8 +657,8 @@ __global__ __launch_bounds__(256, 2) void k_conv_fwd_split(ConvP p) {
       const uint32_t n = fd_div((uint32_t)m0, p.fd_howo);
       const uint32_t chunk = ((uint32_t)m0 - n * (uint32_t)(p.Ho * p.Wo)) / BM;
       double* o = p.in_part + (((size_t)n * p.in_nchunk + chunk) * p.Cout + n0 + tid) * 2;
-      vcg_store_sc1(o, (double)red[tid * 2] + (double)red[(BN + tid) * 2]);
-      vcg_store_sc1(o + 1, (double)red[tid * 2 + 1] + (double)red[(BN + tid) * 2 + 1]);
+      vcg_store_sc1(o, red[tid * 2] + red[(BN + tid) * 2]);
+      vcg_store_sc1(o + 1, red[tid * 2 + 1] + red[(BN + tid) * 2 + 1]);
     }
     if (p.in_tail.out1) {
       const uint32_t n = fd_div((uint32_t)m0, p.fd_howo);

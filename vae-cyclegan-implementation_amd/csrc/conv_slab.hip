@@ -186,11 +186,11 @@ __global__ __launch_bounds__(256, 2) void k_conv_slab(SlabP p) {
   }
 
   // ---- epilogue: bias + activation, NHWC store; optionally the InstanceNorm partials of this pixel block
-  float* const red = reinterpret_cast<float*>(&As[0][0]);     // [wm][BN][2]; the last barrier freed As
+  double* const red = reinterpret_cast<double*>(&As[0][0]);   // [wm][BN][2]; the last barrier freed As.  Sums in double: conv_igemm.hip
   const int cl = wn * 32 + l31, co = n0 + cl;
   const bool cv = co < p.Cout;
   const float bv = (cv && p.bias && co < p.cout_log) ? p.bias[co] : 0.f;
-  float s1 = 0.f, s2 = 0.f;
+  double s1 = 0.0, s2 = 0.0;
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
 #pragma unroll
@@ -200,8 +200,10 @@ __global__ __launch_bounds__(256, 2) void k_conv_slab(SlabP p) {
       const int oy = oy0 + (m >> 4), ox = ox0 + (m & 15);
       const float v = act_apply((acc[i][e] + lo[i][e]) * oscale + bv, p.act);
       if (cv && oy < p.Ho && ox < p.Wo) p.out[(((size_t)n * p.Ho + oy) * p.Wo + ox) * p.Cout + co] = v;
-      s1 += v;
-      s2 += v * v;
+      if (p.in_part) {
+        s1 += (double)v;
+        s2 += (double)v * (double)v;
+      }
     }
   }
   if (p.in_part) {                      // uniform; the host sets it only when every block lies inside the image
@@ -216,8 +218,8 @@ __global__ __launch_bounds__(256, 2) void k_conv_slab(SlabP p) {
       double t1 = 0.0, t2 = 0.0;
 #pragma unroll
       for (int w = 0; w < WM; ++w) {
-        t1 += (double)red[(w * BN + tid) * 2];
-        t2 += (double)red[(w * BN + tid) * 2 + 1];
+        t1 += red[(w * BN + tid) * 2];
+        t2 += red[(w * BN + tid) * 2 + 1];
       }
       double* o = p.in_part + (((size_t)n * p.in_nchunk + blk) * p.Cout + n0 + tid) * 2;
       vcg_store_sc1(o, t1);

@@ -33,6 +33,11 @@ import torch
 import torch.distributed as dist
 
 
+# VCG_DP_FROM_BACKWARD=0: every bucket is exchanged after the backward (at `start`), none from inside it — the reference point of
+# tests/test_gpu_parity.py::test_two_rank_step_equals_the_big_batch_step, which requires the in-backward launches to change no bit
+FROM_BACKWARD = os.environ.get("VCG_DP_FROM_BACKWARD", "1") != "0"
+
+
 def default_bucket_bytes():
     """VCG_BUCKET_MB: size at which a gradient bucket closes (default 64 MiB; xGMI is point-to-point, few large collectives)."""
     return max(1, int(float(os.environ.get("VCG_BUCKET_MB", "64")) * (1 << 20)))
@@ -130,7 +135,7 @@ class GradReducer:
             pl.remaining[b] -= 1
             if stream is not None and not any(s is stream or s == stream for s in pl.streams[b]):
                 pl.streams[b].append(stream)
-            if pl.remaining[b] == 0:
+            if pl.remaining[b] == 0 and FROM_BACKWARD:
                 self._launch(opt, pl, b, stream, "backward")
 
     def start(self, optimizer):
