@@ -27,8 +27,8 @@
 extern "C" {
 #endif
 
-#define VCG_ABI_VERSION 3   /* round 3: packed weights and kept forward state carry fp16 x 2 planes + amax words (sizes changed);
-                               vcg_amax_hint / vcg_amax_last.  round 2: vcg_adam_step takes 1 - beta; vcg_conv_fwd_in,
+#define VCG_ABI_VERSION 4   /* 4: vcg_amax_measure.  3 (round 3): packed weights and kept forward state carry fp16 x 2 planes + amax
+                               words (sizes changed); vcg_amax_hint / vcg_amax_last.  round 2: vcg_adam_step takes 1 - beta; vcg_conv_fwd_in,
                                vcg_conv_wgrad_saved, input transforms, profiling */
 
 /* Operand magnitudes (round 3) ------------------------------------------------
@@ -44,6 +44,11 @@ extern "C" {
  * another tensor scales that operand wrongly: hand over only what vcg_amax_last returned for exactly that tensor. */
 void vcg_amax_hint(uint64_t x_amax, uint64_t dy_amax);
 uint64_t vcg_amax_last(void);
+/* Measure a tensor nobody published an amax for (n floats at t, 16-byte aligned), once, on `stream`: the handle serves every
+ * later call that reads the tensor on a stream ordered after this one (a forward and the weight gradient that re-reads x; the
+ * weight and data gradient of one dy) instead of each of them measuring it again.  0: no slot on this device (callers pass 0 on:
+ * the consumers measure). */
+uint64_t vcg_amax_measure(const float* t, size_t n, void* stream);
 
 /* conv descriptor: int32[16] ------------------------------------------------ */
 enum {

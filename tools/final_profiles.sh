@@ -1,4 +1,5 @@
 # Regenerates the committed profiles of a round on the GPU box:
+# (PART=1: the bench line, kernel stats and PMC passes; PART=2: the other workloads, microbench, accuracy — two gpurun calls)
 #   VCG_HEAD=$(git rev-parse --short HEAD) gpurun --timeout 1100 -- "VCG_HEAD=$VCG_HEAD R=r03 bash tools/final_profiles.sh"
 # (the box has no .git: the commit the passes were taken at travels in VCG_HEAD and ends up in every JSON's "head")
 set -x
@@ -6,6 +7,7 @@ cd $GRAFT_REPO_ROOT
 R=${R:-r03}
 O=$GRAFT_REPO_ROOT/gpurun_out
 export VCG_HEAD=${VCG_HEAD:-unknown}
+if [ "${PART:-all}" != "2" ]; then
 python bench.py --steps 10 --warmup 3 > $O/${R}_bench.json 2> $O/${R}_bench.err || exit 1
 export TMPDIR=/tmp
 cd /tmp
@@ -22,6 +24,9 @@ python tools/pmc_summary.py $F $W 3 $O/${R}_pmc_step_traffic.json > $O/${R}_pmc_
 python tools/pmc_mfma_util.py $M 3 $O/${R}_pmc_mfma_util.json > $O/${R}_pmc_mfma_util.txt || exit 8
 cp $(find $O/prof_ov -name '*kernel_stats.csv' | head -1) $O/${R}_kernel_stats.csv
 cp $(find $O/prof_se -name '*kernel_stats.csv' | head -1) $O/${R}_kernel_stats_serial.csv
+[ "${PART:-all}" = "1" ] && { echo PART 1 DONE; exit 0; }
+fi
+if [ "${PART:-all}" != "1" ]; then
 python bench.py --workload vae --steps 10 --warmup 3 --no-cpu-baseline > $O/${R}_bench_vae.json 2> $O/${R}_bench_vae.err || exit 9
 python bench.py --workload autoencoder --steps 10 --warmup 3 --no-cpu-baseline > $O/${R}_bench_ae.json 2> $O/${R}_bench_ae.err || exit 10
 python tools/conv_bench.py --layers stem,d1,d2,d3,d4,r,mu,vdb,u1,u2,u3,u4,head,disc1 > $O/${R}_conv_microbench.txt 2>&1 || exit 11
@@ -31,4 +36,5 @@ VCG_BENCH_SHAPES=$O/${R}_step_shapes.txt python bench.py --steps 5 --warmup 2 --
 for w in cycleaegan cycleae cyclevae doubleae doublevae aegan vaegan; do
   python bench.py --workload $w --steps 10 --warmup 3 --no-cpu-baseline >> $O/${R}_bench_other_archs.jsonl 2>> $O/${R}_bench.err || echo "FAILED $w"
 done
+fi
 echo ALL DONE

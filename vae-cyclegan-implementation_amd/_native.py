@@ -28,6 +28,7 @@ SIGNATURES = {
     "vcg_last_error": (_c.c_char_p, []),
     "vcg_amax_hint": (None, [_U64, _U64]),
     "vcg_amax_last": (_U64, []),
+    "vcg_amax_measure": (_U64, [_P, _Z, _P]),
     "vcg_profile_enable": (_I, [_I]),
     "vcg_profile_read": (_c.c_long, [_c.c_char_p, _Z]),
     "vcg_nchw_to_nhwc": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
@@ -120,7 +121,7 @@ def lib():
             fn = getattr(handle, name)
             fn.restype = res
             fn.argtypes = args
-        if handle.vcg_abi_version() != 3:
+        if handle.vcg_abi_version() != 4:
             raise RuntimeError("libvcg.so ABI version mismatch; rebuild it")
         _lib = handle
     return _lib

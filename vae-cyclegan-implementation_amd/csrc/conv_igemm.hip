@@ -1749,8 +1749,18 @@ __global__ __launch_bounds__(256) void k_wino_wgrad_reduce(const float* __restri
 }
 
 // OIHW -> Wf[K][Cout] (pad rows / pad columns are zero)
+// (both Wf pack kernels also leave the pack's header: the bit pattern of the kernel's largest magnitude — p.amax_b, measured by the
+// k_absmax launch at the head of vcg_pack_weight — where the kernels that multiply by the pack's planes read it.  Round 3: this was
+// a launch of its own, 44 per step)
+__device__ __forceinline__ void pack_header(const ConvP& p, uint32_t* hdr) {
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 64) {       // wave 0, all lanes: vcg_amax_bits is a wave-wide maximum
+    const uint32_t b = vcg_amax_bits(p.amax_b);
+    if (threadIdx.x == 0) *hdr = b;
+  }
+}
 __global__ void k_pack_weight(const float* __restrict__ w, float* __restrict__ wf, ConvP p, int cin_log,
-                              int cout_log) {
+                              int cout_log, uint32_t* hdr) {
+  pack_header(p, hdr);
   const size_t total = (size_t)p.K * p.Cout;
   for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
        idx += (size_t)gridDim.x * blockDim.x) {
@@ -1776,8 +1786,9 @@ __global__ void k_pack_weight(const float* __restrict__ w, float* __restrict__ w
 // the Wf rows it writes are 128-B segments (co fastest).  The one-thread-per-element kernel reads OIHW at a stride of
 // Cin*KH*KW floats: 0.7 TB/s.  Dynamic LDS: T*8*33 floats.
 __global__ __launch_bounds__(256) void k_pack_weight_t(const float* __restrict__ w, float* __restrict__ wf, ConvP p,
-                                                       int cin_log, int cout_log) {
+                                                       int cin_log, int cout_log, uint32_t* hdr) {
   extern __shared__ __attribute__((aligned(16))) float tile[];
+  pack_header(p, hdr);
   const int U2 = p.ups * p.ups, KK = p.KH * p.KW, T = KK * U2;
   const int co0 = blockIdx.x * 32, c0 = blockIdx.y * 8;
   const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -2126,10 +2137,6 @@ static size_t wfd_offset(const ConvGeom& g) { return wft_offset(g) + (wft_wanted
 // the pack was scaled by: vcg_common.h), read by the kernels that multiply by those planes
 static size_t wamax_offset(const ConvGeom& g) { return wfd_offset(g) + (wfd_wanted(g) ? wfd_floats(g) : 0); }
 const void* vcg_pack_amax(const ConvGeom& g, const float* wf) { return wf + wamax_offset(g); }
-__global__ void k_amax_store(VcgAmax a, uint32_t* dst) {
-  const uint32_t b = vcg_amax_bits(a);
-  if (threadIdx.x == 0) *dst = b;
-}
 // VCG_SLAB=0 keeps the slab kernels (conv_slab.hip) out of the dispatch: A/B measurements only
 static bool slab_enabled() {
   static const int on = [] { const char* e = getenv("VCG_SLAB"); return e ? atoi(e) : 1; }();
@@ -2184,8 +2191,7 @@ extern "C" int vcg_pack_weight(const float* w_oihw, float* wf, const int32_t* cd
   // bits for the kernels that consume the planes
   const VcgAmaxOut aw = vcg_amax_new((hipStream_t)stream);
   if (vcg_absmax_launch(w_oihw, (size_t)g.cout_log * g.cin_log * g.ups * g.ups * g.KH * g.KW, aw, (hipStream_t)stream)) return -2;
-  const VcgAmax amax_w = vcg_amax_in(aw);
-  hipLaunchKernelGGL(k_amax_store, dim3(1), dim3(64), 0, (hipStream_t)stream, amax_w, (uint32_t*)(wf + wamax_offset(g)));
+  const VcgAmax amax_w = vcg_amax_in(aw);                  // the header word is written by the Wf pack kernel at the end of this call
   if (vcg_thin_fold_ok(g) && vcg_thin_fold_pack(g, w_oihw, wf + wf_floats(g), amax_w, (hipStream_t)stream)) return -2;
   if (vcg_thin_fold_dgrad_ok(g) && vcg_thin_fold_dgrad_pack(g, w_oihw, wf + wkd_offset(g), amax_w, (hipStream_t)stream)) return -2;
   if (wft_wanted(g)) {
@@ -2209,15 +2215,17 @@ extern "C" int vcg_pack_weight(const float* w_oihw, float* wf, const int32_t* cd
   if (wino_takes_fwd(g) && vcg_wino_weight(g, w_oihw, wf + wf_floats(g), amax_w, (hipStream_t)stream)) return -2;
   if (wino_takes_dgrad(g) && vcg_wino_weight_dgrad(g, w_oihw, wf + wf_floats(g) + wino_u_floats(g), amax_w, (hipStream_t)stream)) return -2;
   ConvP p; fill_params(g, p);
+  p.amax_b = amax_w;
+  uint32_t* const hdr = (uint32_t*)(wf + wamax_offset(g));
   size_t total = (size_t)g.K * g.Cout;
   const int T = g.KH * g.KW * g.ups * g.ups;
   const size_t lds = (size_t)T * 8 * 33 * sizeof(float);
   if (total < (1u << 20) || lds > 64 * 1024) {
     int blocks = (int)((total + 255) / 256); if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(k_pack_weight, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w_oihw, wf, p, g.cin_log, g.cout_log);
+    hipLaunchKernelGGL(k_pack_weight, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w_oihw, wf, p, g.cin_log, g.cout_log, hdr);
   } else {
     hipLaunchKernelGGL(k_pack_weight_t, dim3((g.Cout + 31) / 32, (g.Cin + 7) / 8), dim3(256), lds, (hipStream_t)stream,
-                       w_oihw, wf, p, g.cin_log, g.cout_log);
+                       w_oihw, wf, p, g.cin_log, g.cout_log, hdr);
   }
   VCG_LAUNCH_CHECK("vcg_pack_weight");
   return 0;

@@ -161,6 +161,12 @@ uint64_t vcg_take_hint_dy() { const uint64_t h = t_hint_dy; t_hint_dy = 0; retur
 void vcg_set_last_amax(uint64_t h) { t_last_amax = h; }
 extern "C" void vcg_amax_hint(uint64_t x_amax, uint64_t dy_amax) { t_hint_x = x_amax; t_hint_dy = dy_amax; }
 extern "C" uint64_t vcg_amax_last(void) { const uint64_t h = t_last_amax; t_last_amax = 0; return h; }
+extern "C" uint64_t vcg_amax_measure(const float* t, size_t n, void* stream) {
+  if (!t || n == 0 || ((uintptr_t)t & 15)) return 0;
+  const VcgAmaxOut o = vcg_amax_new((hipStream_t)stream);
+  if (!o.slot || vcg_absmax_launch(t, n, o, (hipStream_t)stream)) return 0;
+  return vcg_amax_handle(o);
+}
 int vcg_operand_amax(const float* t, size_t n, uint64_t handle, int shift, hipStream_t st, VcgAmax* out) {
   if ((handle >> 56) == VCG_HANDLE_MAGIC) {
     int dev = 0;

@@ -297,6 +297,16 @@ def repack_async(params):
 # (include/vcg.h, vcg_amax_hint).  VCG_AMAX_HANDLES=0: every convolution measures its operands itself (A/B measurements).
 AMAX_HANDLES = os.environ.get("VCG_AMAX_HANDLES", "1") != "0"
 
+def _measured_amax(t):
+    """Handle of the largest magnitude of a tensor no kernel published one for (an image, a latent, the gradient a loss hands
+    down): measured ONCE on the current stream — the forward and the weight gradient that re-reads x, the weight and the data
+    gradient of one dy, two convolutions of one input all take the handle instead of a pass each (round 3: 128 -> ~75 k_absmax
+    launches per step).  0 (the consumers measure) when handles are off."""
+    if not AMAX_HANDLES:
+        return 0
+    return int(_native.lib().vcg_amax_measure(_ptr(t), t.numel(), _stream()))
+
+
 # Keep the forward's Winograd-transformed input for the weight gradient (VCG_KEEP_FORWARD_STATE=0: recompute it, as round 1 did)
 KEEP_FORWARD_STATE = os.environ.get("VCG_KEEP_FORWARD_STATE", "1") != "0"
 
@@ -374,6 +384,12 @@ class _ConvBlockFn(torch.autograd.Function):
         # operand magnitudes (include/vcg.h): the block that wrote x left a handle to its largest magnitude on the tensor; the
         # kernels scale x by it instead of measuring x again (0: unknown, they measure)
         x_amax = int(getattr(x, "_vcg_amax", 0)) if AMAX_HANDLES else 0
+        if not x_amax and AMAX_HANDLES:
+            x_amax = _measured_amax(xp)
+            try:
+                x._vcg_amax = x_amax          # a second convolution of this very tensor object (mu and logvar read one map)
+            except AttributeError:
+                pass
         out_amax = 0
         # forward state the weight gradient can reuse (the Winograd-transformed input V: 4x the activation — HBM is 288 GB)
         # (grad mode is off inside Function.forward: needs_input_grad[1] says whether a backward for the weight will come)
@@ -449,6 +465,8 @@ class _ConvBlockFn(torch.autograd.Function):
         else:
             dt = gp
             dt_amax = 0
+        if not dt_amax and AMAX_HANDLES:
+            dt_amax = _measured_amax(dt)      # on this stream, before the weight gradient forks off: both gradients take it
         wparam, bparam = ctx.wparam, ctx.bparam
         saved = ctx.saved_state
         if wparam is not None and wparam.requires_grad and id(wparam) not in _NO_WGRAD:
