@@ -40,6 +40,9 @@ def main():
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--layers", default="d1,d2,d3,d4,r,u1,u2,u3,u4")
+    ap.add_argument("--fwd-only", action="store_true",
+                    help="forward passes only: the layer's packed weights then stay in the 256 MB Infinity Cache between repetitions "
+                         "(a forward + backward repetition touches more than that), i.e. what a prefetch of the weights would buy")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     for name in args.layers.split(","):
@@ -54,6 +57,10 @@ def main():
         ops.PROFILE = []
         for _ in range(args.reps):
             x.grad = None
+            if args.fwd_only:
+                with torch.no_grad():
+                    y = ops.conv_block(x, w, b, spec)
+                continue
             y = ops.conv_block(x, w, b, spec)
             y.backward(g)
         torch.cuda.synchronize()

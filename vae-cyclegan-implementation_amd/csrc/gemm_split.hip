@@ -246,6 +246,7 @@ constexpr int GD_STAGES = 3;
 // with the eight 16-byte slots XOR-swizzled by (row >> 1) & 7: a ds_read_b128 fragment read (lane = row, one logical slot) then
 // touches 16 different bank groups per 16-lane group, and one DMA wave-instruction moves 8 rows x 128 B = eight FULL cache lines
 // (the [piece][row][64 B] images of k_gemm_split fetch every line twice, half a line per instruction).
+template <bool GD_SPREAD>
 __global__ __launch_bounds__(512, 1) void k_gemm_planes_dma(GemmSplitP p) {
   constexpr int MI = 2, NI = 2;
   __shared__ __attribute__((aligned(1024))) unsigned char smem[GD_STAGES * GD_STAGE];
@@ -290,15 +291,16 @@ __global__ __launch_bounds__(512, 1) void k_gemm_planes_dma(GemmSplitP p) {
     boff[h] = (uint32_t)((size_t)(n0 + rl) * KB * VCG_PBYTES + ((dslot ^ ((rl >> 1) & 7)) << 4));      // N % 128 == 0: in range
   }
   const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
-  auto issue = [&](int stage, int kt) {
+  // DMA number q (0..5) of a stage: four A pieces, two B pieces
+  auto issue_one = [&](int stage, int kt, int q) {
     const uint32_t sbase = __builtin_amdgcn_readfirstlane(lds0 + (uint32_t)stage * GD_STAGE);
     const uint32_t ko = (uint32_t)kt * VCG_PBYTES;
+    if (q < 4) gd_dma16(ra, __builtin_amdgcn_readfirstlane(sbase + (uint32_t)((wid + 8 * q) * 1024)), aoff[q] != GS_OOB ? aoff[q] + ko : GS_OOB);
+    else gd_dma16(rb, __builtin_amdgcn_readfirstlane(sbase + (uint32_t)(GD_A_BYTES + (wid + 8 * (q - 4)) * 1024)), boff[q - 4] + ko);
+  };
+  auto issue = [&](int stage, int kt) {
 #pragma unroll
-    for (int h = 0; h < 4; ++h)
-      gd_dma16(ra, __builtin_amdgcn_readfirstlane(sbase + (uint32_t)((wid + 8 * h) * 1024)), aoff[h] != GS_OOB ? aoff[h] + ko : GS_OOB);
-#pragma unroll
-    for (int h = 0; h < 2; ++h)
-      gd_dma16(rb, __builtin_amdgcn_readfirstlane(sbase + (uint32_t)(GD_A_BYTES + (wid + 8 * h) * 1024)), boff[h] + ko);
+    for (int q = 0; q < 6; ++q) issue_one(stage, kt, q);
   };
 
   f32x16 acc[MI][NI], lo[MI][NI];
@@ -322,8 +324,14 @@ __global__ __launch_bounds__(512, 1) void k_gemm_planes_dma(GemmSplitP p) {
     if (kt + 1 < nkt) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");      // my six DMAs of stage kt have landed; stage kt + 1's stay in flight
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     gd_barrier();                                                           // everybody's have; everybody is done with stage kt - 1
-    if (kt + 2 < nkt) issue((kt + 2) % GD_STAGES, kt + 2);
+    // The six DMAs of stage kt + 2 are issued ONE AT A TIME between the MFMA groups of this step, not in a burst behind the
+    // barrier: an LDS-DMA costs the issuing wave 60-185 cycles (MI355X_MICROARCH.md), and the two waves of a SIMD leave the
+    // barrier together — in a burst both stall on their DMAs at once and the matrix pipe idles; spread out, one wave's DMA sits
+    // beside its partner's MFMAs.
+    const bool more = kt + 2 < nkt;
+    const int nstage = (kt + 2) % GD_STAGES;
     const unsigned char* st = smem + (kt % GD_STAGES) * GD_STAGE;
+    int q = 0;
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       f16x8 a[VCG_NP][MI], b[VCG_NP][NI];
@@ -345,8 +353,15 @@ __global__ __launch_bounds__(512, 1) void k_gemm_planes_dma(GemmSplitP p) {
           c = VCG_MFMA(a[0][i], b[1][j], c);
           lo[i][j] = c;
           acc[i][j] = VCG_MFMA(a[0][i], b[0][j], acc[i][j]);
+          if (GD_SPREAD && q < 6 && !(s == 1 && i == 1 && j == 1)) {          // after 7 of the 8 groups: 6 DMAs + one spare slot
+            __builtin_amdgcn_sched_barrier(0);
+            if (more) issue_one(nstage, kt + 2, q);
+            __builtin_amdgcn_sched_barrier(0);
+            ++q;
+          }
         }
     }
+    if (!GD_SPREAD && more) issue(nstage, kt + 2);
   }
   float* const dst = p.c + (size_t)zb * p.c_bstride;
   const float os = sa_ * sb_;
@@ -412,7 +427,10 @@ int vcg_gemm_planes_batched(const void* APlanes, const void* BtPlanes, float* C,
   if (bn == 128 && rows >= 256 && gemm_dma_on()) {
     dim3 grid((rows + GD_BM - 1) / GD_BM, N / GD_BN, batches);
     VcgProfScope prof("k_gemm_planes_dma", 2.0 * rows * (double)K * N * batches, st);
-    hipLaunchKernelGGL(k_gemm_planes_dma, grid, dim3(512), 0, st, p);
+    // VCG_GEMM_SPREAD=0: the DMAs of a stage in one burst behind the barrier (A/B measurements)
+    static const int spread = [] { const char* e = getenv("VCG_GEMM_SPREAD"); return e ? atoi(e) : 1; }();
+    if (spread) hipLaunchKernelGGL(k_gemm_planes_dma<true>, grid, dim3(512), 0, st, p);
+    else hipLaunchKernelGGL(k_gemm_planes_dma<false>, grid, dim3(512), 0, st, p);
     VCG_LAUNCH_CHECK("vcg_gemm_planes_batched(dma)");
     return 0;
   }
