@@ -246,7 +246,22 @@ constexpr int GD_STAGES = 3;
 // with the eight 16-byte slots XOR-swizzled by (row >> 1) & 7: a ds_read_b128 fragment read (lane = row, one logical slot) then
 // touches 16 different bank groups per 16-lane group, and one DMA wave-instruction moves 8 rows x 128 B = eight FULL cache lines
 // (the [piece][row][64 B] images of k_gemm_split fetch every line twice, half a line per instruction).
-template <bool GD_SPREAD>
+// Diagnostic build only (tools/gemm_dma_probe.hip, -DVCG_GD_STAMP; libvcg.so never has it): per-wave shader-clock totals of the
+// K loop's phases, into a buffer of their own ([workgroup][wave][8] u64)
+#ifdef VCG_GD_STAMP
+__device__ unsigned long long* g_gd_stamp = nullptr;
+int vcg_gd_set_stamp(void* buf) { return hipMemcpyToSymbol(HIP_SYMBOL(g_gd_stamp), &buf, sizeof(buf)) == hipSuccess ? 0 : -1; }
+#define GD_T() (__builtin_amdgcn_sched_barrier(0), __builtin_amdgcn_s_memtime())
+#define GD_ACC(slot, t0) do { const unsigned long long t1__ = GD_T(); gd_acc[slot] += t1__ - (t0); (t0) = t1__; } while (0)
+#else
+#define GD_T() 0ull
+#define GD_ACC(slot, t0) do { } while (0)
+#endif
+// SHAPE 32: v_mfma_f32_32x32x16_f16, a wave's 64 x 64 as 2 x 2 tiles x two 16-deep slices; SHAPE 16: v_mfma_f32_16x16x32_f16, 4 x 4
+// tiles x one 32-deep slice — the same fragment bytes, LDS reads, accumulator registers and matrix-pipe cycles, but the chip,
+// which answers an MFMA-dense loop with a lower clock (1.15-1.76 GHz here: profiles/r03_gemm_dma_stamps.txt), holds a higher one on
+// the 16 x 16 shape (MI355X_MICROARCH.md, DVFS item 7)
+template <bool GD_SPREAD, int SHAPE>
 __global__ __launch_bounds__(512, 1) void k_gemm_planes_dma(GemmSplitP p) {
   constexpr int MI = 2, NI = 2;
   __shared__ __attribute__((aligned(1024))) unsigned char smem[GD_STAGES * GD_STAGE];
@@ -304,26 +319,52 @@ __global__ __launch_bounds__(512, 1) void k_gemm_planes_dma(GemmSplitP p) {
   };
 
   f32x16 acc[MI][NI], lo[MI][NI];
+  f32x4 acc16[4][4], lo16[4][4];
+  if constexpr (SHAPE == 32) {
 #pragma unroll
-  for (int i = 0; i < MI; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
-    for (int j = 0; j < NI; ++j)
+      for (int j = 0; j < NI; ++j)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = lo[i][j][e] = 0.f;
+        for (int e = 0; e < 16; ++e) acc[i][j][e] = lo[i][j][e] = 0.f;
+  } else {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc16[i][j][e] = lo16[i][j][e] = 0.f;
+  }
   uint32_t fa[MI], fb[NI];
   int sa[MI], sb[NI];
 #pragma unroll
   for (int i = 0; i < MI; ++i) { const int r = wm * 64 + i * 32 + l31; fa[i] = (uint32_t)(r * VCG_PBYTES); sa[i] = (r >> 1) & 7; }
 #pragma unroll
   for (int j = 0; j < NI; ++j) { const int r = wn * 64 + j * 32 + l31; fb[j] = (uint32_t)(GD_A_BYTES + r * VCG_PBYTES); sb[j] = (r >> 1) & 7; }
+  // SHAPE 16: lane -> (row lane & 15 of a 16-row tile, 8-deep k slot lane >> 4)
+  const int r16 = lane & 15, kq = lane >> 4;
+  uint32_t fa16[4], fb16[4];
+  int sa16[4], sb16[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { const int r = wm * 64 + i * 16 + r16; fa16[i] = (uint32_t)(r * VCG_PBYTES); sa16[i] = (r >> 1) & 7; }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { const int r = wn * 64 + j * 16 + r16; fb16[j] = (uint32_t)(GD_A_BYTES + r * VCG_PBYTES); sb16[j] = (r >> 1) & 7; }
 
   const int nkt = KB;
+#ifdef VCG_GD_STAMP
+  unsigned long long gd_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const unsigned long long gd_start = GD_T(), gd_rt0 = __builtin_amdgcn_s_memrealtime();
+#endif
   issue(0, 0);
   if (nkt > 1) issue(1, 1);
+  unsigned long long gd_t = GD_T();
+  (void)gd_t;
   for (int kt = 0; kt < nkt; ++kt) {
     if (kt + 1 < nkt) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");      // my six DMAs of stage kt have landed; stage kt + 1's stay in flight
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    GD_ACC(0, gd_t);
     gd_barrier();                                                           // everybody's have; everybody is done with stage kt - 1
+    GD_ACC(1, gd_t);
     // The six DMAs of stage kt + 2 are issued ONE AT A TIME between the MFMA groups of this step, not in a burst behind the
     // barrier: an LDS-DMA costs the issuing wave 60-185 cycles (MI355X_MICROARCH.md), and the two waves of a SIMD leave the
     // barrier together — in a burst both stall on their DMAs at once and the matrix pipe idles; spread out, one wave's DMA sits
@@ -332,28 +373,57 @@ __global__ __launch_bounds__(512, 1) void k_gemm_planes_dma(GemmSplitP p) {
     const int nstage = (kt + 2) % GD_STAGES;
     const unsigned char* st = smem + (kt % GD_STAGES) * GD_STAGE;
     int q = 0;
+    if constexpr (SHAPE == 32) {
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      f16x8 a[VCG_NP][MI], b[VCG_NP][NI];
+      for (int s = 0; s < 2; ++s) {
+        f16x8 a[VCG_NP][MI], b[VCG_NP][NI];
+#pragma unroll
+        for (int pc = 0; pc < VCG_NP; ++pc) {
+#pragma unroll
+          for (int i = 0; i < MI; ++i)
+            a[pc][i] = *reinterpret_cast<const f16x8*>(st + fa[i] + (((pc * 4 + 2 * s + lh) ^ sa[i]) << 4));
+#pragma unroll
+          for (int j = 0; j < NI; ++j)
+            b[pc][j] = *reinterpret_cast<const f16x8*>(st + fb[j] + (((pc * 4 + 2 * s + lh) ^ sb[j]) << 4));
+        }
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int j = 0; j < NI; ++j) {
+            f32x16 c = lo[i][j];
+            c = VCG_MFMA(a[1][i], b[0][j], c);
+            c = VCG_MFMA(a[0][i], b[1][j], c);
+            lo[i][j] = c;
+            acc[i][j] = VCG_MFMA(a[0][i], b[0][j], acc[i][j]);
+            if (GD_SPREAD && q < 6 && !(s == 1 && i == 1 && j == 1)) {          // after 7 of the 8 groups: 6 DMAs + one spare slot
+              __builtin_amdgcn_sched_barrier(0);
+              if (more) issue_one(nstage, kt + 2, q);
+              __builtin_amdgcn_sched_barrier(0);
+              ++q;
+            }
+          }
+      }
+    } else {
+      f16x8 a[VCG_NP][4], b[VCG_NP][4];
 #pragma unroll
       for (int pc = 0; pc < VCG_NP; ++pc) {
 #pragma unroll
-        for (int i = 0; i < MI; ++i)
-          a[pc][i] = *reinterpret_cast<const f16x8*>(st + fa[i] + (((pc * 4 + 2 * s + lh) ^ sa[i]) << 4));
+        for (int i = 0; i < 4; ++i)
+          a[pc][i] = *reinterpret_cast<const f16x8*>(st + fa16[i] + (((pc * 4 + kq) ^ sa16[i]) << 4));
 #pragma unroll
-        for (int j = 0; j < NI; ++j)
-          b[pc][j] = *reinterpret_cast<const f16x8*>(st + fb[j] + (((pc * 4 + 2 * s + lh) ^ sb[j]) << 4));
+        for (int j = 0; j < 4; ++j)
+          b[pc][j] = *reinterpret_cast<const f16x8*>(st + fb16[j] + (((pc * 4 + kq) ^ sb16[j]) << 4));
       }
 #pragma unroll
-      for (int i = 0; i < MI; ++i)
+      for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < NI; ++j) {
-          f32x16 c = lo[i][j];
-          c = VCG_MFMA(a[1][i], b[0][j], c);
-          c = VCG_MFMA(a[0][i], b[1][j], c);
-          lo[i][j] = c;
-          acc[i][j] = VCG_MFMA(a[0][i], b[0][j], acc[i][j]);
-          if (GD_SPREAD && q < 6 && !(s == 1 && i == 1 && j == 1)) {          // after 7 of the 8 groups: 6 DMAs + one spare slot
+        for (int j = 0; j < 4; ++j) {
+          f32x4 c = lo16[i][j];
+          c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[1][i], b[0][j], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[0][i], b[1][j], c, 0, 0, 0);
+          lo16[i][j] = c;
+          acc16[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[0][i], b[0][j], acc16[i][j], 0, 0, 0);
+          if (GD_SPREAD && (j & 1) && q < 6) {                                   // after every second group: 8 slots for 6 DMAs
             __builtin_amdgcn_sched_barrier(0);
             if (more) issue_one(nstage, kt + 2, q);
             __builtin_amdgcn_sched_barrier(0);
@@ -362,22 +432,47 @@ __global__ __launch_bounds__(512, 1) void k_gemm_planes_dma(GemmSplitP p) {
         }
     }
     if (!GD_SPREAD && more) issue(nstage, kt + 2);
+    GD_ACC(2, gd_t);
   }
   float* const dst = p.c + (size_t)zb * p.c_bstride;
   const float os = sa_ * sb_;
+  if constexpr (SHAPE == 32) {
 #pragma unroll
-  for (int j = 0; j < NI; ++j) {
-    const int n = n0 + wn * 64 + j * 32 + l31;
-    if (n >= p.N) continue;
+    for (int j = 0; j < NI; ++j) {
+      const int n = n0 + wn * 64 + j * 32 + l31;
+      if (n >= p.N) continue;
 #pragma unroll
-    for (int i = 0; i < MI; ++i)
+      for (int i = 0; i < MI; ++i)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int row = (e & 3) + 8 * (e >> 2) + 4 * lh;
-        const int m = m0 + wm * 64 + i * 32 + row;
-        if (m < p.rows) dst[(size_t)m * p.N + n] = (acc[i][j][e] + lo[i][j][e]) * os;
-      }
+        for (int e = 0; e < 16; ++e) {
+          const int row = (e & 3) + 8 * (e >> 2) + 4 * lh;
+          const int m = m0 + wm * 64 + i * 32 + row;
+          if (m < p.rows) dst[(size_t)m * p.N + n] = (acc[i][j][e] + lo[i][j][e]) * os;
+        }
+    }
+  } else {
+    // 16 x 16 accumulator: lane -> column lane & 15, rows 4 (lane >> 4) + e
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = n0 + wn * 64 + j * 16 + r16;
+      if (n >= p.N) continue;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int m = m0 + wm * 64 + i * 16 + 4 * kq + e;
+          if (m < p.rows) dst[(size_t)m * p.N + n] = (acc16[i][j][e] + lo16[i][j][e]) * os;
+        }
+    }
   }
+#ifdef VCG_GD_STAMP
+  GD_ACC(3, gd_t);
+  if (g_gd_stamp && lane == 0) {
+    unsigned long long* o = g_gd_stamp + ((size_t)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) * 8 + wid) * 8;
+    o[0] = gd_acc[0]; o[1] = gd_acc[1]; o[2] = gd_acc[2]; o[3] = gd_acc[3];
+    o[6] = __builtin_amdgcn_s_memrealtime() - gd_rt0; o[7] = gd_t - gd_start;
+  }
+#endif
 }
 // VCG_GEMM_DMA=0: the register-staged 128 x 128 kernel for every shape (A/B measurements)
 static bool gemm_dma_on() {
@@ -429,8 +524,15 @@ int vcg_gemm_planes_batched(const void* APlanes, const void* BtPlanes, float* C,
     VcgProfScope prof("k_gemm_planes_dma", 2.0 * rows * (double)K * N * batches, st);
     // VCG_GEMM_SPREAD=0: the DMAs of a stage in one burst behind the barrier (A/B measurements)
     static const int spread = [] { const char* e = getenv("VCG_GEMM_SPREAD"); return e ? atoi(e) : 1; }();
-    if (spread) hipLaunchKernelGGL(k_gemm_planes_dma<true>, grid, dim3(512), 0, st, p);
-    else hipLaunchKernelGGL(k_gemm_planes_dma<false>, grid, dim3(512), 0, st, p);
+    // VCG_GEMM_SHAPE=32: v_mfma_f32_32x32x16_f16 tiles (A/B measurements)
+    static const int shape = [] { const char* e = getenv("VCG_GEMM_SHAPE"); return e ? atoi(e) : 16; }();
+    if (shape == 16) {
+      if (spread) hipLaunchKernelGGL((k_gemm_planes_dma<true, 16>), grid, dim3(512), 0, st, p);
+      else hipLaunchKernelGGL((k_gemm_planes_dma<false, 16>), grid, dim3(512), 0, st, p);
+    } else {
+      if (spread) hipLaunchKernelGGL((k_gemm_planes_dma<true, 32>), grid, dim3(512), 0, st, p);
+      else hipLaunchKernelGGL((k_gemm_planes_dma<false, 32>), grid, dim3(512), 0, st, p);
+    }
     VCG_LAUNCH_CHECK("vcg_gemm_planes_batched(dma)");
     return 0;
   }
