@@ -4,7 +4,7 @@ Class names, constructor signatures, attribute names, `forward` return order, me
 and state_dict keys/shapes follow the reference (file:line cited per class) so a
 reference checkpoint loads and `train.py` drives these classes unchanged.  Underneath,
 every block is a fused HIP launch sequence (`ops.conv_block`): implicit-GEMM / Winograd conv on the
-bf16 matrix pipe with split fp32 operands (fp32-level rounding) and a bias/activation epilogue,
+16-bit matrix pipe with split fp32 operands (two fp16 pieces, fp32-level rounding) and a bias/activation epilogue,
 two-stage InstanceNorm statistics, and a normalise(+activation)(+residual)(+PixelShuffle) store.  torch modules (`nn.Conv2d`,
 `spectral_norm`) are used only as parameter containers — their forwards are never run.
 

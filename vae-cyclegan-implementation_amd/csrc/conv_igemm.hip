@@ -453,10 +453,10 @@ __device__ __forceinline__ SplitScales split_scales(const ConvP& p) {
   return r;
 }
 
-// The forward implicit GEMM on the bf16 matrix pipe with split operands (gemm_split.hip explains the arithmetic: three
-// bf16 pieces per fp32 value, six MFMA products, fp32 accumulation — fp32-level rounding at 2.7x less matrix-pipe
-// time).  Same gather as k_conv_fwd; B comes from the transposed pack WfT[Cout][K] so that both operands are staged as
-// k-contiguous quads, split, and written to the swizzled [row][32 bf16] images that ds_read_b128 feeds to the MFMA.
+// The forward implicit GEMM on the 16-bit matrix pipe with split operands (vcg_common.h / gemm_split.hip explain the arithmetic:
+// two fp16 pieces of x / s per fp32 value, three MFMA products, fp32 accumulation — fp32-level rounding).  Same gather as
+// k_conv_fwd; B comes from the transposed pack WfT[Cout][K] so that both operands are staged as k-contiguous quads: A scaled,
+// split and written to the swizzled [row][32 fp16] images that ds_read_b128 feeds to the MFMA, B copied from its planes.
 template <int BN>
 __global__ __launch_bounds__(256, 2) void k_conv_fwd_split(ConvP p) {
   VCG_STAMP_AT(0);
@@ -522,7 +522,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_fwd_split(ConvP p) {
   // Cin/32 K-steps), so a steady-state K-step costs one add per row instead of the reflect arithmetic
   uint32_t rowoff[AR];
   int tap_cur = -1;
-  // weight tile from the WfT PLANES (the transposed pack, split into bf16 pieces when it was packed: [Cout][K/32][3][32],
+  // weight tile from the WfT PLANES (the transposed pack, split into fp16 pieces when it was packed: [Cout][K/32][2][32],
   // K zero-padded to 32): thread (row b_r = tid >> 2, 16-byte chunk b_q = tid & 3 of a 64-byte piece row); pass j =
   // (64-row half, piece).  Rows past Cout fall off the end of the buffer and read as zeros.
   constexpr int BP = VCG_NP * BN / 64;
@@ -885,7 +885,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_dgrad(ConvP p) {
   VCG_STAMP_AT(3);
 }
 
-// The data gradient on the split-operand bf16 path (see k_conv_fwd_split / gemm_split.hip).  Same gather as
+// The data gradient on the split-operand path (see k_conv_fwd_split / gemm_split.hip).  Same gather as
 // k_conv_dgrad — including the fold of the reflect halo, summed in fp32 BEFORE the split — and the same weight rows
 // (Wf viewed as [tap][J][co] is already k-contiguous per output column J).
 template <int BN, int WN, bool BPL = (BN >= 64)>
@@ -1317,15 +1317,15 @@ __global__ __launch_bounds__(NT) void k_conv_wgrad(ConvP p) {
   VCG_STAMP_AT(3);
 }
 
-// The weight gradient on the split-operand bf16 path.  Here the reduction index (the pixel) is the SLOW index of both
+// The weight gradient on the split-operand path.  Here the reduction index (the pixel) is the SLOW index of both
 // operands — x and dy are [pixel][channel] — while the MFMA wants 8 consecutive reduction indices per lane.  The
-// tiles are therefore staged as they come, [32 pixels][128 channels] bf16 per piece (256-byte rows, 16-byte chunks
+// tiles are therefore staged as they come, [32 pixels][128 channels] fp16 per piece (256-byte rows, 16-byte chunks
 // XOR-swizzled by ((row & 3) << 2) | ((row >> 2) & 3)), and read with gfx950's transposing LDS read
 // ds_read_b64_tr_b16: per 16-lane group it takes a 4-row x 16-column block and hands each lane one column's four
 // rows — two such reads give a lane its 8 reduction indices.  Everything else (stream-K segments, gather, slabs) is
 // k_conv_wgrad's.
 template <int COLS>
-__device__ __forceinline__ uint32_t tr_off(int row, int col) {       // byte offset of element (row, col) in a [rows][COLS] bf16 image
+__device__ __forceinline__ uint32_t tr_off(int row, int col) {       // byte offset of element (row, col) in a [rows][COLS] fp16 image
   const int f = (((row & 3) << 2) | ((row >> 2) & 3)) & (COLS / 8 - 1);
   return (uint32_t)(2 * COLS * row + 16 * ((col >> 3) ^ f) + (col & 7) * 2);
 }
@@ -2445,7 +2445,7 @@ extern "C" int vcg_conv_dgrad(const float* dy, const float* wf, float* dx, const
     const bool planes = bm == 128 && bn >= 64 && wfd_wanted(g);       // weight rows from the pre-split WFD planes of the pack
     if (planes) { p.b = wf + wfd_offset(g); p.b_bytes = (uint32_t)(wfd_floats(g) * 4); }
     // layers without planes (the 4-channel dy of the 7x7 head: K = (tap, co) is not a multiple of 32 per tap) still run on the
-    // bf16 pipe when their tile is 128 x 64: the weight rows are split in the kernel from Wf
+    // 16-bit pipe when their tile is 128 x 64: the weight rows are split in the kernel from Wf
     const bool nopl64 = !planes && bm == 128 && bn == 64 && g.Cout % 4 == 0;
     const bool split = planes || bn == 32 || nopl64;
     if (split) {                                            // fp16 x 2 kernels: the operands' largest magnitudes (vcg_common.h)
@@ -2457,7 +2457,7 @@ extern "C" int vcg_conv_dgrad(const float* dy, const float* wf, float* dx, const
     VcgProfScope prof(!split ? "k_conv_dgrad<fp32 MFMA>" : bn == 128 ? "k_conv_dgrad_split<128, 2>" : bn == 64 ? "k_conv_dgrad_split<64, 2>"
                                                                                                              : "k_conv_dgrad_split<32, 1>",
                       gemm_flops, st);
-    if (planes) {                                           // split-operand bf16 kernel
+    if (planes) {                                           // split-operand kernel
       if (bn == 128) hipLaunchKernelGGL((k_conv_dgrad_split<128, 2>), grid, dim3(256), 0, st, p);
       else hipLaunchKernelGGL((k_conv_dgrad_split<64, 2>), grid, dim3(256), 0, st, p);
     } else if (bn == 32) hipLaunchKernelGGL((k_conv_dgrad_split<32, 1>), grid, dim3(256), 0, st, p);
@@ -2574,7 +2574,7 @@ int vcg_wino_wgrad_core(const ConvGeom& g, const float* V, const float* dM, int 
   {
     VcgProfScope prof(wp.bm == 128 ? (wp.bn == 128 ? "k_conv_wgrad_split<128>" : "k_conv_wgrad_split<64>") : "k_conv_wgrad<fp32 MFMA>",
                       2.0 * 16 * (double)T * q.K * q.Cout, st);
-    if (wp.bm == 128 && wp.bn == 128) hipLaunchKernelGGL(k_conv_wgrad_split<128>, grid, dim3(256), 0, st, p);        // split-operand bf16
+    if (wp.bm == 128 && wp.bn == 128) hipLaunchKernelGGL(k_conv_wgrad_split<128>, grid, dim3(256), 0, st, p);        // split-operand
     else if (wp.bm == 128 && wp.bn == 64) hipLaunchKernelGGL(k_conv_wgrad_split<64>, grid, dim3(256), 0, st, p);
     else if (wp.bm == 64 && wp.bn == 128) hipLaunchKernelGGL((k_conv_wgrad<64, 128>), grid, dim3(256), 0, st, p);
     else hipLaunchKernelGGL((k_conv_wgrad<64, 64>), grid, dim3(256), 0, st, p);
@@ -2699,7 +2699,7 @@ extern "C" int vcg_conv_wgrad_saved(const float* x, const float* dy, float* gw_o
     VcgProfScope prof(bm == 128 ? (bn == 128 ? "k_conv_wgrad_split<128>" : "k_conv_wgrad_split<64>") : "k_conv_wgrad<fp32 MFMA>",
                       2.0 * g.M * (double)g.K * g.Cout, st);
     if (bm == 256) hipLaunchKernelGGL((k_conv_wgrad<256, 128, 512>), grid, dim3(512), 0, st, p);
-    else if (bm == 128 && bn == 128) hipLaunchKernelGGL(k_conv_wgrad_split<128>, grid, dim3(256), 0, st, p);     // split-operand bf16
+    else if (bm == 128 && bn == 128) hipLaunchKernelGGL(k_conv_wgrad_split<128>, grid, dim3(256), 0, st, p);     // split-operand
     else if (bm == 128 && bn == 64) hipLaunchKernelGGL(k_conv_wgrad_split<64>, grid, dim3(256), 0, st, p);
     else if (bm == 64 && bn == 128) hipLaunchKernelGGL((k_conv_wgrad<64, 128>), grid, dim3(256), 0, st, p);
     else hipLaunchKernelGGL((k_conv_wgrad<64, 64>), grid, dim3(256), 0, st, p);

@@ -1,5 +1,5 @@
 // Weight gradients of the layers whose 64-column implicit-GEMM tiles starve (U4: 32 -> 64 at 256^2; the 7x7 head 64 -> 3
-// and stem 3 -> 64): k_conv_wgrad_split<64> ran them at 13-14 % of the bf16 pipe, the im2col operand being gathered, split
+// and stem 3 -> 64): k_conv_wgrad_split<64> ran them at 13-14 % of the (then bf16 x 3) pipe, the im2col operand being gathered, split
 // and stored once per tap (and, for the 4-channel tensors, through the adjoint-of-padding gather per element).
 //
 // Here the reduction walks the image row by row.  A workgroup owns a 32-pixel column segment of a band of rows; per row it
@@ -8,7 +8,7 @@
 //   * the "ring" operand — the one the taps shift — into a ring of KH + 1 row slots, where it stays for KH steps:
 //       U mode  (3x3, 32 channels per group):  [34 px][32 ch]; tap (kh, kw) = slot kh, pixel offset kw;
 //       T mode  (7x7, a 4-channel tensor):     [39 px][4 ch] — the 32 columns of a tap row kh are (j = 0..7, c = 0..3),
-//               i.e. 32 CONTIGUOUS bf16 starting at pixel px + j: the Toeplitz matrix the kw-folded GEMM needs never
+//               i.e. 32 CONTIGUOUS 16-bit values starting at pixel px + j: the Toeplitz matrix the kw-folded GEMM needs never
 //               exists, a lane of ds_read_b64_tr_b16 simply addresses pixel (row + q + j).
 // The MFMA's reduction index is the pixel, which is the slow index of both images: fragments come out through the
 // transposing LDS read, as in k_conv_wgrad_split.  Four waves: wave w owns wide column block w & 1 and the upper or lower
@@ -46,7 +46,7 @@ __device__ __forceinline__ float4 rg_load4(__amdgpu_buffer_rsrc_t r, uint32_t of
   const rg_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0);
   return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
 }
-// byte offset of element (row, col) in a [rows][64] bf16 image (128-byte rows, 16-byte chunks XOR-swizzled: conv_igemm.hip tr_off<64>)
+// byte offset of element (row, col) in a [rows][64] fp16 image (128-byte rows, 16-byte chunks XOR-swizzled: conv_igemm.hip tr_off<64>)
 __device__ __forceinline__ uint32_t rg_woff(int row, int col) {
   const int f = (((row & 3) << 2) | ((row >> 2) & 3)) & 7;
   return (uint32_t)(128 * row + 16 * ((col >> 3) ^ f) + (col & 7) * 2);

@@ -1,11 +1,11 @@
 // 3x3 / stride-1 convolutions of the high-resolution, few-channel layers (U3, U4 of the decoders: 128^2 and 256^2 maps,
-// 32..128 channels) on the split-operand bf16 pipe, with the input staged ONCE per workgroup as an LDS slab.
+// 32..128 channels) on the split-operand 16-bit pipe, with the input staged ONCE per workgroup as an LDS slab.
 //
-// Why: the implicit-GEMM kernels (conv_igemm.hip) gather, split (fp32 -> three bf16 pieces) and store the im2col tile of
+// Why: the implicit-GEMM kernels (conv_igemm.hip) gather, split (fp32 -> two fp16 pieces; rounds 1-2: three bf16 ones) and store the im2col tile of
 // every tap — each input value nine times — and with <= 64 output columns that staging outweighs the MFMAs: the
 // 64-column tiles ran their matrix pipe 17-23 % busy (profiles/r01_pmc_mfma_util.txt).  Here a workgroup owns a PR x 16
 // block of output pixels and, per 32-channel chunk, loads the (PR + 2) x 18 input pixels under it once: 180 (or 324)
-// 16-byte gathers, splits and LDS stores instead of 9 x 128 (256).  The image has the same [row][32 bf16] swizzled
+// 16-byte gathers, splits and LDS stores instead of 9 x 128 (256).  The image has the same [row][32 fp16] swizzled
 // layout as the GEMM kernels' A tile with "row" = slab pixel, so a tap is nothing but a row offset (kh * 18 + kw) in the
 // fragment address.  The weight tile of a (chunk, tap) — BN rows x 32 k, pre-split planes from the pack — is copied
 // global -> registers -> LDS under the previous tap's MFMAs, one barrier per tap.

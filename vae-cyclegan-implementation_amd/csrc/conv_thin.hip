@@ -145,7 +145,7 @@ size_t vcg_thin_dgrad_workspace(const ConvGeom& g) {
 // useful work for 7 x 7 x 3 instead of 9 % — run by the forward implicit-GEMM kernel on its 128 x 32 tile; the
 // second is a 17-float gather per output pixel.  4x faster than the VALU kernel above on the 64 -> 3 decoder head.
 int vcg_fwd_launch(const ConvGeom& g, const float* x, const float* wf, float* y, hipStream_t st);
-// conv_slab.hip: the same (KH x 1) convolution on the split-operand bf16 pipe, the input rows staged once per workgroup
+// conv_slab.hip: the same (KH x 1) convolution on the split-operand 16-bit pipe, the input rows staged once per workgroup
 bool vcg_slab_col_ok(int KH, int C);
 int vcg_slab_col(const float* x, const void* planes, size_t planes_bytes, const void* w_amax, float* P, int N, int H, int W, int C, int Ho, int Wo,
                  int KH, int pad, int reflect, hipStream_t st, uint64_t x_handle);

@@ -3,7 +3,7 @@
 //
 //   V[xi][t][k]  = (B^T d B)[xi]       input transform of the 4x4 patch of output tile t (2x2 outputs), k = (i, j, c)
 //   U[xi][co][k] = (G g G^T)[xi]       weight transform, once per optimizer step (vcg_pack_weight)
-//   M[xi][t][co] = sum_k V U           16 independent GEMMs: one launch of the split-operand bf16 GEMM (gemm_split.hip)
+//   M[xi][t][co] = sum_k V U           16 independent GEMMs: one launch of the split-operand GEMM (gemm_split.hip)
 //   y            = A^T M A + bias, activation
 //
 // Padding (reflect or zero) and the folded PixelUnshuffle of the D blocks live in the input transform's gather, so
@@ -316,7 +316,7 @@ __global__ __launch_bounds__(256) void k_wino_out_stats(WinoP p, double* __restr
 }
 
 // The transformed kernels (G g G^T)[xi], G = [[1, 0, 0], [.5, .5, .5], [.5, -.5, .5], [0, 0, 1]], written as the B^T operand of
-// the batched GEMM, already split into bf16 "blocked planes" (gemm_split.hip): for GEMM row n and reduction index kk,
+// the batched GEMM, already split into fp16 "blocked planes" (gemm_split.hip): for GEMM row n and reduction index kk,
 //     up[((xi * NR + n) * KD/32 + kk/32) * VCG_PBLK + piece * 32 + kk % 32]      (fp16 pieces of the value / s, s from the kernel's amax)
 // DGRAD = false: the forward GEMM M = V . U^T — n = co (NR = Cout), kk = k = (phase, c) (KD = Kc);
 // DGRAD = true:  the data-gradient GEMM over the padded domain — n = k (NR = Kc), kk = co (KD = Cout), kernel flipped:
