@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define VCG_ABI_VERSION 4   /* 4: vcg_amax_measure.  3 (round 3): packed weights and kept forward state carry fp16 x 2 planes + amax
+#define VCG_ABI_VERSION 5   /* 5: vcg_conv_reads_wf, cd[VCG_CD_PACK_FLAGS].  4: vcg_amax_measure.  3 (round 3): packed weights and kept forward state carry fp16 x 2 planes + amax
                                words (sizes changed); vcg_amax_hint / vcg_amax_last.  round 2: vcg_adam_step takes 1 - beta; vcg_conv_fwd_in,
                                vcg_conv_wgrad_saved, input transforms, profiling */
 
@@ -66,6 +66,7 @@ enum {
   VCG_CD_ACT = 11,   /* epilogue activation: VCG_ACT_* */
   VCG_CD_CIN_LOGICAL = 12, /* channels of the physical input that carry data (3 for images) */
   VCG_CD_COUT_LOGICAL = 13,
+  VCG_CD_PACK_FLAGS = 14,  /* vcg_pack_weight only: bit 0 = leave the fp32 Wf block out (vcg_conv_reads_wf); 0 everywhere else */
   VCG_CD_LEN = 16
 };
 
@@ -93,17 +94,24 @@ int vcg_fill(float* dst, float value, size_t n, void* stream);
      Wf[K][Cout]          K ordered (kh,kw,i,j,c), so PixelUnshuffle (Networks.py:86) needs no data movement;
                           the B operand of the data-gradient and weight-gradient GEMMs
      U, Ud[16][..]        3x3 / stride-1 layers: the Winograd F(2x2,3x3) transforms G g G^T of the kernel (forward,
-                          [xi][Cout][K]) and of the flipped kernel (data gradient, [xi][K][Cout]), ALREADY SPLIT into the
-                          three bf16 pieces the GEMMs multiply with ("blocked planes": 192 bytes per row and 32-wide block)
+                          [xi][Cout][K]) and of the flipped kernel (data gradient, [xi][K][Cout]), ALREADY SCALED AND SPLIT into
+                          the two fp16 pieces the GEMMs multiply with ("blocked planes": 128 bytes per row and 32-wide block)
      Wk, Wkd              7x7 layers with <= 4 channels on one side: kw folded into the GEMM's N (forward / data gradient)
      WFT, WFD planes      other layers with >= 64 output channels: the transpose of Wf (forward) and its rows per tap (data
                           gradient), pre-split the same way for the direct split-operand kernels
-   vcg_pack_weight_floats: floats the caller must provide for `wf` (spatial fields of cd are ignored). */
+   vcg_pack_weight_floats: floats the caller must provide for `wf` (spatial fields of cd are ignored).
+   vcg_conv_reads_wf(cd): 1 if vcg_conv_fwd / _fwd_in / _dgrad at THIS geometry (N, H, W count) read the fp32 Wf block of the
+     pack — the thin layers, tiles the split-operand kernels do not take, maps Winograd cannot take — 0 if every direction runs
+     from the pre-split planes.  A caller whose layer answers 0 for every geometry it is used at may set cd[VCG_CD_PACK_FLAGS] = 1
+     in the descriptor it hands to vcg_pack_weight: the Wf block is then not written (round 3: 0.6 ms and 1 GB per training step
+     for the D / R / U layers, whose Wf nothing reads).  Reading a Wf that was left out is undefined: ask again when the geometry
+     changes, and repack in full if the answer does. */
 size_t vcg_pack_weight_floats(const int32_t* cd);
+int vcg_conv_reads_wf(const int32_t* cd);
 int vcg_pack_weight(const float* w_oihw, float* wf, const int32_t* cd, void* stream);
-/* y = act(conv(x) + bias).  fp32 in, fp32 out, fp32 accumulate; the GEMMs run on the bf16 matrix pipe
-   (v_mfma_f32_32x32x16_bf16) with every fp32 operand split into three bf16 pieces and six products per
-   multiply-add (fp32-level rounding, csrc/gemm_split.hip); thin layers use v_mfma_f32_32x32x2_f32.
+/* y = act(conv(x) + bias).  fp32 in, fp32 out, fp32 accumulate; the GEMMs run on the 16-bit matrix pipe
+   (v_mfma_f32_{32x32x16,16x16x32}_f16) with every fp32 operand scaled by a power of two and split into two fp16 pieces, three
+   products per multiply-add (fp32-level rounding, csrc/vcg_common.h); thin layers use v_mfma_f32_32x32x2_f32.
    3x3 / stride-1 layers go through Winograd F(2x2,3x3) (16 batched GEMMs, V and M in `ws`); layers with few
    output tiles slice K across workgroups into fp32 slabs in `ws` (vcg_conv_fwd_workspace bytes, may be 0). */
 size_t vcg_conv_fwd_workspace(const int32_t* cd);

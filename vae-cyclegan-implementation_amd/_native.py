@@ -36,6 +36,7 @@ SIGNATURES = {
     "vcg_fill": (_I, [_P, _F, _Z, _P]),
     "vcg_pack_weight_floats": (_Z, [_I32P]),
     "vcg_pack_weight": (_I, [_P, _P, _I32P, _P]),
+    "vcg_conv_reads_wf": (_I, [_I32P]),
     "vcg_conv_fwd_workspace": (_Z, [_I32P]),
     "vcg_conv_fwd": (_I, [_P, _P, _P, _P, _I32P, _P, _Z, _P]),
     "vcg_conv_fwd_in_workspace": (_Z, [_I32P]),
@@ -121,7 +122,7 @@ def lib():
             fn = getattr(handle, name)
             fn.restype = res
             fn.argtypes = args
-        if handle.vcg_abi_version() != 4:
+        if handle.vcg_abi_version() != 5:
             raise RuntimeError("libvcg.so ABI version mismatch; rebuild it")
         _lib = handle
     return _lib

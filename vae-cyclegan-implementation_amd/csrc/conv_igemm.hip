@@ -2217,6 +2217,12 @@ extern "C" int vcg_pack_weight(const float* w_oihw, float* wf, const int32_t* cd
   ConvP p; fill_params(g, p);
   p.amax_b = amax_w;
   uint32_t* const hdr = (uint32_t*)(wf + wamax_offset(g));
+  if (cd[VCG_CD_PACK_FLAGS] & 1) {                          // the caller knows nothing reads Wf (vcg_conv_reads_wf): the header only
+    ConvP q = p; q.K = 0; q.Cout = 0;
+    hipLaunchKernelGGL(k_pack_weight, dim3(1), dim3(64), 0, (hipStream_t)stream, w_oihw, wf, q, g.cin_log, g.cout_log, hdr);
+    VCG_LAUNCH_CHECK("vcg_pack_weight(header)");
+    return 0;
+  }
   size_t total = (size_t)g.K * g.Cout;
   const int T = g.KH * g.KW * g.ups * g.ups;
   const size_t lds = (size_t)T * 8 * 33 * sizeof(float);
@@ -2390,6 +2396,31 @@ static int dgrad_setup(const ConvGeom& g, ConvP& p, int& bm, int& bn, int& nspli
       gemm_plan(p.Mc, p.NB, ((g.KH / s) * (g.KW / s) * g.Cout + BK - 1) / BK, true, bm, bn, nsplit, kt_per, s * s, true);
   }
   return 0;
+}
+
+// does the forward / the data gradient at this geometry read the fp32 Wf block?  (mirrors conv_fwd_impl and vcg_conv_dgrad)
+static bool fwd_reads_wf(const ConvGeom& g) {
+  if (vcg_thin_fold_ok(g)) return false;
+  if (vcg_thin_fwd_ok(g)) return true;
+  if (vcg_wino_fwd_ok(g) || fwd_slab_ok(g)) return false;
+  int bm, bn, nsplit, kt_per;
+  fwd_plan(g, bm, bn, nsplit, kt_per);
+  return !(bm == 128 && bn >= 64 && wft_wanted(g));
+}
+static bool dgrad_reads_wf(const ConvGeom& g) {
+  if (g.Hl % g.stride || g.Wl % g.stride) return true;
+  if (vcg_thin_fold_dgrad_ok(g)) return false;
+  if (vcg_thin_dgrad_ok(g)) return true;
+  if (vcg_wino_dgrad_ok(g) || dgrad_slab_ok(g)) return false;
+  ConvP p; fill_params(g, p);
+  int bm, bn, nsplit, kt_per;
+  dgrad_setup(g, p, bm, bn, nsplit, kt_per);
+  return !(bm == 128 && bn >= 64 && wfd_wanted(g));          // planes; everything else (no planes, 32-column, fp32) reads Wf
+}
+extern "C" int vcg_conv_reads_wf(const int32_t* cd) {
+  ConvGeom g;
+  if (vcg_conv_geom(cd, &g, "vcg_conv_reads_wf")) return 1;
+  return (fwd_reads_wf(g) || dgrad_reads_wf(g)) ? 1 : 0;
 }
 
 extern "C" size_t vcg_conv_dgrad_workspace(const int32_t* cd) {

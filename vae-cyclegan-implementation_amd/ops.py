@@ -224,6 +224,9 @@ class ConvSpec:
         self._pack_stream = None
         self._pack_event = None
         self._pack_weight = None
+        self._need_wf = False            # some geometry this spec has run at reads the fp32 Wf block of the pack (sticky)
+        self._wf_packed = False          # the current pack holds it
+        self._geoms_seen = set()
 
     def desc(self, n, h, w):
         cd = (ctypes.c_int32 * 16)()
@@ -238,14 +241,23 @@ class ConvSpec:
         hl, wl = h // self.ups, w // self.ups
         return ((hl + 2 * self.pad - self.k) // self.stride + 1, (wl + 2 * self.pad - self.k) // self.stride + 1)
 
-    def packed(self, weight):
+    def packed(self, weight, geom=None):
         """Packed weight buffer (Wf + the transformed copies) for the current parameter values: repacked once per
         optimizer step.  Parameters owned by a FusedAdam carry that optimizer's step counter (`_vcg_epoch`), so a step
-        of one optimizer does not invalidate the packs of another's parameters."""
+        of one optimizer does not invalidate the packs of another's parameters.
+        `geom` = (n, h, w) of the call that is about to use the pack: the fp32 Wf block is only written for specs some
+        geometry of which reads it (include/vcg.h, vcg_conv_reads_wf: the D / R / U layers run from their planes in every
+        direction — a third of the pack traffic of a step).  No geometry given (tests, `repack_async`): what is known so far."""
+        if geom is not None and geom not in self._geoms_seen:
+            self._geoms_seen.add(geom)
+            if LAZY_WF and not self._need_wf and _native.lib().vcg_conv_reads_wf(self.desc(*geom)):
+                self._need_wf = True
+        want_wf = self._need_wf or not LAZY_WF or not self._geoms_seen       # never used through a geometry yet: the full pack
         ep = getattr(weight, "_vcg_epoch", None)
         key = (ep[0] if ep is not None else PARAM_EPOCH[0], id(ep), weight._version, weight.data_ptr())
-        if self._packed is None or self._packed_key != key or self._packed.device != weight.device:
+        if self._packed is None or self._packed_key != key or self._packed.device != weight.device or (want_wf and not self._wf_packed):
             cd = self.desc(1, max(self.ups * self.k, 2 * self.ups * (self.pad + 1)), max(self.ups * self.k, 2 * self.ups * (self.pad + 1)))
+            cd[14] = 0 if want_wf else 1                                   # VCG_CD_PACK_FLAGS
             if self._packed is None or self._packed.device != weight.device:
                 nfl = int(_native.lib().vcg_pack_weight_floats(cd))
                 if nfl <= 0:
@@ -255,6 +267,7 @@ class ConvSpec:
             if not w.is_contiguous():
                 w = w.contiguous()
             _native.check(_native.lib().vcg_pack_weight(_ptr(w), _ptr(self._packed), cd, _stream()), "vcg_pack_weight")
+            self._wf_packed = want_wf
             self._packed_key = key
             self._pack_stream = torch.cuda.current_stream(weight.device)
             self._pack_event = torch.cuda.Event()
@@ -306,6 +319,9 @@ def _measured_amax(t):
         return 0
     return int(_native.lib().vcg_amax_measure(_ptr(t), t.numel(), _stream()))
 
+
+# VCG_LAZY_WF=0: every pack carries the fp32 Wf block, read or not (A/B measurements)
+LAZY_WF = os.environ.get("VCG_LAZY_WF", "1") != "0"
 
 # Keep the forward's Winograd-transformed input for the weight gradient (VCG_KEEP_FORWARD_STATE=0: recompute it, as round 1 did)
 KEEP_FORWARD_STATE = os.environ.get("VCG_KEEP_FORWARD_STATE", "1") != "0"
@@ -375,7 +391,7 @@ class _ConvBlockFn(torch.autograd.Function):
             raise RuntimeError(f"conv block expected {spec.cin_phys_log} input channels (pitch {spec.cin_pitch}), got pitch {pin}")
         ho, wo = spec.out_hw(h, w)
         cd = spec.desc(n, h, w)
-        wf = spec.packed(weight)
+        wf = spec.packed(weight, (n, h, w))
         dev = x.device
         t = torch.empty((n, ho, wo, spec.cout_pitch), dtype=torch.float32, device=dev)
         flops = 2.0 * n * ho * wo * spec.cout * spec.k * spec.k * spec.cin
