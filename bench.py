@@ -88,6 +88,11 @@ def main():
 
     pkg = importlib.import_module("vae-cyclegan-implementation_amd")
     ops, N = pkg.ops, pkg.Networks
+    if not os.path.exists(pkg._native.LIB_PATH):     # a tree without the built library (it normally travels with it): rank 0 builds,
+        if rank == 0:                                # the others wait — never N concurrent hipcc runs into one output file
+            pkg._native.build(verbose=False)
+        if world > 1:
+            dist.barrier()
     pkg._native.lib()                      # fail loudly if the HIP extension is missing
 
     wl = args.workload
