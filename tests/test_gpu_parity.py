@@ -322,7 +322,8 @@ def test_conv_fwd_in_equals_conv_then_statistics(case, pkg, device):
         # the kept V — pre-split fp16 planes of V / s — then a 16-float tail whose first word is the bit pattern of the largest
         # magnitude of the conv INPUT: s is derived from it (|B^T d B| <= 4 max|d|, csrc/conv_wino.hip) and the weight gradient's
         # GEMMs must scale V the same way
-        assert saved[nsv - 16:nsv - 15].view(torch.int32).item() == xp.abs().max().view(torch.int32).item()
+        if os.environ.get("VCG_WINO_PLANES", "1") != "0":      # (the fp32-V diagnostic mode keeps V's own amax there)
+            assert saved[nsv - 16:nsv - 15].view(torch.int32).item() == xp.abs().max().view(torch.int32).item()
         assert torch.equal(grads[0][0], grads[1][0]) and torch.equal(grads[0][1], grads[1][1])
 
 
