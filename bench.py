@@ -61,6 +61,8 @@ def main():
     ap.add_argument("--latent", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-eager-baseline", action="store_true",
+                    help="skip the stock PyTorch-ROCm (MIOpen / rocBLAS eager) run of the same step beside cpu_baseline")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -88,11 +90,18 @@ def main():
 
     pkg = importlib.import_module("vae-cyclegan-implementation_amd")
     ops, N = pkg.ops, pkg.Networks
-    if not os.path.exists(pkg._native.LIB_PATH):     # a tree without the built library (it normally travels with it): rank 0 builds,
-        if rank == 0:                                # the others wait — never N concurrent hipcc runs into one output file
+    # A tree without the built library (it normally travels with it): rank 0 builds, the others wait — never N concurrent
+    # hipcc runs.  The decision is rank 0's alone and every rank takes the same collectives whatever it sees on disk (a rank
+    # that started late and found the file rank 0 had just linked used to skip the barrier rank 0 was sitting in); the
+    # link goes to a temporary name and is renamed into place (_native.build), so no rank maps a half-written file.
+    if world > 1:
+        flag = torch.tensor([0 if os.path.exists(pkg._native.LIB_PATH) else 1], dtype=torch.int32, device=dev if backend == "nccl" else "cpu")
+        dist.broadcast(flag, src=0)
+        if int(flag.item()) and rank == 0:
             pkg._native.build(verbose=False)
-        if world > 1:
-            dist.barrier()
+        dist.barrier()
+    elif not os.path.exists(pkg._native.LIB_PATH):
+        pkg._native.build(verbose=False)
     pkg._native.lib()                      # fail loudly if the HIP extension is missing
 
     wl = args.workload
@@ -198,6 +207,12 @@ def main():
             out.update(roof)
     if rank == 0 and world == 1 and not args.no_cpu_baseline and wl in ("cyclevaegan", "vae", "autoencoder"):
         out["cpu_baseline"] = cpu_baseline(pkg, wl, S, latent)
+    if rank == 0 and world == 1 and not args.no_eager_baseline and wl in ("cyclevaegan", "vae", "autoencoder"):
+        del model, pool
+        gc.unfreeze()
+        gc.collect()
+        torch.cuda.empty_cache()
+        out["rocm_eager_baseline"] = rocm_eager_baseline(pkg, wl, B, S, latent, dev)
     if world > 1:
         dist.barrier()
     if rank == 0:
@@ -396,11 +411,60 @@ def cpu_baseline(pkg, wl, S, latent):
             oracle.autoencoder_step(P, state, x, x, 2e-4)
         times.append(time.perf_counter() - t0)
     t = sum(times[1:]) / len(times[1:])
-    ref = {"cyclevaegan": "0.200 images/s (batch 8)", "vae": "0.89 images/s (batch 16, latent 1024)", "autoencoder": "1.39 images/s (batch 16)"}[wl]
+    ref = {"cyclevaegan": (0.200, 8), "vae": (0.89, 16), "autoencoder": (1.39, 16)}[wl]
     return {"value": round(b / t, 4), "unit": "images/s", "cores": cores, "kind": "port",
             "sample": f"oracle (functional PyTorch fp32 CPU restatement) {wl} step, batch {b}, {S}x{S}, mean of steps 2-3 of 3 "
-                      f"({sum(times):.1f} s of CPU work in all); the reference's own module on the 8-core build container: {ref} "
-                      "(BASELINE.md §2; it cannot travel to this box)"}
+                      f"({sum(times):.1f} s of CPU work in all)",
+            # the reference's own module cannot travel to this box; its timing was taken where it runs
+            "reference_in_build_container": {"value": ref[0], "unit": "images/s", "cores": 8, "kind": "reference", "batch": ref[1],
+                                             "sample": f"/root/reference {wl} training_step, batch {ref[1]}, {S}x{S}, torch.set_num_threads(8), "
+                                                       "median of 3 steps after warm-up, taken in the 8-core build container "
+                                                       "(BASELINE.md §2); not re-measured in this run"}}
+
+
+def rocm_eager_baseline(pkg, wl, B, S, latent, dev):
+    """The same step on the same GPU through stock PyTorch-ROCm eager ops (MIOpen convolutions, ATen instance_norm / losses,
+    autograd): the oracle's functional restatement — the reference's algorithm as written, six VAE forwards and the
+    discriminator re-forward included — with its tensors on cuda:0 at the bench's batch size.  Outside the timed region, after
+    the hand-written path has been measured and its model freed; a baseline beside cpu_baseline, never a fallback: nothing in the
+    product can reach it.  One untimed step (MIOpen picks its algorithms there) and two timed ones."""
+    os.environ.setdefault("MIOPEN_FIND_MODE", "FAST")          # the default exhaustive find takes minutes for ~40 conv shapes
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    oracle = importlib.import_module("vcg_oracle")
+    Nn = pkg.Networks
+    torch.manual_seed(1234)
+    if wl == "cyclevaegan":
+        model = Nn.CycleVAEGAN(latent_dim=latent, paired=False)
+    elif wl == "vae":
+        model = Nn.VariationalAutoencoder(latent_dim=latent)
+    else:
+        model = Nn.Autoencoder()
+    P = {k: v.detach().clone().to(dev) for k, v in model.state_dict().items()}
+    del model
+    x = pkg.ops.rand_uniform((B, 3, S, S), dev, seed=1234, offset=0)
+    y = pkg.ops.rand_uniform((B, 3, S, S), dev, seed=1234, offset=1 << 22)
+    times, state = [], {}
+    try:
+        for it in range(3):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            if wl == "cyclevaegan":
+                eps = [torch.randn((B, latent, S // 16, S // 16), device=dev) for _ in range(6)]
+                oracle.cyclevaegan_step(P, state, x, y, eps, 2e-4, False)
+            elif wl == "vae":
+                oracle.vae_step(P, state, x, x, torch.randn((B, latent, S // 16, S // 16), device=dev), 2e-4)
+            else:
+                oracle.autoencoder_step(P, state, x, x, 2e-4)
+            torch.cuda.synchronize()
+            times.append(time.perf_counter() - t0)
+    except Exception as e:  # noqa: BLE001 — a baseline that cannot run must not take the measured line with it
+        return {"value": None, "error": f"{type(e).__name__}: {e}"[:300]}
+    t = sum(times[1:]) / len(times[1:])
+    return {"value": round(B / t, 2), "unit": "images/s", "ms_per_step": round(t * 1e3, 2), "kind": "stock PyTorch-ROCm eager ops",
+            "torch": torch.__version__, "batch": B,
+            "sample": f"oracle/vcg_oracle.py {wl} step as the reference writes it (fp32, MIOpen / ATen kernels, autograd) on cuda:0, batch {B}, "
+                      f"{S}x{S}; mean of steps 2-3 of 3 (first step {times[0]:.1f} s: MIOpen algorithm search, MIOPEN_FIND_MODE="
+                      f"{os.environ.get('MIOPEN_FIND_MODE')})"}
 
 
 if __name__ == "__main__":

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define VCG_ABI_VERSION 5   /* 5: vcg_conv_reads_wf, cd[VCG_CD_PACK_FLAGS].  4: vcg_amax_measure.  3 (round 3): packed weights and kept forward state carry fp16 x 2 planes + amax
+#define VCG_ABI_VERSION 6   /* 6 (round 4): vcg_amax_valid, the explicit-argument forms vcg_*_h.  5: vcg_conv_reads_wf, cd[VCG_CD_PACK_FLAGS].  4: vcg_amax_measure.  3 (round 3): packed weights and kept forward state carry fp16 x 2 planes + amax
                                words (sizes changed); vcg_amax_hint / vcg_amax_last.  round 2: vcg_adam_step takes 1 - beta; vcg_conv_fwd_in,
                                vcg_conv_wgrad_saved, input transforms, profiling */
 
@@ -49,6 +49,22 @@ uint64_t vcg_amax_last(void);
  * weight and data gradient of one dy) instead of each of them measuring it again.  0: no slot on this device (callers pass 0 on:
  * the consumers measure). */
 uint64_t vcg_amax_measure(const float* t, size_t n, void* stream);
+/* 1 while `handle` would still be honoured on the current device, 0 once it is too old (or is not a handle): a caller that keeps
+ * handles across many calls (ops.py keeps one per tensor object) asks before handing one on and measures again — refreshing what it
+ * keeps — instead of carrying a handle every consumer refuses.  A handle is honoured while its slot is >= 6144 generations from
+ * reuse: the check runs when a kernel is enqueued, the kernel reads the slot up to one training step (~1 500 generations) later. */
+int vcg_amax_valid(uint64_t handle);
+/* A handle describes the tensor's CONTENTS at the time it was published: a caller that lets anything write into the tensor
+ * afterwards (in-place ops, buffer reuse) must drop the handle (ops.py keys it on torch's version counter and the data pointer).
+ *
+ * Explicit-argument forms (ABI v6) — the same calls with the operand handles as arguments and the handle of what the call wrote
+ * returned through a pointer, for callers that do not want per-thread state between two calls; vcg_amax_hint / vcg_amax_last
+ * remain as the shim they are built on:
+ *   vcg_conv_fwd_in_h(..., x_amax, stream)             == vcg_amax_hint(x_amax, 0);  vcg_conv_fwd_in(...)
+ *   vcg_conv_dgrad_h(..., dy_amax, stream)             == vcg_amax_hint(0, dy_amax); vcg_conv_dgrad(...)
+ *   vcg_conv_wgrad_saved_h(..., x_amax, dy_amax, stream)
+ *   vcg_in_apply_h / vcg_in_bwd_h / vcg_act_bwd_h(..., &amax_of_what_was_written, stream)   (pointer may be NULL)
+ * declared next to their base forms below. */
 
 /* conv descriptor: int32[16] ------------------------------------------------ */
 enum {
@@ -130,10 +146,14 @@ size_t vcg_conv_fwd_in_workspace(const int32_t* cd);
 size_t vcg_conv_saved_floats(const int32_t* cd);
 int vcg_conv_fwd_in(const float* x, const float* wf, const float* bias, float* y, float* mean, float* rstd, float eps,
                     float* saved, const int32_t* cd, void* ws, size_t ws_bytes, void* stream);
+int vcg_conv_fwd_in_h(const float* x, const float* wf, const float* bias, float* y, float* mean, float* rstd, float eps,
+                      float* saved, const int32_t* cd, void* ws, size_t ws_bytes, uint64_t x_amax, void* stream);
 /* dx = conv^T(dy) including the adjoint of the reflect padding.              */
 size_t vcg_conv_dgrad_workspace(const int32_t* cd);
 int vcg_conv_dgrad(const float* dy, const float* wf, float* dx, const int32_t* cd,
                    void* ws, size_t ws_bytes, void* stream);
+int vcg_conv_dgrad_h(const float* dy, const float* wf, float* dx, const int32_t* cd,
+                     void* ws, size_t ws_bytes, uint64_t dy_amax, void* stream);
 /* gw_oihw += x^T dy (split-K slabs in ws, deterministic reduce); gbias += sum(dy).
    gbias may be NULL.                                                         */
 size_t vcg_conv_wgrad_workspace(const int32_t* cd);
@@ -142,6 +162,8 @@ int vcg_conv_wgrad(const float* x, const float* dy, float* gw_oihw, float* gbias
 /* vcg_conv_wgrad with the forward state vcg_conv_fwd_in kept in `saved` (NULL: identical to vcg_conv_wgrad). */
 int vcg_conv_wgrad_saved(const float* x, const float* dy, float* gw_oihw, float* gbias, const float* saved,
                          const int32_t* cd, void* ws, size_t ws_bytes, void* stream);
+int vcg_conv_wgrad_saved_h(const float* x, const float* dy, float* gw_oihw, float* gbias, const float* saved,
+                           const int32_t* cd, void* ws, size_t ws_bytes, uint64_t x_amax, uint64_t dy_amax, void* stream);
 
 /* nn.InstanceNorm2d(eps=1e-5, affine=False) — Networks.py:61,88,102,105,123 -- */
 size_t vcg_in_workspace(int N, int HW, int C);
@@ -151,14 +173,20 @@ int vcg_in_stats(const float* t, float* mean, float* rstd, int N, int HW, int C,
    nn.PixelShuffle(2) (Networks.py:121): out is (N,2H,2W,C/4).                */
 int vcg_in_apply(const float* t, const float* mean, const float* rstd, const float* residual,
                  float* out, int N, int H, int W, int C, int post_act, int shuffle, void* stream);
+int vcg_in_apply_h(const float* t, const float* mean, const float* rstd, const float* residual,
+                   float* out, int N, int H, int W, int C, int post_act, int shuffle, uint64_t* out_amax, void* stream);
 /* dt = epi_act'(t) * IN-backward(post_act'(.) * g); g is in `out` layout.   */
 int vcg_in_bwd(const float* g, const float* t, const float* mean, const float* rstd, float* dt,
                int N, int H, int W, int C, int epi_act, int post_act, int shuffle,
                void* ws, size_t ws_bytes, void* stream);
+int vcg_in_bwd_h(const float* g, const float* t, const float* mean, const float* rstd, float* dt,
+                 int N, int H, int W, int C, int epi_act, int post_act, int shuffle,
+                 void* ws, size_t ws_bytes, uint64_t* dt_amax, void* stream);
 /* nn.PixelShuffle(2) — Networks.py:121 — as a copy: (N,H,W,C) -> (N,2H,2W,C/4); inverse=1 is its backward */
 int vcg_pixel_shuffle(const float* src, float* dst, int N, int H, int W, int C, int inverse, void* stream);
 /* dt = g * act'(t) where t is the activation OUTPUT (blocks without a norm). */
 int vcg_act_bwd(const float* g, const float* t, float* dt, size_t n, int act, void* stream);
+int vcg_act_bwd_h(const float* g, const float* t, float* dt, size_t n, int act, uint64_t* dt_amax, void* stream);
 
 /* VariationalEncoderBlock.forward — Networks.py:219-227 -------------------- */
 /* lvc = clamp(lv,-10,10); z = mu + eps*exp(0.5*lvc). eps==NULL: eps is drawn

@@ -166,12 +166,14 @@ def assert_checksum(t, ck, what, tol=RTOL):
         raise AssertionError(f"{what}: sampled elements differ by {err:.3e} = {err / ref:.2e} of their scale")
 
 
-# One ReLU-mask flip (below) moves the weight gradients of its layer and of everything upstream by 0.3..1.0e-2: seen on dve64 when
-# round 3 moved the D1 / U2 forward from the Winograd to the direct kernels — every tensor upstream of decoder_A's last ReLU went
-# from ~2e-4 to 3..8e-3 of its norm (decoder_A.model.0.conv2.weight: 1.00e-2), the untouched decoder_B stayed at 5e-5
-# (profiles/r03_grad_error.txt) — and the reference's own fp32 run sits at 1.38e-2 from its fp64 run on that tensor of the
-# sibling fixture dae64.  1e-2 was calibrated on one flip among 65 536 activations; the maps here go down to 32 768.  Hence 1.5e-2.
-FLIP_BUDGET = 1.5e-2
+# One ReLU-mask flip (below) moves the weight gradients of its layer and of everything upstream by 0.3..1.0e-2: calibrated on one
+# flip among 65 536 activations.  The budget is PER FIXTURE (round 4; round 3 had raised it to 1.5e-2 for every deep step): only
+# dve64 needs more — when round 3 moved the D1 / U2 forward from the Winograd to the direct kernels every tensor upstream of its
+# decoder_A's last ReLU went from ~2e-4 to 3..8e-3 of its norm (decoder_A.model.0.conv2.weight: 1.00e-2; maps of 32 768
+# activations), the untouched decoder_B stayed at 5e-5 (profiles/r03_grad_error.txt), and the reference's own fp32 run sits at
+# 1.38e-2 from its fp64 run on that tensor of the sibling fixture dae64.  Everything else measures <= 8.5e-3 and keeps 1e-2.
+FLIP_BUDGET = 1e-2
+FLIP_BUDGET_BY_KEY = {"dve64": 1.5e-2}
 
 # every deep-step gradient comparison is appended here as (fixture key, tensor, ours / ||g||, reference fp32 / ||g||,
 # bound / ||g||); VCG_GRAD_ERROR_LOG=<file> writes the table at the end of the session (profiles/r02_grad_error.txt)
@@ -255,8 +257,9 @@ GAN_FLIP_BUDGET = FLIP_BUDGET   # round 1 allowed 1e-1 on the GAN steps; the 4 x
 #                                 reference's own fp32 error there (0.9e-2 .. 1e-2 on G and F, 0.77 on D's spectral-norm weight)
 
 
-def check_step_state(params, grads, key, golden, lr, snap="", tol=RTOL, nsteps=1, flip=FLIP_BUDGET):
+def check_step_state(params, grads, key, golden, lr, snap="", tol=RTOL, nsteps=1, flip=None):
     """params/grads: {state_dict name: tensor}.  Compares with the reference's post-step snapshot."""
+    flip = FLIP_BUDGET_BY_KEY.get(key, FLIP_BUDGET) if flip is None else flip
     bad = []
     pw = [(n, v) for n, v in params.items() if not (in_cancelled_bias(n) or n.endswith("weight_u"))]
     gw = [(n, g) for n, g in (grads or {}).items() if not (g is None or in_cancelled_bias(n))]

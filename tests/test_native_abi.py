@@ -42,7 +42,7 @@ def test_no_c_symbol_is_exported_behind_the_headers_back(pkg):
 def test_python_binding_covers_the_header(pkg):
     assert sorted(pkg._native.SIGNATURES) == header_symbols()
     lib = pkg._native.lib()
-    assert lib.vcg_abi_version() == 5
+    assert lib.vcg_abi_version() == 6
 
 
 def test_code_object_targets_gfx950(pkg):

@@ -21,6 +21,7 @@ _Z = _c.c_size_t
 _F = _c.c_float
 _U64 = _c.c_uint64
 _I32P = _c.POINTER(_c.c_int32)
+_U64P = _c.POINTER(_c.c_uint64)
 
 # name -> (restype, argtypes); mirrors include/vcg.h one to one
 SIGNATURES = {
@@ -29,6 +30,13 @@ SIGNATURES = {
     "vcg_amax_hint": (None, [_U64, _U64]),
     "vcg_amax_last": (_U64, []),
     "vcg_amax_measure": (_U64, [_P, _Z, _P]),
+    "vcg_amax_valid": (_I, [_U64]),
+    "vcg_conv_fwd_in_h": (_I, [_P, _P, _P, _P, _P, _P, _F, _P, _I32P, _P, _Z, _U64, _P]),
+    "vcg_conv_dgrad_h": (_I, [_P, _P, _P, _I32P, _P, _Z, _U64, _P]),
+    "vcg_conv_wgrad_saved_h": (_I, [_P, _P, _P, _P, _P, _I32P, _P, _Z, _U64, _U64, _P]),
+    "vcg_in_apply_h": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _U64P, _P]),
+    "vcg_in_bwd_h": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _Z, _U64P, _P]),
+    "vcg_act_bwd_h": (_I, [_P, _P, _P, _Z, _I, _U64P, _P]),
     "vcg_profile_enable": (_I, [_I]),
     "vcg_profile_read": (_c.c_long, [_c.c_char_p, _Z]),
     "vcg_nchw_to_nhwc": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
@@ -76,6 +84,7 @@ SIGNATURES = {
 }
 
 _lib = None
+ABI_VERSION = 6
 
 
 def hipcc_path():
@@ -98,13 +107,38 @@ def build(force=False, verbose=False):
     # and packed-fp32 VALU issues badly beside another wave's MFMA stream (MI355X_MICROARCH.md, "price of one filler beside
     # MFMAs"): measured on the ping-pong GEMM, the staging phase of the waves that run beside their partners' matrix phase
     # took 3500 shader clocks per K-step with the packed ops and 1900 without (profiles/r02_gemm_pp_stamps.txt)
-    cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-fPIC", "-shared",
-           "-o", LIB_PATH] + srcs
+    # one hipcc per source, in parallel (no -fgpu-rdc: the translation units share no device symbol), objects under csrc/_obj
+    # (git-ignored), then one link into a temporary name that is renamed over libvcg.so: a process that is loading the old
+    # library, or another rank that finds the file while it is being linked, never maps a half-written one
+    from concurrent.futures import ThreadPoolExecutor
+    objdir = os.path.join(CSRC, "_obj")
+    os.makedirs(objdir, exist_ok=True)
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-fPIC"]
+    hdr_time = max(os.path.getmtime(os.path.join(CSRC, "vcg_common.h")), os.path.getmtime(HEADER))
+
+    def compile_one(src):
+        obj = os.path.join(objdir, os.path.basename(src) + ".o")
+        if not force and os.path.exists(obj) and os.path.getmtime(obj) >= max(os.path.getmtime(src), hdr_time):
+            return obj, None
+        cmd = [hipcc_path()] + flags + ["-c", src, "-o", obj]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        res = subprocess.run(cmd, capture_output=True, text=True)
+        return obj, (res.stdout + res.stderr if res.returncode != 0 else None)
+
+    with ThreadPoolExecutor(max_workers=min(len(srcs), os.cpu_count() or 4)) as pool:
+        results = list(pool.map(compile_one, srcs))
+    bad = [err for _, err in results if err]
+    if bad:
+        raise RuntimeError("hipcc failed:\n" + "\n".join(bad))
+    tmp = LIB_PATH + f".tmp{os.getpid()}"
+    cmd = [hipcc_path(), "--offload-arch=gfx950", "-fPIC", "-shared", "-o", tmp] + [o for o, _ in results]
     if verbose:
-        print(" ".join(cmd))
+        print(" ".join(cmd), flush=True)
     res = subprocess.run(cmd, capture_output=True, text=True)
     if res.returncode != 0:
-        raise RuntimeError("hipcc failed:\n" + res.stdout + res.stderr)
+        raise RuntimeError("hipcc (link) failed:\n" + res.stdout + res.stderr)
+    os.replace(tmp, LIB_PATH)
     return LIB_PATH
 
 
@@ -122,7 +156,7 @@ def lib():
             fn = getattr(handle, name)
             fn.restype = res
             fn.argtypes = args
-        if handle.vcg_abi_version() != 5:
+        if handle.vcg_abi_version() != ABI_VERSION:
             raise RuntimeError("libvcg.so ABI version mismatch; rebuild it")
         _lib = handle
     return _lib

@@ -167,14 +167,29 @@ extern "C" uint64_t vcg_amax_measure(const float* t, size_t n, void* stream) {
   if (!o.slot || vcg_absmax_launch(t, n, o, (hipStream_t)stream)) return 0;
   return vcg_amax_handle(o);
 }
+// A handle is honoured while its slot is at least VCG_AMAX_MARGIN generations away from reuse.  The check runs on the host when a
+// kernel is ENQUEUED; the kernel reads the slot later, by as much as the host runs ahead of the device — at most one training step
+// (every step ends with a metric read-back; a step takes ~1 500 generations, side stream included), so the margin is several steps
+// (round 3 had 1 024: less than one step — ADVICE r3).
+#define VCG_AMAX_MARGIN 6144
+static bool amax_handle_valid(uint64_t handle, int dev) {
+  if ((handle >> 56) != VCG_HANDLE_MAGIC) return false;
+  const uint32_t gen = (uint32_t)handle;
+  const uint32_t age = (uint32_t)g_amax_gen.load() - gen;
+  return (int)((handle >> 40) & 0xFF) == (dev & 0xFF) && gen != 0 && age < VCG_AMAX_SLOTS - VCG_AMAX_MARGIN;
+}
+extern "C" int vcg_amax_valid(uint64_t handle) {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  return amax_base(dev) && amax_handle_valid(handle, dev) ? 1 : 0;
+}
 int vcg_operand_amax(const float* t, size_t n, uint64_t handle, int shift, hipStream_t st, VcgAmax* out) {
   if ((handle >> 56) == VCG_HANDLE_MAGIC) {
     int dev = 0;
     (void)hipGetDevice(&dev);
     const uint32_t gen = (uint32_t)handle;
-    const uint32_t age = (uint32_t)g_amax_gen.load() - gen;
     unsigned long long* base = amax_base(dev);
-    if (base && (int)((handle >> 40) & 0xFF) == (dev & 0xFF) && gen != 0 && age < VCG_AMAX_SLOTS - 1024) {
+    if (base && amax_handle_valid(handle, dev)) {
       VcgAmaxOut o; o.gen = gen; o.slot = base + (size_t)(gen % VCG_AMAX_SLOTS) * 64;
       *out = vcg_amax_in(o, shift);
       return 0;
@@ -790,4 +805,49 @@ extern "C" int vcg_adam_step(float* p, const float* g, float* m, float* v, size_
                      beta2, one_minus_beta1, one_minus_beta2, eps, bc2_sqrt, grad_scale);
   VCG_LAUNCH_CHECK("vcg_adam_step");
   return 0;
+}
+
+// ---------------------------------------------------------------- explicit-argument forms of the amax hand-off (ABI v6, include/vcg.h)
+// The operand handles travel as arguments and the handle of what the call wrote comes back through a pointer; the thread-local
+// pair vcg_amax_hint / vcg_amax_last stays as the shim these forms are built on (set, call, take — all on the calling thread).
+extern "C" int vcg_conv_fwd_in_h(const float* x, const float* wf, const float* bias, float* y, float* mean, float* rstd, float eps,
+                                 float* saved, const int32_t* cd, void* ws, size_t ws_bytes, uint64_t x_amax, void* stream) {
+  vcg_amax_hint(x_amax, 0);
+  const int rc = vcg_conv_fwd_in(x, wf, bias, y, mean, rstd, eps, saved, cd, ws, ws_bytes, stream);
+  vcg_amax_hint(0, 0);
+  return rc;
+}
+extern "C" int vcg_conv_dgrad_h(const float* dy, const float* wf, float* dx, const int32_t* cd, void* ws, size_t ws_bytes,
+                                uint64_t dy_amax, void* stream) {
+  vcg_amax_hint(0, dy_amax);
+  const int rc = vcg_conv_dgrad(dy, wf, dx, cd, ws, ws_bytes, stream);
+  vcg_amax_hint(0, 0);
+  return rc;
+}
+extern "C" int vcg_conv_wgrad_saved_h(const float* x, const float* dy, float* gw_oihw, float* gbias, const float* saved,
+                                      const int32_t* cd, void* ws, size_t ws_bytes, uint64_t x_amax, uint64_t dy_amax, void* stream) {
+  vcg_amax_hint(x_amax, dy_amax);
+  const int rc = vcg_conv_wgrad_saved(x, dy, gw_oihw, gbias, saved, cd, ws, ws_bytes, stream);
+  vcg_amax_hint(0, 0);
+  return rc;
+}
+extern "C" int vcg_in_apply_h(const float* t, const float* mean, const float* rstd, const float* residual, float* out, int N, int H,
+                              int W, int C, int post_act, int shuffle, uint64_t* out_amax, void* stream) {
+  const int rc = vcg_in_apply(t, mean, rstd, residual, out, N, H, W, C, post_act, shuffle, stream);
+  const uint64_t h = vcg_amax_last();
+  if (out_amax) *out_amax = rc ? 0 : h;
+  return rc;
+}
+extern "C" int vcg_in_bwd_h(const float* g, const float* t, const float* mean, const float* rstd, float* dt, int N, int H, int W,
+                            int C, int epi_act, int post_act, int shuffle, void* ws, size_t ws_bytes, uint64_t* dt_amax, void* stream) {
+  const int rc = vcg_in_bwd(g, t, mean, rstd, dt, N, H, W, C, epi_act, post_act, shuffle, ws, ws_bytes, stream);
+  const uint64_t h = vcg_amax_last();
+  if (dt_amax) *dt_amax = rc ? 0 : h;
+  return rc;
+}
+extern "C" int vcg_act_bwd_h(const float* g, const float* t, float* dt, size_t n, int act, uint64_t* dt_amax, void* stream) {
+  const int rc = vcg_act_bwd(g, t, dt, n, act, stream);
+  const uint64_t h = vcg_amax_last();
+  if (dt_amax) *dt_amax = rc ? 0 : h;
+  return rc;
 }
