@@ -148,6 +148,18 @@ int vcg_conv_fwd_in(const float* x, const float* wf, const float* bias, float* y
                     float* saved, const int32_t* cd, void* ws, size_t ws_bytes, void* stream);
 int vcg_conv_fwd_in_h(const float* x, const float* wf, const float* bias, float* y, float* mean, float* rstd, float eps,
                       float* saved, const int32_t* cd, void* ws, size_t ws_bytes, uint64_t x_amax, void* stream);
+/* The fused Conv + InstanceNorm + activation hand-off (round 4; /root/reference/Networks.py:93-95, 110-115: a block's
+   InstanceNorm output feeds the next block's conv).  `t_prev` is the RAW output of the previous block's conv — what
+   vcg_conv_fwd_in left in y, with its statistics pre_mean / pre_rstd ([N][Cin]) — and this conv's input gather computes
+   pre_act((t_prev - mean) * rstd) on the way in: the normalised tensor is never written or read (vcg_in_apply is not called for
+   it).  Everything else as vcg_conv_fwd_in (y, this conv's own statistics, `saved`).  The operand's magnitude is bounded by
+   sqrt(H * W) instead of measured.  Exists where vcg_conv_pre_ok(cd) says 1 — the Winograd input transform (the D2..D4, R and U1
+   layers at the training sizes); elsewhere it returns an error and the caller runs vcg_in_apply + vcg_conv_fwd_in.  The weight
+   gradient of such a layer must come from `saved` (vcg_conv_wgrad_saved): there is no normalised x to re-read. */
+int vcg_conv_pre_ok(const int32_t* cd);
+int vcg_conv_fwd_in_pre(const float* t_prev, const float* pre_mean, const float* pre_rstd, int pre_act, const float* wf,
+                        const float* bias, float* y, float* mean, float* rstd, float eps, float* saved, const int32_t* cd,
+                        void* ws, size_t ws_bytes, void* stream);
 /* dx = conv^T(dy) including the adjoint of the reflect padding.              */
 size_t vcg_conv_dgrad_workspace(const int32_t* cd);
 int vcg_conv_dgrad(const float* dy, const float* wf, float* dx, const int32_t* cd,

@@ -433,6 +433,55 @@ def test_amax_handles_change_no_bit_and_stale_ones_are_refused(pkg, device):
     assert lib.vcg_amax_valid(base[4])
 
 
+def test_deferred_instance_norm_equals_the_materialised_path(pkg, oracle, device):
+    """The fused Conv + IN + act hand-off (include/vcg.h, vcg_conv_fwd_in_pre; /root/reference/Networks.py:93-95 feeding :87): inside
+    an Encoder a D block hands its raw conv output and statistics to the next D block, whose Winograd input transform normalises on
+    the fly — the normalised tensor is never written.  Same results as the materialised path (VCG_DEFER_NORM=0) up to the rounding
+    of the operand scale (bounded by sqrt(HW) instead of measured), same gradients, and against the oracle's D -> D -> R chain."""
+    ops, N = pkg.ops, pkg.Networks
+    torch.manual_seed(5)
+    blocks = torch.nn.Sequential(N.D(64, 128), N.D(128, 256), N.R(256)).to(device)
+    x0 = torch.randn(2, 64, 64, 64, device=device)
+    g0 = torch.randn(2, 256, 16, 16, device=device)
+
+    def run(defer):
+        prev = ops.DEFER_NORM
+        ops.DEFER_NORM = defer
+        try:
+            for p_ in blocks.parameters():
+                p_.grad = None
+            x = ops.to_nhwc(x0).requires_grad_(True)
+            d1, d2, r = blocks
+            n, _, h, w = x.shape
+            use = ops.consumer_takes_deferred(d2._spec, n, h // 2, w // 2)
+            assert use == defer, "D(128, 256) at 32 x 32 is a Winograd layer: its gather must take a deferred input"
+            h1 = d1(x, defer_out=use)
+            if defer:
+                assert getattr(h1, "_vcg_lazy", None) is not None
+            y = r(d2(h1))
+            assert getattr(h1, "_vcg_lazy", None) is not None or not defer      # never materialised on the fused path
+            y.backward(ops.to_nhwc(g0))
+            return nchw(y), nchw(x.grad), {k: v.grad.detach().cpu().clone() for k, v in blocks.named_parameters()}
+        finally:
+            ops.DEFER_NORM = prev
+
+    y1, dx1, gw1 = run(True)
+    y0, dx0, gw0 = run(False)
+    assert rel_l2(y1, y0) <= 2e-6 and rel_l2(dx1, dx0) <= 1e-5, (rel_l2(y1, y0), rel_l2(dx1, dx0))
+    for k in gw0:
+        if gw0[k].norm() > 0:
+            assert rel_l2(gw1[k], gw0[k]) <= 1e-5, (k, rel_l2(gw1[k], gw0[k]))
+    # and against the oracle (CPU, fp32 torch ops) through the same three blocks
+    P = {k: v.detach().cpu() for k, v in blocks.state_dict().items()}
+    xr = x0.cpu().requires_grad_(True)
+    yr = oracle.r_block(oracle.d_block(oracle.d_block(xr, P, "0."), P, "1."), P, "2.")
+    yr.backward(g0.cpu())
+    assert_close(y1, yr.detach(), "D -> D -> R output", l2=1e-4)
+    # through four ReLU masks the gradient sits on the flip floor (conftest.FLIP_BUDGET; measured 4.7e-3 — the materialised
+    # path gives the same number: the two agree to 1e-5 above)
+    assert_close(dx1, xr.grad, "D -> D -> R input gradient", l2=1e-2, mx=1e-1)
+
+
 def test_in_place_writes_drop_the_amax_handle(pkg, device):
     """VERDICT r3 weak #8 / ADVICE r3: the handle a block leaves on its output describes the tensor's contents when it was
     written.  `h = block(x); h.mul_(2**10); block2(h)` must not scale h by the stale amax (the fp16 split has 2-4x of headroom:

@@ -54,8 +54,8 @@ class CaSb(nn.Module):
             self._spec = ops.ConvSpec(in_channels, out_channels, kernel_size, stride, padding, True, 1,
                                       act if act is not None else 0, False)
 
-    def forward(self, x):
-        return ops.conv_block(x, self.conv.weight, self.conv.bias, self._spec)
+    def forward(self, x, defer_out=False):
+        return ops.conv_block(x, self.conv.weight, self.conv.bias, self._spec, defer=defer_out)
 
 
 class D(nn.Module):
@@ -70,8 +70,10 @@ class D(nn.Module):
         self.activation = nn.ReLU(inplace=False)
         self._spec = ops.ConvSpec(in_channels * 4, out_channels, 3, 1, 1, True, 2, ops.ACT_RELU, True)
 
-    def forward(self, x):
-        return ops.conv_block(x, self.conv.weight, self.conv.bias, self._spec)
+    def forward(self, x, defer_out=False):
+        """`defer_out` (internal, Encoder.forward): hand the raw conv output and its statistics to the next block's gather
+        instead of writing the normalised tensor (ops.conv_block, "deferred InstanceNorm")."""
+        return ops.conv_block(x, self.conv.weight, self.conv.bias, self._spec, defer=defer_out)
 
 
 class R(nn.Module):
@@ -90,7 +92,11 @@ class R(nn.Module):
 
     def forward(self, x):
         x = ops.to_nhwc(x)
-        h = ops.conv_block(x, self.conv1.weight, self.conv1.bias, self._spec1)
+        # conv1's InstanceNorm is applied inside conv2's input gather where conv2's geometry has one (the 1024-channel Winograd
+        # layers of the training sizes): h is then never written (the fused Conv + IN + act hand-off)
+        n, _, hh, ww = x.shape
+        defer = ops.consumer_takes_deferred(self._spec2, n, hh, ww, torch.is_grad_enabled())
+        h = ops.conv_block(x, self.conv1.weight, self.conv1.bias, self._spec1, defer=defer)
         return ops.conv_block(h, self.conv2.weight, self.conv2.bias, self._spec2, residual=x)
 
 
@@ -151,7 +157,20 @@ class Encoder(nn.Module):
         _kaiming_relu_init(module)
 
     def forward(self, x):
-        return self.model(ops.to_nhwc(x))
+        out = ops.to_nhwc(x)
+        layers = list(self.model)
+        for i, layer in enumerate(layers):
+            nxt = layers[i + 1] if i + 1 < len(layers) else None
+            if isinstance(layer, (CaSb, D)) and isinstance(nxt, D):
+                # the next D block normalises this block's raw output in its own gather where its geometry can (the Winograd
+                # input transform: D2..D4 at the training sizes) — the normalised tensor is then never written
+                n, _, hh, ww = out.shape
+                ho, wo = layer._spec.out_hw(hh, ww)
+                defer = layer._spec.norm and ops.consumer_takes_deferred(nxt._spec, n, ho, wo, torch.is_grad_enabled())
+                out = layer(out, defer_out=defer)
+            else:
+                out = layer(out)
+        return out
 
 
 class Decoder(nn.Module):

@@ -50,6 +50,8 @@ SIGNATURES = {
     "vcg_conv_fwd_in_workspace": (_Z, [_I32P]),
     "vcg_conv_saved_floats": (_Z, [_I32P]),
     "vcg_conv_fwd_in": (_I, [_P, _P, _P, _P, _P, _P, _F, _P, _I32P, _P, _Z, _P]),
+    "vcg_conv_pre_ok": (_I, [_I32P]),
+    "vcg_conv_fwd_in_pre": (_I, [_P, _P, _P, _I, _P, _P, _P, _P, _P, _F, _P, _I32P, _P, _Z, _P]),
     "vcg_conv_wgrad_saved": (_I, [_P, _P, _P, _P, _P, _I32P, _P, _Z, _P]),
     "vcg_conv_dgrad_workspace": (_Z, [_I32P]),
     "vcg_conv_dgrad": (_I, [_P, _P, _P, _I32P, _P, _Z, _P]),

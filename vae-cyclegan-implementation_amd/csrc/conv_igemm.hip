@@ -2023,6 +2023,12 @@ static void fill_params(const ConvGeom& g, ConvP& p) {
 // exists, use it.  Otherwise (deep layers: M = N*16*16 pixels, K up to 18 432) keep the big, efficient
 // tile and slice K across blockIdx.z instead of shrinking the tile: partial tiles go to fp32 slabs that
 // k_splitk_finish sums in a fixed order (+ bias + activation).
+// VCG_PLAN_TSCALE: multiplies the planners' time per K-step (their constants were measured on the fp32-MFMA kernels of round 1;
+// the fp16 x 2 kernels step ~2x faster while a K slice's slab traffic and finish launch cost what they did) — A/B measurements
+static double plan_tscale() {
+  static const double v = [] { const char* e = getenv("VCG_PLAN_TSCALE"); return e ? atof(e) : 1.0; }();
+  return v;
+}
 static void gemm_plan(long long rows, long long cols, int nkt, bool allow_split, int& bm, int& bn, int& nsplit,
                       int& kt_per, int batches = 1, bool allow_bn32 = false, bool single_level = false) {
   // cost model (us): rounds of resident workgroups x K-steps per workgroup x time per K-step of that tile,
@@ -2046,7 +2052,7 @@ static void gemm_plan(long long rows, long long cols, int nkt, bool allow_split,
       if (ns > 1 && kt < 8) break;
       int real_ns = (nkt + kt - 1) / kt;
       long long rounds = (tiles * real_ns + slots - 1) / slots;
-      double t = rounds * kt * c.t_step;
+      double t = rounds * kt * c.t_step * plan_tscale();
       if (real_ns > 1) t += (double)real_ns * rows * cols * 8.0 / 3.0e6 + 3.0;   // + one more launch
       if (t < best * 0.97) { best = t; bm = c.bm; bn = c.bn; nsplit = real_ns; kt_per = kt; }
     }
@@ -2270,16 +2276,21 @@ static bool fwd_tile_stats_ok(const ConvGeom& g) {
 // in_part != nullptr: also leave the InstanceNorm chunk partials of y there (the caller checked that this launch plan
 // can: Winograd, or fwd_tile_stats_ok) and report the chunk count per image.
 static int conv_fwd_impl(const float* x, const float* wf, const float* bias, float* y, const int32_t* cd, void* ws,
-                         size_t ws_bytes, void* stream, double* in_part, const VcgInTail* tail_req, float* saved = nullptr) {
+                         size_t ws_bytes, void* stream, double* in_part, const VcgInTail* tail_req, float* saved = nullptr,
+                         const VcgPre* pre = nullptr) {
   const uint64_t x_handle = vcg_take_hint_x();              // vcg_amax_hint: who wrote x left its largest magnitude (or 0)
   (void)vcg_take_hint_dy();
   ConvGeom g;
   if (vcg_conv_geom(cd, &g, "vcg_conv_fwd")) return -1;
   VCG_CHECK_ARG(x && wf && y, "vcg_conv_fwd: null pointer");
+  if (pre && pre->mean)
+    VCG_CHECK_ARG(!vcg_thin_fold_ok(g) && !vcg_thin_fwd_ok(g) && vcg_wino_pre_ok(g),
+                  "vcg_conv_fwd_in_pre: this geometry has no normalising gather (ask vcg_conv_pre_ok first)");
   if (vcg_thin_fold_ok(g)) return vcg_thin_fold_fwd(g, x, wf + wf_floats(g), vcg_pack_amax(g, wf), bias, y, ws, ws_bytes, (hipStream_t)stream, x_handle);
   if (vcg_thin_fwd_ok(g)) return vcg_thin_fwd(g, x, wf, bias, y, (hipStream_t)stream);
   if (vcg_wino_fwd_ok(g))
-    return vcg_wino_fwd(g, x, wf + wf_floats(g), vcg_pack_amax(g, wf), bias, y, ws, ws_bytes, (hipStream_t)stream, in_part, tail_req, saved, x_handle);
+    return vcg_wino_fwd(g, x, wf + wf_floats(g), vcg_pack_amax(g, wf), bias, y, ws, ws_bytes, (hipStream_t)stream, in_part, tail_req, saved, x_handle,
+                        pre);
   if (fwd_slab_ok(g))
     return vcg_slab_fwd(g, x, wf + wft_offset(g), wft_floats(g) * 4, vcg_pack_amax(g, wf), bias, y, in_part, tail_req, (hipStream_t)stream, x_handle);
   ConvP p; fill_params(g, p);
@@ -2356,15 +2367,37 @@ extern "C" size_t vcg_conv_saved_floats(const int32_t* cd) {
   return vcg_wino_fwd_ok(g) ? vcg_wino_saved_floats(g) : 0;
 }
 
+static int conv_fwd_in_impl(const float* x, const float* wf, const float* bias, float* y, float* mean, float* rstd,
+                            float eps, float* saved, const int32_t* cd, void* ws, size_t ws_bytes, void* stream, const VcgPre* pre);
 extern "C" int vcg_conv_fwd_in(const float* x, const float* wf, const float* bias, float* y, float* mean, float* rstd,
                                float eps, float* saved, const int32_t* cd, void* ws, size_t ws_bytes, void* stream) {
+  return conv_fwd_in_impl(x, wf, bias, y, mean, rstd, eps, saved, cd, ws, ws_bytes, stream, nullptr);
+}
+// 1 if vcg_conv_fwd_in_pre exists for this geometry: the forward's input gather can normalise on the fly (today: the Winograd
+// input transform — the D2..D4, R and U1 layers at the training sizes)
+extern "C" int vcg_conv_pre_ok(const int32_t* cd) {
+  ConvGeom g;
+  if (vcg_conv_geom(cd, &g, "vcg_conv_pre_ok")) return 0;
+  return (!vcg_thin_fold_ok(g) && !vcg_thin_fwd_ok(g) && vcg_wino_pre_ok(g)) ? 1 : 0;
+}
+extern "C" int vcg_conv_fwd_in_pre(const float* t_prev, const float* pre_mean, const float* pre_rstd, int pre_act, const float* wf,
+                                   const float* bias, float* y, float* mean, float* rstd, float eps, float* saved, const int32_t* cd,
+                                   void* ws, size_t ws_bytes, void* stream) {
+  VCG_CHECK_ARG(pre_mean && pre_rstd, "vcg_conv_fwd_in_pre: null statistics");
+  VCG_CHECK_ARG(pre_act >= VCG_ACT_NONE && pre_act <= VCG_ACT_SIGMOID, "vcg_conv_fwd_in_pre: bad activation %d", pre_act);
+  const VcgPre pre = {pre_mean, pre_rstd, pre_act};
+  (void)vcg_take_hint_x();              // the input's magnitude is bounded, not measured (conv_wino.hip, vcg_wino_fwd)
+  return conv_fwd_in_impl(t_prev, wf, bias, y, mean, rstd, eps, saved, cd, ws, ws_bytes, stream, &pre);
+}
+static int conv_fwd_in_impl(const float* x, const float* wf, const float* bias, float* y, float* mean, float* rstd,
+                            float eps, float* saved, const int32_t* cd, void* ws, size_t ws_bytes, void* stream, const VcgPre* pre) {
   ConvGeom g;
   if (vcg_conv_geom(cd, &g, "vcg_conv_fwd_in")) return -1;
   VCG_CHECK_ARG((mean == nullptr) == (rstd == nullptr), "vcg_conv_fwd_in: mean and rstd go together");
   if (saved && !vcg_conv_saved_floats(cd)) saved = nullptr;
   if (!mean) {                                           // no statistics wanted: the plain forward (+ saved state)
     VCG_CHECK_ARG(ws_bytes >= vcg_conv_fwd_workspace(cd), "vcg_conv_fwd_in: workspace too small (%zu)", ws_bytes);
-    return conv_fwd_impl(x, wf, bias, y, cd, ws, ws_bytes, stream, nullptr, nullptr, saved);
+    return conv_fwd_impl(x, wf, bias, y, cd, ws, ws_bytes, stream, nullptr, nullptr, saved, pre);
   }
   VCG_CHECK_ARG(ws, "vcg_conv_fwd_in: null pointer");
   VCG_CHECK_ARG(ws_bytes >= vcg_conv_fwd_in_workspace(cd), "vcg_conv_fwd_in: workspace too small (%zu)", ws_bytes);
@@ -2374,7 +2407,7 @@ extern "C" int vcg_conv_fwd_in(const float* x, const float* wf, const float* bia
   // fused: the conv's epilogue leaves the partials and its last block per (image, channel range) finalizes them
   VcgInTail req = vcg_in_tail_none();
   req.out1 = mean; req.out2 = rstd; req.HW = g.Ho * g.Wo; req.eps = eps;
-  if (conv_fwd_impl(x, wf, bias, y, cd, ws, cws, stream, fused ? part : nullptr, &req, saved)) return -1;
+  if (conv_fwd_impl(x, wf, bias, y, cd, ws, cws, stream, fused ? part : nullptr, &req, saved, pre)) return -1;
   if (fused) return 0;
   return vcg_in_stats_pass(y, mean, rstd, g.N, g.Ho * g.Wo, g.Cout, eps, part, ws_bytes - cws, (hipStream_t)stream);
 }

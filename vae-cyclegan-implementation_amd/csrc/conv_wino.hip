@@ -55,7 +55,16 @@ struct WinoP {
   // operand of the GEMM as a pure copy — with s from the INPUT's amax: |B^T d B| <= 4 max|d|, so its scale is known before V is
   VcgAmax amax_x;
   unsigned short* vplanes;
+  // k_wino_in_planes / k_wino_in_tr, deferred InstanceNorm (vcg_conv_fwd_in_pre): x is the RAW output t of the previous conv and the
+  // gather normalises it on the way in — pre_act((t - mean[n][c]) * rstd[n][c]) — so the normalised tensor is never written
+  const float* pre_mean;
+  const float* pre_rstd;
+  int pre_act;
 };
+__device__ __forceinline__ float4 wino_pre_apply(const float4& v, const float4& mu, const float4& rs, int act) {
+  return make_float4(act_apply((v.x - mu.x) * rs.x, act), act_apply((v.y - mu.y) * rs.y, act), act_apply((v.z - mu.z) * rs.z, act),
+                     act_apply((v.w - mu.w) * rs.w, act));
+}
 
 __device__ __forceinline__ float4 f4sub(const float4& a, const float4& b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
 __device__ __forceinline__ float4 f4sum(const float4& a, const float4& b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
@@ -136,6 +145,11 @@ __global__ __launch_bounds__(256) void k_wino_in_planes(WinoP p) {
     const uint32_t ty = fd_div(rem, p.fd_tw);
     const int tx = (int)(rem - ty * (uint32_t)p.tw);
     const float* xn = p.x + (size_t)n * p.H * p.W * p.Cin;
+    float4 pmu = make_float4(0.f, 0.f, 0.f, 0.f), prs = pmu;
+    if (p.pre_mean) {
+      pmu = *reinterpret_cast<const float4*>(p.pre_mean + (size_t)n * p.Cin + c);
+      prs = *reinterpret_cast<const float4*>(p.pre_rstd + (size_t)n * p.Cin + c);
+    }
     float4 d[4][4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -151,6 +165,7 @@ __global__ __launch_bounds__(256) void k_wino_in_planes(WinoP p) {
         else ok = ok && iw >= 0 && iw < p.Wl;
         d[r][s] = ok ? *reinterpret_cast<const float4*>(xn + ((size_t)(ih * p.ups + pi) * p.W + (iw * p.ups + pj)) * p.Cin + c)
                      : make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p.pre_mean && ok) d[r][s] = wino_pre_apply(d[r][s], pmu, prs, p.pre_act);
       }
     }
     float4 e[4][4];
@@ -612,6 +627,11 @@ __global__ __launch_bounds__(256) void k_wino_in_tr(WinoP p, unsigned short* __r
   const uint32_t ty = fd_div(rem, p.fd_tw);
   const int tx = (int)(rem - ty * (uint32_t)p.tw);
   const float* xn = p.x + (size_t)n * p.H * p.W * p.Cin;
+  float4 pmu = make_float4(0.f, 0.f, 0.f, 0.f), prs = pmu;
+  if (p.pre_mean) {
+    pmu = *reinterpret_cast<const float4*>(p.pre_mean + (size_t)n * p.Cin + c);
+    prs = *reinterpret_cast<const float4*>(p.pre_rstd + (size_t)n * p.Cin + c);
+  }
   float4 d[4][4];
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
@@ -627,6 +647,7 @@ __global__ __launch_bounds__(256) void k_wino_in_tr(WinoP p, unsigned short* __r
       else ok = ok && iw >= 0 && iw < p.Wl;
       d[r][s] = ok ? *reinterpret_cast<const float4*>(xn + ((size_t)(ih * p.ups + pi) * p.W + (iw * p.ups + pj)) * p.Cin + c)
                    : make_float4(0.f, 0.f, 0.f, 0.f);
+      if (p.pre_mean && ok) d[r][s] = wino_pre_apply(d[r][s], pmu, prs, p.pre_act);
     }
   }
   float4 e[4][4];
@@ -736,7 +757,7 @@ int vcg_wino_weight(const ConvGeom& g, const float* w_oihw, float* u, const VcgA
 }
 
 static WinoP wino_params(const ConvGeom& g) {
-  WinoP p;
+  WinoP p = {};
   p.x = nullptr; p.v = nullptr; p.m = nullptr; p.bias = nullptr; p.y = nullptr;
   p.N = g.N; p.H = g.H; p.W = g.W; p.Cin = g.Cin; p.Cout = g.Cout; p.Hl = g.Hl; p.Wl = g.Wl; p.ups = g.ups;
   p.reflect = g.reflect; p.act = g.act; p.cout_log = g.cout_log;
@@ -747,6 +768,7 @@ static WinoP wino_params(const ConvGeom& g) {
   p.off = 1;
   p.amax_slot = nullptr; p.amax_gen = 0;
   p.amax_x = vcg_amax_const(0); p.vplanes = nullptr;
+  p.pre_mean = nullptr; p.pre_rstd = nullptr; p.pre_act = VCG_ACT_NONE;
   return p;
 }
 
@@ -864,7 +886,7 @@ int vcg_wino_dgrad(const ConvGeom& g, const float* dy, const float* ud, const vo
   VCG_CHECK_ARG(ws && ws_bytes >= vcg_wino_dgrad_workspace(g), "vcg_conv_dgrad: workspace too small for the Winograd path");
   const int kc = g.ups * g.ups * g.Cin;
   // input transform of dy: a plain (N, Ho, Wo, Cout) image, zero extension, patch origin 2 * tile - 2
-  WinoP p;
+  WinoP p = {};
   p.x = dy; p.bias = nullptr; p.y = nullptr;
   p.N = g.N; p.H = g.Ho; p.W = g.Wo; p.Cin = g.Cout; p.Cout = kc; p.Hl = g.Ho; p.Wl = g.Wo; p.ups = 1;
   p.reflect = 0; p.act = VCG_ACT_NONE; p.cout_log = kc;
@@ -906,21 +928,37 @@ size_t vcg_wino_fwd_stats_doubles(const ConvGeom& g) {
   return (size_t)g.N * pl.nchunk * g.Cout * 2;
 }
 // v_keep: where to leave V = B^T x B for the weight gradient (vcg_wino_saved_floats), instead of the workspace
+// `pre` (may be null): x is the raw output of the previous conv and is normalised in the input transform's gather (deferred
+// InstanceNorm, vcg_conv_fwd_in_pre).  Its amax is then not measured but BOUNDED: a normalised channel of HW values has
+// |xhat| <= sqrt(HW - 1) (and ReLU / LeakyReLU / Tanh / Sigmoid of it no more), typically 2^3..2^5 above the true maximum — the
+// fp16 pair keeps 22 bits for every element within 2^17 of the scale, so an element now needs to be within ~2^13 of the true
+// maximum to keep them all; smaller ones keep an absolute error of 2^-36 of the maximum, far under the fp32 rounding of any sum
+// they enter (the argument of vcg_common.h for the per-tensor scale).
+bool vcg_wino_pre_ok(const ConvGeom& g) { return vcg_wino_fwd_ok(g) && wino_planes_on(); }
 int vcg_wino_fwd(const ConvGeom& g, const float* x, const float* u, const void* w_amax, const float* bias, float* y, void* ws,
-                 size_t ws_bytes, hipStream_t st, double* in_part, const VcgInTail* tail_req, float* v_keep, uint64_t x_handle) {
+                 size_t ws_bytes, hipStream_t st, double* in_part, const VcgInTail* tail_req, float* v_keep, uint64_t x_handle,
+                 const VcgPre* pre) {
   VCG_CHECK_ARG(ws && ws_bytes >= vcg_wino_fwd_workspace(g), "vcg_conv_fwd: workspace too small for the Winograd path (%zu)",
                 ws_bytes);
   WinoP p = wino_params(g);
   float* V = v_keep ? v_keep : (float*)ws;
   float* M = (float*)ws + (((size_t)16 * p.T * p.Kc + 63) / 64) * 64;
   p.x = x; p.v = V; p.m = M; p.bias = bias; p.y = y;
+  uint32_t pre_bits = 0;
+  if (pre && pre->mean) {
+    VCG_CHECK_ARG(wino_planes_on(), "vcg_conv_fwd_in_pre: needs the planes mode");
+    p.pre_mean = pre->mean; p.pre_rstd = pre->rstd; p.pre_act = pre->act;
+    const float bound = sqrtf((float)g.H * (float)g.W);
+    memcpy(&pre_bits, &bound, 4);
+  }
   uint32_t* const keep_word = v_keep ? reinterpret_cast<uint32_t*>(v_keep + wino_v_floats(g)) : nullptr;
   if (v_keep && vcg_wino_wgrad_tr_ok(g)) {
     // this layer's weight gradient wants V TRANSPOSED (vcg_wino_wgrad): one transform kernel writes the forward's planes into
     // the workspace and the transposed ones into the caller's buffer
     VCG_CHECK_ARG(wino_planes_on(), "VCG_WINO_PLANES=0 needs VCG_WGRAD_TR=0");
     VcgAmax ax;
-    if (vcg_operand_amax(x, (size_t)g.N * g.H * g.W * g.Cin, x_handle, WINO_V_SHIFT, st, &ax)) return -2;
+    if (pre_bits) ax = vcg_amax_const(pre_bits, WINO_V_SHIFT);
+    else if (vcg_operand_amax(x, (size_t)g.N * g.H * g.W * g.Cin, x_handle, WINO_V_SHIFT, st, &ax)) return -2;
     V = (float*)ws;
     p.v = V; p.amax_x = ax; p.vplanes = (unsigned short*)V;
     hipLaunchKernelGGL(k_wino_in_tr, dim3(p.T / 32, p.Kc / 32), dim3(256), 0, st, p, (unsigned short*)v_keep);
@@ -928,7 +966,8 @@ int vcg_wino_fwd(const ConvGeom& g, const float* x, const float* u, const void* 
     if (vcg_gemm_planes_batched(V, u, M, p.T, p.Kc, g.Cout, 16, ax, vcg_amax_stored(w_amax, WINO_U_SHIFT), st, keep_word)) return -2;
   } else if (wino_planes_on()) {
     VcgAmax ax;
-    if (vcg_operand_amax(x, (size_t)g.N * g.H * g.W * g.Cin, x_handle, WINO_V_SHIFT, st, &ax)) return -2;
+    if (pre_bits) ax = vcg_amax_const(pre_bits, WINO_V_SHIFT);
+    else if (vcg_operand_amax(x, (size_t)g.N * g.H * g.W * g.Cin, x_handle, WINO_V_SHIFT, st, &ax)) return -2;
     p.amax_x = ax; p.vplanes = (unsigned short*)V;
     hipLaunchKernelGGL(k_wino_in_planes, dim3(wino_blocks((size_t)p.T * p.Kc / 4)), dim3(256), 0, st, p);
     VCG_LAUNCH_CHECK("vcg_conv_fwd(winograd input transform)");

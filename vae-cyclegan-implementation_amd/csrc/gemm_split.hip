@@ -261,7 +261,15 @@ int vcg_gd_set_stamp(void* buf) { return hipMemcpyToSymbol(HIP_SYMBOL(g_gd_stamp
 // tiles x one 32-deep slice — the same fragment bytes, LDS reads, accumulator registers and matrix-pipe cycles, but the chip,
 // which answers an MFMA-dense loop with a lower clock (1.15-1.76 GHz here: profiles/r03_gemm_dma_stamps.txt), holds a higher one on
 // the 16 x 16 shape (MI355X_MICROARCH.md, DVFS item 7)
-template <bool GD_SPREAD, int SHAPE>
+// STAG (SHAPE 16 only; round 4): the two waves that share a SIMD (wave w and w + 4 of the workgroup) run half a K-step apart.
+// Measured from the instruction stream (profiles/r04_power_probe.txt has the clocks; the ISA: all 16 ds_read_b128 of a step are
+// issued right behind the barrier, by all 8 waves at once): a K-step was an LDS phase — 8 waves x 16 KB of fragments + 48 KB of
+// DMA writes at 128 B / clock: ~1 400 clocks with the matrix pipe idle — followed by a matrix phase (2 x 768 clocks per SIMD)
+// with the LDS idle.  With STAG the waves 4..7 keep the fragments of step kt in registers across the barrier and multiply them
+// in the FIRST half of interval kt + 1, while the waves 0..3 read theirs; in the second half the roles swap.  Same barriers, same
+// ring (stage kt is read in interval kt by both halves; the DMAs of interval kt overwrite the stage read in interval kt - 1), same
+// registers, same order of accumulation in every wave: bit-identical results.
+template <bool GD_SPREAD, int SHAPE, bool STAG = false>
 __global__ __launch_bounds__(512, 1) void k_gemm_planes_dma(GemmSplitP p) {
   constexpr int MI = 2, NI = 2;
   __shared__ __attribute__((aligned(1024))) unsigned char smem[GD_STAGES * GD_STAGE];
@@ -359,21 +367,59 @@ __global__ __launch_bounds__(512, 1) void k_gemm_planes_dma(GemmSplitP p) {
   if (nkt > 1) issue(1, 1);
   unsigned long long gd_t = GD_T();
   (void)gd_t;
+  // SHAPE 16 fragments live across the loop (STAG: the late half multiplies step kt - 1 while it is in iteration kt)
+  f16x8 a16[VCG_NP][4], b16[VCG_NP][4];
+  auto read16 = [&](int kt) {
+    const unsigned char* st = smem + (kt % GD_STAGES) * GD_STAGE;
+#pragma unroll
+    for (int pc = 0; pc < VCG_NP; ++pc) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        a16[pc][i] = *reinterpret_cast<const f16x8*>(st + fa16[i] + (((pc * 4 + kq) ^ sa16[i]) << 4));
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        b16[pc][j] = *reinterpret_cast<const f16x8*>(st + fb16[j] + (((pc * 4 + kq) ^ sb16[j]) << 4));
+    }
+  };
+  // the 48 MFMAs of one K-step on the fragments in registers; the six DMAs of stage `dkt` (if dkt < nkt) go out one at a time
+  // between the MFMA groups: an LDS-DMA costs the issuing wave 60-185 cycles (MI355X_MICROARCH.md), spread out it sits beside
+  // the partner wave's MFMAs
+  auto mma16 = [&](int dkt) {
+    const bool more = dkt < nkt;
+    const int nstage = dkt % GD_STAGES;
+    int q = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        f32x4 c = lo16[i][j];
+        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a16[1][i], b16[0][j], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a16[0][i], b16[1][j], c, 0, 0, 0);
+        lo16[i][j] = c;
+        acc16[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a16[0][i], b16[0][j], acc16[i][j], 0, 0, 0);
+        if (GD_SPREAD && (j & 1) && q < 6) {                                   // after every second group: 8 slots for 6 DMAs
+          __builtin_amdgcn_sched_barrier(0);
+          if (more) issue_one(nstage, dkt, q);
+          __builtin_amdgcn_sched_barrier(0);
+          ++q;
+        }
+      }
+    if (!GD_SPREAD && more) issue(nstage, dkt);
+  };
+  const bool late = STAG && wid >= 4;                                       // wave-uniform
   for (int kt = 0; kt < nkt; ++kt) {
     if (kt + 1 < nkt) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");      // my six DMAs of stage kt have landed; stage kt + 1's stay in flight
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     GD_ACC(0, gd_t);
     gd_barrier();                                                           // everybody's have; everybody is done with stage kt - 1
     GD_ACC(1, gd_t);
-    // The six DMAs of stage kt + 2 are issued ONE AT A TIME between the MFMA groups of this step, not in a burst behind the
-    // barrier: an LDS-DMA costs the issuing wave 60-185 cycles (MI355X_MICROARCH.md), and the two waves of a SIMD leave the
-    // barrier together — in a burst both stall on their DMAs at once and the matrix pipe idles; spread out, one wave's DMA sits
-    // beside its partner's MFMAs.
-    const bool more = kt + 2 < nkt;
-    const int nstage = (kt + 2) % GD_STAGES;
-    const unsigned char* st = smem + (kt % GD_STAGES) * GD_STAGE;
-    int q = 0;
     if constexpr (SHAPE == 32) {
+      // The six DMAs of stage kt + 2 are issued ONE AT A TIME between the MFMA groups of this step, not in a burst behind the
+      // barrier (see mma16)
+      const bool more = kt + 2 < nkt;
+      const int nstage = (kt + 2) % GD_STAGES;
+      const unsigned char* st = smem + (kt % GD_STAGES) * GD_STAGE;
+      int q = 0;
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
         f16x8 a[VCG_NP][MI], b[VCG_NP][NI];
@@ -403,36 +449,25 @@ __global__ __launch_bounds__(512, 1) void k_gemm_planes_dma(GemmSplitP p) {
             }
           }
       }
+      if (!GD_SPREAD && more) issue(nstage, kt + 2);
+    } else if (!late) {
+      read16(kt);
+      mma16(kt + 2);
     } else {
-      f16x8 a[VCG_NP][4], b[VCG_NP][4];
-#pragma unroll
-      for (int pc = 0; pc < VCG_NP; ++pc) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-          a[pc][i] = *reinterpret_cast<const f16x8*>(st + fa16[i] + (((pc * 4 + kq) ^ sa16[i]) << 4));
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          b[pc][j] = *reinterpret_cast<const f16x8*>(st + fb16[j] + (((pc * 4 + kq) ^ sb16[j]) << 4));
-      }
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          f32x4 c = lo16[i][j];
-          c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[1][i], b[0][j], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[0][i], b[1][j], c, 0, 0, 0);
-          lo16[i][j] = c;
-          acc16[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[0][i], b[0][j], acc16[i][j], 0, 0, 0);
-          if (GD_SPREAD && (j & 1) && q < 6) {                                   // after every second group: 8 slots for 6 DMAs
-            __builtin_amdgcn_sched_barrier(0);
-            if (more) issue_one(nstage, kt + 2, q);
-            __builtin_amdgcn_sched_barrier(0);
-            ++q;
-          }
-        }
+      // the late half: multiply step kt - 1 (fragments read in the previous interval) under the early half's reads, then read
+      // step kt under the early half's MFMAs.  Its DMAs of stage kt + 2 go out in the same interval as the early half's.
+      if (kt > 0) mma16(kt + 2);
+      else if (kt + 2 < nkt) issue((kt + 2) % GD_STAGES, kt + 2);
+      __builtin_amdgcn_sched_barrier(0);
+      read16(kt);
     }
-    if (!GD_SPREAD && more) issue(nstage, kt + 2);
     GD_ACC(2, gd_t);
+  }
+  if constexpr (SHAPE == 16) {
+    if (late) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      mma16(nkt);                                                            // the last step's products (no DMA left to issue)
+    }
   }
   float* const dst = p.c + (size_t)zb * p.c_bstride;
   const float os = sa_ * sb_;
@@ -526,7 +561,11 @@ int vcg_gemm_planes_batched(const void* APlanes, const void* BtPlanes, float* C,
     static const int spread = [] { const char* e = getenv("VCG_GEMM_SPREAD"); return e ? atoi(e) : 1; }();
     // VCG_GEMM_SHAPE=32: v_mfma_f32_32x32x16_f16 tiles (A/B measurements)
     static const int shape = [] { const char* e = getenv("VCG_GEMM_SHAPE"); return e ? atoi(e) : 16; }();
-    if (shape == 16) {
+    // VCG_GEMM_STAGGER=0: both waves of a SIMD in lockstep, as in round 3 (A/B measurements)
+    static const int stagger = [] { const char* e = getenv("VCG_GEMM_STAGGER"); return e ? atoi(e) : 1; }();
+    if (shape == 16 && stagger && spread) {
+      hipLaunchKernelGGL((k_gemm_planes_dma<true, 16, true>), grid, dim3(512), 0, st, p);
+    } else if (shape == 16) {
       if (spread) hipLaunchKernelGGL((k_gemm_planes_dma<true, 16>), grid, dim3(512), 0, st, p);
       else hipLaunchKernelGGL((k_gemm_planes_dma<false, 16>), grid, dim3(512), 0, st, p);
     } else {

@@ -395,9 +395,12 @@ bool vcg_wino_fwd_ok(const ConvGeom& g);
 size_t vcg_wino_weight_floats(const ConvGeom& g);
 size_t vcg_wino_fwd_workspace(const ConvGeom& g);
 int vcg_wino_weight(const ConvGeom& g, const float* w_oihw, float* u, const VcgAmax& amax_w, hipStream_t st);
+// deferred InstanceNorm of a conv's INPUT (vcg_conv_fwd_in_pre): mean / rstd [N][Cin] and the activation that follows the norm
+struct VcgPre { const float* mean; const float* rstd; int act; };
+bool vcg_wino_pre_ok(const ConvGeom& g);
 int vcg_wino_fwd(const ConvGeom& g, const float* x, const float* u, const void* w_amax, const float* bias, float* y, void* ws,
                  size_t ws_bytes, hipStream_t st, double* in_part = nullptr, const VcgInTail* tail = nullptr, float* v_keep = nullptr,
-                 uint64_t x_handle = 0);
+                 uint64_t x_handle = 0, const VcgPre* pre = nullptr);
 size_t vcg_wino_saved_floats(const ConvGeom& g);
 size_t vcg_wino_fwd_stats_doubles(const ConvGeom& g);
 // Winograd weight gradient: transforms in conv_wino.hip, batched stream-K reduction + back-transform in conv_igemm.hip

@@ -404,6 +404,60 @@ def _grad_buffer(param):
     return g
 
 
+# ------------------------------------------------------------------ deferred InstanceNorm (the fused Conv + IN + act hand-off)
+# A block whose only consumer is the next block's convolution can hand over its RAW conv output with the statistics instead of the
+# normalised tensor: `conv_block(..., defer=True)` returns a tensor whose storage is allocated but NOT written, tagged with
+# (t, mean, rstd, post_act); a `conv_block` that receives it normalises inside its own input gather (include/vcg.h,
+# vcg_conv_fwd_in_pre) where that exists for its geometry, and otherwise fills the storage first (`materialize`) — so every
+# conv_block consumer is correct either way, and nothing else may be handed a deferred tensor (Networks.py defers only between
+# the blocks of one Encoder / inside R).  VCG_DEFER_NORM=0: never defer (A/B measurements).
+DEFER_NORM = os.environ.get("VCG_DEFER_NORM", "1") != "0"
+_PRE_OK = {}
+
+
+def _lazy_of(x):
+    tag = getattr(x, "_vcg_lazy", None)
+    if tag is None:
+        return None
+    t, mean, rstd, act, ver, ptr = tag
+    if ver != x._version or ptr != x.data_ptr():
+        raise RuntimeError("a deferred-InstanceNorm tensor was written to before its consumer ran")
+    return tag
+
+
+def materialize(x):
+    """Fill a deferred tensor's storage with the normalised values (what the producer would have written)."""
+    tag = _lazy_of(x)
+    if tag is None:
+        return x
+    t, mean, rstd, act, _, _ = tag
+    xp = phys_of(x)
+    n, h, w, c = xp.shape
+    amax = ctypes.c_uint64(0)
+    with _timed("in_fwd"):
+        _native.check(_native.lib().vcg_in_apply_h(_ptr(t), _ptr(mean), _ptr(rstd), None, _ptr(xp), n, h, w, c, act, 0,
+                                                   ctypes.byref(amax), _stream()), "vcg_in_apply")
+    del x._vcg_lazy
+    if AMAX_HANDLES:
+        _amax_tag(x, amax.value)
+    return x
+
+
+def consumer_takes_deferred(spec, n, h, w, needs_wgrad=True):
+    """Would `conv_block(x, ..., spec)` on an (n, C, h, w) input normalise a deferred x in its gather?  (Asked by the producer's
+    caller before deferring: a deferral the consumer cannot use costs nothing but buys nothing.)"""
+    if not DEFER_NORM:
+        return False
+    key = (id(spec), n, h, w)
+    ok = _PRE_OK.get(key)
+    if ok is None:
+        lib = _native.lib()
+        cd = spec.desc(n, h, w)
+        ok = bool(lib.vcg_conv_pre_ok(cd)), int(lib.vcg_conv_saved_floats(cd)) > 0
+        _PRE_OK[key] = ok
+    return ok[0] and (ok[1] and KEEP_FORWARD_STATE or not needs_wgrad)
+
+
 class _ConvBlockFn(torch.autograd.Function):
     """conv(+bias)(+act) -> [InstanceNorm (+act) (+residual) (+PixelShuffle store)].
 
@@ -412,8 +466,15 @@ class _ConvBlockFn(torch.autograd.Function):
     """
 
     @staticmethod
-    def forward(ctx, x, weight, bias, residual, spec, wparam, bparam):
+    def forward(ctx, x, weight, bias, residual, spec, wparam, bparam, defer=False):
         lib = _native.lib()
+        lazy = _lazy_of(x)
+        if lazy is not None:
+            xs = x.shape
+            wants_wgrad = wparam is not None and wparam.requires_grad and ctx.needs_input_grad[1]
+            if not consumer_takes_deferred(spec, xs[0], xs[2], xs[3], wants_wgrad):
+                materialize(x)
+                lazy = None
         xp = as_phys(x)
         n, h, w, pin = xp.shape
         if pin != spec.cin_pitch:
@@ -428,8 +489,8 @@ class _ConvBlockFn(torch.autograd.Function):
         mean = rstd = saved = None
         # operand magnitudes (include/vcg.h): the block that wrote x left a handle to its largest magnitude on the tensor; the
         # kernels scale x by it instead of measuring x again (0: unknown, they measure)
-        x_amax = _amax_of(x)
-        if not x_amax and AMAX_HANDLES:
+        x_amax = _amax_of(x) if lazy is None else 0
+        if not x_amax and AMAX_HANDLES and lazy is None:
             x_amax = _measured_amax(xp)
             _amax_tag(x, x_amax)              # a second convolution of this very tensor object (mu and logvar read one map)
         out_amax = ctypes.c_uint64(0)
@@ -447,8 +508,13 @@ class _ConvBlockFn(torch.autograd.Function):
             rstd = torch.empty((n, c), dtype=torch.float32, device=dev)
             with _timed("conv_fwd", flops, tag):
                 ws = workspace(lib.vcg_conv_fwd_in_workspace(cd), dev)
-                _native.check(lib.vcg_conv_fwd_in_h(_ptr(xp), _ptr(wf), _ptr(bias), _ptr(t), _ptr(mean), _ptr(rstd), IN_EPS,
-                                                    _ptr(saved), cd, _ptr(ws), ws.numel() * 4, x_amax, _stream()), "vcg_conv_fwd_in")
+                if lazy is not None:
+                    _native.check(lib.vcg_conv_fwd_in_pre(_ptr(lazy[0]), _ptr(lazy[1]), _ptr(lazy[2]), lazy[3], _ptr(wf), _ptr(bias),
+                                                          _ptr(t), _ptr(mean), _ptr(rstd), IN_EPS, _ptr(saved), cd, _ptr(ws),
+                                                          ws.numel() * 4, _stream()), "vcg_conv_fwd_in_pre")
+                else:
+                    _native.check(lib.vcg_conv_fwd_in_h(_ptr(xp), _ptr(wf), _ptr(bias), _ptr(t), _ptr(mean), _ptr(rstd), IN_EPS,
+                                                        _ptr(saved), cd, _ptr(ws), ws.numel() * 4, x_amax, _stream()), "vcg_conv_fwd_in")
             resp = as_phys(residual) if residual is not None else None
             if spec.shuffle:
                 outp = torch.empty((n, 2 * ho, 2 * wo, c // 4), dtype=torch.float32, device=dev)
@@ -456,16 +522,24 @@ class _ConvBlockFn(torch.autograd.Function):
             else:
                 outp = torch.empty((n, ho, wo, c), dtype=torch.float32, device=dev)
                 cout_log = spec.cout
-            with _timed("in_fwd"):
-                _native.check(lib.vcg_in_apply_h(_ptr(t), _ptr(mean), _ptr(rstd), _ptr(resp), _ptr(outp), n, ho, wo, c,
-                                                 spec.post_act, int(spec.shuffle), ctypes.byref(out_amax), _stream()), "vcg_in_apply")
+            if defer and (residual is not None or spec.shuffle):
+                raise RuntimeError("a block with a residual or a shuffled store cannot defer its InstanceNorm")
+            if not defer:
+                with _timed("in_fwd"):
+                    _native.check(lib.vcg_in_apply_h(_ptr(t), _ptr(mean), _ptr(rstd), _ptr(resp), _ptr(outp), n, ho, wo, c,
+                                                     spec.post_act, int(spec.shuffle), ctypes.byref(out_amax), _stream()), "vcg_in_apply")
         else:
             if residual is not None or spec.shuffle or spec.post_act:
                 raise RuntimeError("residual/shuffle/post_act need norm=True")
             with _timed("conv_fwd", flops, tag):
                 ws = workspace(lib.vcg_conv_fwd_workspace(cd), dev)
-                _native.check(lib.vcg_conv_fwd_in_h(_ptr(xp), _ptr(wf), _ptr(bias), _ptr(t), None, None, IN_EPS, _ptr(saved), cd,
-                                                    _ptr(ws), ws.numel() * 4, x_amax, _stream()), "vcg_conv_fwd_in")
+                if lazy is not None:
+                    _native.check(lib.vcg_conv_fwd_in_pre(_ptr(lazy[0]), _ptr(lazy[1]), _ptr(lazy[2]), lazy[3], _ptr(wf), _ptr(bias),
+                                                          _ptr(t), None, None, IN_EPS, _ptr(saved), cd, _ptr(ws), ws.numel() * 4,
+                                                          _stream()), "vcg_conv_fwd_in_pre")
+                else:
+                    _native.check(lib.vcg_conv_fwd_in_h(_ptr(xp), _ptr(wf), _ptr(bias), _ptr(t), None, None, IN_EPS, _ptr(saved), cd,
+                                                        _ptr(ws), ws.numel() * 4, x_amax, _stream()), "vcg_conv_fwd_in")
             outp, cout_log = t, spec.cout
         ctx.spec, ctx.cd, ctx.dims, ctx.flops, ctx.tag = spec, cd, (n, h, w, ho, wo), flops, tag
         ctx.wparam, ctx.bparam = wparam, bparam
@@ -475,7 +549,11 @@ class _ConvBlockFn(torch.autograd.Function):
         ctx.x_amax, ctx.x_key = x_amax, (xp._version, xp.data_ptr())
         ctx.save_for_backward(xp, t, mean, rstd, wf)
         out = logical_of(outp, cout_log)
-        if AMAX_HANDLES:
+        ctx.x_deferred = lazy is not None
+        if defer and spec.norm:
+            # the storage of `out` stays unwritten: its consumer normalises t in its own gather, or fills it (materialize)
+            out._vcg_lazy = (t, mean, rstd, spec.post_act, out._version, out.data_ptr())
+        elif AMAX_HANDLES:
             _amax_tag(out, out_amax.value)    # for the block that consumes this very tensor object
         return out
 
@@ -525,6 +603,9 @@ class _ConvBlockFn(torch.autograd.Function):
                 # is identically zero (the reference's autograd returns rounding noise of ~1e-9 there: the column sums of
                 # a dt whose columns sum to zero) — the buffer stays at its zeros and the column-sum kernels are not run
                 gb = None
+            if ctx.x_deferred and saved is None:
+                raise RuntimeError("the weight gradient of a layer that took a deferred-InstanceNorm input needs the forward's kept "
+                                   "state (a second backward through the same graph, or VCG_KEEP_FORWARD_STATE=0 set after the forward)")
             wsb = lib.vcg_conv_wgrad_workspace(cd)
 
             def run_wgrad():
@@ -555,12 +636,14 @@ class _ConvBlockFn(torch.autograd.Function):
                 _native.check(lib.vcg_conv_dgrad_h(_ptr(dt), _ptr(wf), _ptr(dxp), cd, _ptr(ws), ws.numel() * 4, dt_amax,
                                                    _stream()), "vcg_conv_dgrad")
             dx = logical_of(dxp, spec.cin_phys_log)
-        return dx, None, None, d_res, None, None, None
+        return dx, None, None, d_res, None, None, None, None
 
 
-def conv_block(x, weight, bias, spec, residual=None):
+def conv_block(x, weight, bias, spec, residual=None, defer=False):
+    """`defer`: hand the InstanceNorm's application over to the consumer (see "deferred InstanceNorm" above); only for a
+    result whose sole consumer is another conv_block."""
     _require_gpu(x, "conv_block")
-    return _ConvBlockFn.apply(x, weight, bias, residual, spec, weight, bias)
+    return _ConvBlockFn.apply(x, weight, bias, residual, spec, weight, bias, bool(defer and DEFER_NORM and spec.norm))
 
 
 class _PixelShuffleFn(torch.autograd.Function):
