@@ -194,6 +194,13 @@ int vcg_in_bwd(const float* g, const float* t, const float* mean, const float* r
 int vcg_in_bwd_h(const float* g, const float* t, const float* mean, const float* rstd, float* dt,
                  int N, int H, int W, int C, int epi_act, int post_act, int shuffle,
                  void* ws, size_t ws_bytes, uint64_t* dt_amax, void* stream);
+/* vcg_in_bwd that also ACCUMULATES sum over (n, pixel) of dt into gbias[0 .. c_log): the bias gradient of the convolution in front
+   of this InstanceNorm when an activation sits between the two (conv -> ReLU -> IN, Networks.py:93-95, 110-111, 128-130; with no
+   activation between them it is identically zero) — from the pass that writes dt, instead of a pass of its own inside
+   vcg_conv_wgrad (hand that call gbias = NULL).  dt_amax: as vcg_in_bwd_h (may be NULL).  Same workspace. */
+int vcg_in_bwd_bias(const float* g, const float* t, const float* mean, const float* rstd, float* dt,
+                    int N, int H, int W, int C, int epi_act, int post_act, int shuffle, float* gbias, int c_log,
+                    void* ws, size_t ws_bytes, uint64_t* dt_amax, void* stream);
 /* nn.PixelShuffle(2) — Networks.py:121 — as a copy: (N,H,W,C) -> (N,2H,2W,C/4); inverse=1 is its backward */
 int vcg_pixel_shuffle(const float* src, float* dst, int N, int H, int W, int C, int inverse, void* stream);
 /* dt = g * act'(t) where t is the activation OUTPUT (blocks without a norm). */

@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 # VCG_LIBVCG: load another build of the same sources (A/B runs of kernel variants, tools/); the default is the in-tree library
 LIB_PATH = os.environ.get("VCG_LIBVCG") or os.path.join(_HERE, "libvcg.so")
-SOURCES = ["conv_igemm.hip", "conv_thin.hip", "conv_wino.hip", "conv_slab.hip", "conv_ring.hip", "gemm_split.hip", "norm.hip", "misc.hip", "input.hip"]
+SOURCES = ["conv_igemm.hip", "conv_thin.hip", "conv_thinin.hip", "conv_wino.hip", "conv_slab.hip", "conv_ring.hip", "gemm_split.hip", "norm.hip", "misc.hip", "input.hip"]
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "vcg.h")
 
 _c = ctypes
@@ -36,6 +36,7 @@ SIGNATURES = {
     "vcg_conv_wgrad_saved_h": (_I, [_P, _P, _P, _P, _P, _I32P, _P, _Z, _U64, _U64, _P]),
     "vcg_in_apply_h": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _U64P, _P]),
     "vcg_in_bwd_h": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _Z, _U64P, _P]),
+    "vcg_in_bwd_bias": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P, _Z, _U64P, _P]),
     "vcg_act_bwd_h": (_I, [_P, _P, _P, _Z, _I, _U64P, _P]),
     "vcg_profile_enable": (_I, [_I]),
     "vcg_profile_read": (_c.c_long, [_c.c_char_p, _Z]),

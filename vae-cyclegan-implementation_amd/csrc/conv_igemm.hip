@@ -2251,7 +2251,7 @@ extern "C" size_t vcg_conv_fwd_workspace(const int32_t* cd) {
   ConvGeom g;
   if (vcg_conv_geom(cd, &g, "vcg_conv_fwd_workspace")) return 0;
   if (vcg_thin_fold_ok(g)) return vcg_thin_fold_workspace(g);
-  if (vcg_thin_fwd_ok(g)) return 0;
+  if (vcg_thin_fwd_ok(g) || vcg_thinin_fwd_ok(g)) return 0;
   if (vcg_wino_fwd_ok(g)) return vcg_wino_fwd_workspace(g);
   if (fwd_slab_ok(g)) return 0;
   int bm, bn, nsplit, kt_per;
@@ -2267,7 +2267,7 @@ static int ew_grid(size_t work) {
 
 // does the direct split-operand forward leave the InstanceNorm partials itself?  (every 128-row tile inside one image)
 static bool fwd_tile_stats_ok(const ConvGeom& g) {
-  if (vcg_thin_fold_ok(g) || vcg_thin_fwd_ok(g) || vcg_wino_fwd_ok(g) || fwd_slab_ok(g)) return false;
+  if (vcg_thin_fold_ok(g) || vcg_thin_fwd_ok(g) || vcg_thinin_fwd_ok(g) || vcg_wino_fwd_ok(g) || fwd_slab_ok(g)) return false;
   int bm, bn, nsplit, kt_per;
   fwd_plan(g, bm, bn, nsplit, kt_per);
   return bm == 128 && bn >= 64 && nsplit == 1 && wft_wanted(g) && (g.Ho * g.Wo) % 128 == 0;
@@ -2288,6 +2288,13 @@ static int conv_fwd_impl(const float* x, const float* wf, const float* bias, flo
                   "vcg_conv_fwd_in_pre: this geometry has no normalising gather (ask vcg_conv_pre_ok first)");
   if (vcg_thin_fold_ok(g)) return vcg_thin_fold_fwd(g, x, wf + wf_floats(g), vcg_pack_amax(g, wf), bias, y, ws, ws_bytes, (hipStream_t)stream, x_handle);
   if (vcg_thin_fwd_ok(g)) return vcg_thin_fwd(g, x, wf, bias, y, (hipStream_t)stream);
+  if (vcg_thinin_fwd_ok(g)) {
+    if (vcg_thinin_fwd(g, x, wf, vcg_pack_amax(g, wf), bias, y, in_part, (hipStream_t)stream, x_handle)) return -2;
+    if (in_part)
+      return vcg_in_finalize(in_part, tail_req->out1, tail_req->out2, g.N, tail_req->HW, g.Cout, vcg_thinin_nchunk(g), tail_req->eps,
+                             (hipStream_t)stream);
+    return 0;
+  }
   if (vcg_wino_fwd_ok(g))
     return vcg_wino_fwd(g, x, wf + wf_floats(g), vcg_pack_amax(g, wf), bias, y, ws, ws_bytes, (hipStream_t)stream, in_part, tail_req, saved, x_handle,
                         pre);
@@ -2352,7 +2359,9 @@ extern "C" size_t vcg_conv_fwd_in_workspace(const int32_t* cd) {
   ConvGeom g;
   if (vcg_conv_geom(cd, &g, "vcg_conv_fwd_in_workspace")) return 0;
   size_t part;
-  if (vcg_wino_fwd_ok(g)) part = vcg_wino_fwd_stats_doubles(g) * sizeof(double);
+  const bool thinin = !vcg_thin_fold_ok(g) && !vcg_thin_fwd_ok(g) && vcg_thinin_fwd_ok(g);
+  if (thinin) part = (size_t)g.N * vcg_thinin_nchunk(g) * g.Cout * 2 * sizeof(double);
+  else if (vcg_wino_fwd_ok(g)) part = vcg_wino_fwd_stats_doubles(g) * sizeof(double);
   else if (fwd_slab_ok(g) && vcg_slab_fwd_stats_ok(g)) part = (size_t)g.N * vcg_slab_fwd_nchunk(g) * g.Cout * 2 * sizeof(double);
   else if (fwd_tile_stats_ok(g)) part = (size_t)g.N * (g.Ho * g.Wo / 128) * g.Cout * 2 * sizeof(double);
   else part = vcg_in_workspace(g.N, g.Ho * g.Wo, g.Cout);
@@ -2403,7 +2412,8 @@ static int conv_fwd_in_impl(const float* x, const float* wf, const float* bias, 
   VCG_CHECK_ARG(ws_bytes >= vcg_conv_fwd_in_workspace(cd), "vcg_conv_fwd_in: workspace too small (%zu)", ws_bytes);
   const size_t cws = fwd_in_conv_ws(cd);
   double* part = reinterpret_cast<double*>(static_cast<char*>(ws) + cws);
-  const bool fused = vcg_wino_fwd_ok(g) || (fwd_slab_ok(g) && vcg_slab_fwd_stats_ok(g)) || fwd_tile_stats_ok(g);
+  const bool thinin = !vcg_thin_fold_ok(g) && !vcg_thin_fwd_ok(g) && vcg_thinin_fwd_ok(g);
+  const bool fused = thinin || vcg_wino_fwd_ok(g) || (fwd_slab_ok(g) && vcg_slab_fwd_stats_ok(g)) || fwd_tile_stats_ok(g);
   // fused: the conv's epilogue leaves the partials and its last block per (image, channel range) finalizes them
   VcgInTail req = vcg_in_tail_none();
   req.out1 = mean; req.out2 = rstd; req.HW = g.Ho * g.Wo; req.eps = eps;
@@ -2434,7 +2444,7 @@ static int dgrad_setup(const ConvGeom& g, ConvP& p, int& bm, int& bn, int& nspli
 // does the forward / the data gradient at this geometry read the fp32 Wf block?  (mirrors conv_fwd_impl and vcg_conv_dgrad)
 static bool fwd_reads_wf(const ConvGeom& g) {
   if (vcg_thin_fold_ok(g)) return false;
-  if (vcg_thin_fwd_ok(g)) return true;
+  if (vcg_thin_fwd_ok(g) || vcg_thinin_fwd_ok(g)) return true;
   if (vcg_wino_fwd_ok(g) || fwd_slab_ok(g)) return false;
   int bm, bn, nsplit, kt_per;
   fwd_plan(g, bm, bn, nsplit, kt_per);

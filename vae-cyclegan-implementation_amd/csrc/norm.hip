@@ -238,6 +238,98 @@ __global__ __launch_bounds__(256) void k_in_bwd_apply(const float* __restrict__ 
   if (amax_slot) vcg_amax_publish(amax, amax_slot, amax_gen, amax_red);
 }
 
+// The same dt, by the workgroups of k_in_partial (one pixel chunk x TC channel quads of one image), which lets the kernel leave
+// the COLUMN SUMS of what it writes: the bias gradient of the conv in front of this InstanceNorm is sum over pixels of dt
+// (conv -> ReLU -> IN blocks: D, U, R.conv1 — /root/reference/Networks.py:93-95), which used to be a pass of its own over dt
+// (k_colsum_partial: 64 launches and ~2 GB per CycleVAEGAN step).  colpart[(n * nchunk + chunk) * C + c], summed in a fixed
+// order by k_in_colsum_final.
+__global__ __launch_bounds__(256) void k_in_bwd_apply_cs(const float* __restrict__ g, const float* __restrict__ t,
+                                                         const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                         const float* __restrict__ s12, float* __restrict__ dt,
+                                                         float* __restrict__ colpart, int H, int W, int C, NormPlan pl, int epi_act,
+                                                         int post_act, int shuffle, unsigned long long* amax_slot, uint32_t amax_gen) {
+  __shared__ float4 red[256];
+  __shared__ uint32_t amax_red[4];
+  uint32_t amax = 0;
+  const int tc = threadIdx.x % pl.TC, tp = threadIdx.x / pl.TC;
+  const int c4 = blockIdx.z * pl.TC + tc;
+  const int n = blockIdx.y;
+  const int HW = H * W;
+  const int pb = blockIdx.x * pl.chunk;
+  int pe = pb + pl.chunk;
+  if (pe > HW) pe = HW;
+  float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (c4 * 4 < C) {
+    const float4 mu = *reinterpret_cast<const float4*>(mean + (size_t)n * C + c4 * 4);
+    const float4 rs = *reinterpret_cast<const float4*>(rstd + (size_t)n * C + c4 * 4);
+    const float* sp = s12 + ((size_t)n * C + c4 * 4) * 2;
+    const float4 sa = *reinterpret_cast<const float4*>(sp), sb = *reinterpret_cast<const float4*>(sp + 4);   // (s1, s2) of channels 0, 1 | 2, 3
+    const int C4 = C / 4;
+    for (int pix = pb + tp; pix < pe; pix += pl.TP) {
+      const size_t off = ((size_t)n * HW + pix) * C + c4 * 4;
+      const float4 v = *reinterpret_cast<const float4*>(t + off);
+      float4 gv;
+      if (shuffle) {
+        const int h = pix / W, w = pix - h * W;
+        const float* gp = g + (((size_t)n * 2 * H + 2 * h) * (2 * W) + 2 * w) * C4 + c4;
+        gv.x = gp[0];
+        gv.y = gp[C4];
+        gv.z = gp[(size_t)2 * W * C4];
+        gv.w = gp[(size_t)2 * W * C4 + C4];
+      } else {
+        gv = *reinterpret_cast<const float4*>(g + off);
+      }
+      float xh, gg;
+      float4 o;
+      xh = (v.x - mu.x) * rs.x; gg = gv.x * act_grad_from_in(xh, post_act);
+      o.x = act_grad_from_out(v.x, epi_act) * rs.x * (gg - sa.x - xh * sa.y);
+      xh = (v.y - mu.y) * rs.y; gg = gv.y * act_grad_from_in(xh, post_act);
+      o.y = act_grad_from_out(v.y, epi_act) * rs.y * (gg - sa.z - xh * sa.w);
+      xh = (v.z - mu.z) * rs.z; gg = gv.z * act_grad_from_in(xh, post_act);
+      o.z = act_grad_from_out(v.z, epi_act) * rs.z * (gg - sb.x - xh * sb.y);
+      xh = (v.w - mu.w) * rs.w; gg = gv.w * act_grad_from_in(xh, post_act);
+      o.w = act_grad_from_out(v.w, epi_act) * rs.w * (gg - sb.z - xh * sb.w);
+      *reinterpret_cast<float4*>(dt + off) = o;
+      amax = max(amax, vcg_abs_bits4(o));
+      cs.x += o.x; cs.y += o.y; cs.z += o.z; cs.w += o.w;
+    }
+  }
+  red[threadIdx.x] = cs;
+  __syncthreads();
+  if (tp == 0 && c4 * 4 < C) {
+    for (int k = 1; k < pl.TP; ++k) {
+      const float4 r = red[k * pl.TC + tc];
+      cs.x += r.x; cs.y += r.y; cs.z += r.z; cs.w += r.w;
+    }
+    *reinterpret_cast<float4*>(colpart + ((size_t)n * pl.nchunk + blockIdx.x) * C + c4 * 4) = cs;
+  }
+  if (amax_slot) vcg_amax_publish(amax, amax_slot, amax_gen, amax_red);
+}
+// gbias[c] += sum over the nrows partial rows of colpart[row][c], in a fixed order: 8 channels x 32 row lanes per block
+__global__ __launch_bounds__(256) void k_in_colsum_final(const float* __restrict__ part, float* __restrict__ out, int C, int nrows, int c_log) {
+  __shared__ float red[32][8];
+  const int il = threadIdx.x & 7, kl = threadIdx.x >> 3;
+  const int c = blockIdx.x * 8 + il;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (c < c_log) {
+    int k = kl;
+    for (; k + 96 < nrows; k += 128) {
+      s0 += part[(size_t)k * C + c];
+      s1 += part[(size_t)(k + 32) * C + c];
+      s2 += part[(size_t)(k + 64) * C + c];
+      s3 += part[(size_t)(k + 96) * C + c];
+    }
+    for (; k < nrows; k += 32) s0 += part[(size_t)k * C + c];
+  }
+  red[kl][il] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (kl == 0 && c < c_log) {
+    float s = red[0][il];
+    for (int k = 1; k < 32; ++k) s += red[k][il];
+    out[c] += s;
+  }
+}
+
 __global__ __launch_bounds__(256) void k_act_bwd(const float* __restrict__ g, const float* __restrict__ t,
                                                  float* __restrict__ dt, size_t n4, int act, unsigned long long* amax_slot,
                                                  uint32_t amax_gen) {
@@ -267,7 +359,7 @@ static int ew_blocks(size_t work) {
 extern "C" size_t vcg_in_workspace(int N, int HW, int C) {
   if (N <= 0 || HW <= 0 || C <= 0 || C % 4) return 0;
   NormPlan pl = make_plan(N, HW, C);
-  return (size_t)N * pl.nchunk * C * 2 * sizeof(double) + (size_t)N * C * 2 * sizeof(float) + 256;
+  return (size_t)N * pl.nchunk * C * 2 * sizeof(double) + (size_t)N * C * 2 * sizeof(float) + (size_t)N * pl.nchunk * C * sizeof(float) + 512;
 }
 
 // chunk partials [N][nchunk][C][2] (sum, sum of squares, in double) -> mean, rstd
@@ -312,9 +404,9 @@ extern "C" int vcg_in_apply(const float* t, const float* mean, const float* rstd
   return 0;
 }
 
-extern "C" int vcg_in_bwd(const float* g, const float* t, const float* mean, const float* rstd, float* dt,
-                          int N, int H, int W, int C, int epi_act, int post_act, int shuffle,
-                          void* ws, size_t ws_bytes, void* stream) {
+static int in_bwd_impl(const float* g, const float* t, const float* mean, const float* rstd, float* dt,
+                       int N, int H, int W, int C, int epi_act, int post_act, int shuffle, float* gbias, int c_log,
+                       void* ws, size_t ws_bytes, void* stream) {
   VCG_CHECK_ARG(g && t && mean && rstd && dt && ws, "vcg_in_bwd: null pointer");
   VCG_CHECK_ARG(N > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "vcg_in_bwd: bad dims");
   VCG_CHECK_ARG(!shuffle || C % 16 == 0, "vcg_in_bwd: pixel shuffle needs C %% 16 == 0");
@@ -324,6 +416,8 @@ extern "C" int vcg_in_bwd(const float* g, const float* t, const float* mean, con
   hipStream_t st = (hipStream_t)stream;
   double* part = (double*)ws;
   float* s12 = (float*)(part + (size_t)N * pl.nchunk * C * 2);
+  float* colpart = s12 + (size_t)N * C * 2 + 64;
+  colpart = (float*)(((uintptr_t)colpart + 15) & ~(uintptr_t)15);
   VcgInTail tail = vcg_in_tail_make(s12, nullptr, N * pl.cgroups, HW, 0.f);
   if (tail.out1)
     hipLaunchKernelGGL((k_in_partial<1, true>), dim3(pl.nchunk, N, pl.cgroups), dim3(256), 0, st, t, g, mean, rstd, part, H, W,
@@ -336,11 +430,35 @@ extern "C" int vcg_in_bwd(const float* g, const float* t, const float* mean, con
                        (float*)nullptr, N, HW, C, pl.nchunk, 0.f);
   size_t total = (size_t)N * HW * (C / 4);
   const VcgAmaxOut ao = vcg_amax_new(st);
-  hipLaunchKernelGGL(k_in_bwd_apply, dim3(ew_blocks(total)), dim3(256), 0, st, g, t, mean, rstd, (const float*)s12,
-                     dt, N, H, W, C, epi_act, post_act, shuffle, ao.slot, ao.gen);
+  if (gbias) {
+    // dt and its column sums in one pass (the bias gradient of the conv in front of this norm)
+    hipLaunchKernelGGL(k_in_bwd_apply_cs, dim3(pl.nchunk, N, pl.cgroups), dim3(256), 0, st, g, t, mean, rstd, (const float*)s12, dt,
+                       colpart, H, W, C, pl, epi_act, post_act, shuffle, ao.slot, ao.gen);
+    hipLaunchKernelGGL(k_in_colsum_final, dim3((c_log + 7) / 8), dim3(256), 0, st, (const float*)colpart, gbias, C, N * pl.nchunk, c_log);
+  } else {
+    hipLaunchKernelGGL(k_in_bwd_apply, dim3(ew_blocks(total)), dim3(256), 0, st, g, t, mean, rstd, (const float*)s12,
+                       dt, N, H, W, C, epi_act, post_act, shuffle, ao.slot, ao.gen);
+  }
   VCG_LAUNCH_CHECK("vcg_in_bwd");
   vcg_set_last_amax(vcg_amax_handle(ao));               // vcg_amax_last(): the largest magnitude of `dt`
   return 0;
+}
+extern "C" int vcg_in_bwd(const float* g, const float* t, const float* mean, const float* rstd, float* dt,
+                          int N, int H, int W, int C, int epi_act, int post_act, int shuffle,
+                          void* ws, size_t ws_bytes, void* stream) {
+  return in_bwd_impl(g, t, mean, rstd, dt, N, H, W, C, epi_act, post_act, shuffle, nullptr, 0, ws, ws_bytes, stream);
+}
+// vcg_in_bwd that also ACCUMULATES the column sums of dt into gbias[0 .. c_log) — the bias gradient of the convolution whose
+// output this InstanceNorm normalises, when an activation sits between them (otherwise it is identically zero) — instead of a
+// separate pass over dt inside vcg_conv_wgrad (hand that call gbias = NULL then).  dt_amax as in vcg_in_bwd_h (may be NULL).
+extern "C" int vcg_in_bwd_bias(const float* g, const float* t, const float* mean, const float* rstd, float* dt,
+                               int N, int H, int W, int C, int epi_act, int post_act, int shuffle, float* gbias, int c_log,
+                               void* ws, size_t ws_bytes, uint64_t* dt_amax, void* stream) {
+  VCG_CHECK_ARG(gbias && c_log > 0 && c_log <= C, "vcg_in_bwd_bias: bad bias gradient arguments");
+  const int rc = in_bwd_impl(g, t, mean, rstd, dt, N, H, W, C, epi_act, post_act, shuffle, gbias, c_log, ws, ws_bytes, stream);
+  const uint64_t h = vcg_amax_last();
+  if (dt_amax) *dt_amax = rc ? 0 : h;
+  return rc;
 }
 
 extern "C" int vcg_act_bwd(const float* g, const float* t, float* dt, size_t n, int act, void* stream) {

@@ -386,6 +386,12 @@ int vcg_thin_fwd(const ConvGeom& g, const float* x, const float* wf, const float
 int vcg_thin_dgrad(const ConvGeom& g, const float* dy, const float* wf, float* dx, void* ws, size_t ws_bytes,
                    hipStream_t st);
 
+// conv_thinin.hip: forward of the layers with a 4-channel input and 64 outputs (the 7x7 stem, the discriminators' first layer)
+bool vcg_thinin_fwd_ok(const ConvGeom& g);
+int vcg_thinin_nchunk(const ConvGeom& g);
+int vcg_thinin_fwd(const ConvGeom& g, const float* x, const float* wf, const void* w_amax, const float* bias, float* y, double* in_part,
+                   hipStream_t st, uint64_t x_handle);
+
 // conv_wino.hip: Winograd F(2x2,3x3) forward for the 3x3 / stride-1 / pad-1 layers
 bool vcg_wino_weight_ok(const ConvGeom& g);
 long long vcg_wino_gate_fwd();

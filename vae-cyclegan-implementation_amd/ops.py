@@ -349,6 +349,9 @@ def _measured_amax(t):
     return int(_native.lib().vcg_amax_measure(_ptr(t), t.numel(), _stream()))
 
 
+# VCG_BIAS_IN_BWD=0: bias gradients of the conv -> act -> InstanceNorm blocks from a pass of their own over dt (A/B measurements)
+BIAS_IN_BWD = os.environ.get("VCG_BIAS_IN_BWD", "1") != "0"
+
 # VCG_LAZY_WF=0: every pack carries the fp32 Wf block, read or not (A/B measurements)
 LAZY_WF = os.environ.get("VCG_LAZY_WF", "1") != "0"
 
@@ -567,15 +570,27 @@ class _ConvBlockFn(torch.autograd.Function):
         gp = as_phys(g)
         d_res = g if ctx.has_res else None
         c = spec.cout_pitch
+        wparam, bparam = ctx.wparam, ctx.bparam
+        want_w = wparam is not None and wparam.requires_grad and id(wparam) not in _NO_WGRAD
+        # conv -> act -> InstanceNorm (D, U, R.conv1): the bias gradient is the column sum of dt, taken by the pass that writes dt
+        # (include/vcg.h, vcg_in_bwd_bias) instead of a pass of its own inside the weight gradient.  VCG_BIAS_IN_BWD=0: as before.
+        gb_here = None
+        if spec.norm and spec.epi_act != ACT_NONE and want_w and BIAS_IN_BWD and bparam is not None and bparam.requires_grad:
+            gb_here = _grad_buffer(bparam)
         if spec.norm:
             dt = torch.empty_like(t)
             wsb = lib.vcg_in_workspace(n, ho * wo, c)
             ws = workspace(wsb, dev)
             with _timed("in_bwd"):
                 h = ctypes.c_uint64(0)
-                _native.check(lib.vcg_in_bwd_h(_ptr(gp), _ptr(t), _ptr(mean), _ptr(rstd), _ptr(dt), n, ho, wo, c,
-                                               spec.epi_act, spec.post_act, int(spec.shuffle), _ptr(ws), ws.numel() * 4,
-                                               ctypes.byref(h), _stream()), "vcg_in_bwd")
+                if gb_here is not None:
+                    _native.check(lib.vcg_in_bwd_bias(_ptr(gp), _ptr(t), _ptr(mean), _ptr(rstd), _ptr(dt), n, ho, wo, c,
+                                                      spec.epi_act, spec.post_act, int(spec.shuffle), _ptr(gb_here), spec.cout,
+                                                      _ptr(ws), ws.numel() * 4, ctypes.byref(h), _stream()), "vcg_in_bwd_bias")
+                else:
+                    _native.check(lib.vcg_in_bwd_h(_ptr(gp), _ptr(t), _ptr(mean), _ptr(rstd), _ptr(dt), n, ho, wo, c,
+                                                   spec.epi_act, spec.post_act, int(spec.shuffle), _ptr(ws), ws.numel() * 4,
+                                                   ctypes.byref(h), _stream()), "vcg_in_bwd")
             dt_amax = h.value if AMAX_HANDLES else 0
         elif spec.epi_act != ACT_NONE:
             dt = torch.empty_like(t)
@@ -587,12 +602,11 @@ class _ConvBlockFn(torch.autograd.Function):
             dt_amax = _amax_of(g)
         if not dt_amax and AMAX_HANDLES:
             dt_amax = _measured_amax(dt)      # on this stream, before the weight gradient forks off: both gradients take it
-        wparam, bparam = ctx.wparam, ctx.bparam
         saved = ctx.saved_state
         # x as the forward saw it?  (autograd refuses a saved tensor that was modified in place, so this only guards a
         # handle that has aged out between forward and backward: measured again below by the library)
         x_amax = ctx.x_amax if (ctx.x_amax and ctx.x_key == (xp._version, xp.data_ptr()) and lib.vcg_amax_valid(ctx.x_amax)) else 0
-        if wparam is not None and wparam.requires_grad and id(wparam) not in _NO_WGRAD:
+        if want_w:
             # hand the 4x buffer back once the weight gradient has consumed it — not on a traversal that skips the weight
             # gradient (`no_wgrad`: the G phase through a discriminator), whose retained graph is differentiated again
             ctx.saved_state = None
@@ -603,6 +617,8 @@ class _ConvBlockFn(torch.autograd.Function):
                 # is identically zero (the reference's autograd returns rounding noise of ~1e-9 there: the column sums of
                 # a dt whose columns sum to zero) — the buffer stays at its zeros and the column-sum kernels are not run
                 gb = None
+            if gb_here is not None:
+                gb = None            # already accumulated by vcg_in_bwd_bias above, on the main stream
             if ctx.x_deferred and saved is None:
                 raise RuntimeError("the weight gradient of a layer that took a deferred-InstanceNorm input needs the forward's kept "
                                    "state (a second backward through the same graph, or VCG_KEEP_FORWARD_STATE=0 set after the forward)")
@@ -627,7 +643,11 @@ class _ConvBlockFn(torch.autograd.Function):
                 run_wgrad()
                 wstream = torch.cuda.current_stream(dev)
             if GRAD_READY_HOOK[0] is not None:
-                GRAD_READY_HOOK[0](wparam, bparam, wstream)
+                if gb_here is not None:      # the bias gradient came from the main stream, the weight gradient from `wstream`
+                    GRAD_READY_HOOK[0](None, bparam, torch.cuda.current_stream(dev))
+                    GRAD_READY_HOOK[0](wparam, None, wstream)
+                else:
+                    GRAD_READY_HOOK[0](wparam, bparam, wstream)
         dx = None
         if ctx.needs_input_grad[0] and id(spec) not in _NO_DGRAD:
             dxp = torch.empty_like(xp)
