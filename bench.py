@@ -137,6 +137,13 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # VCG_MAIN_PRIORITY=high: the step's own stream gets HIP's high priority (the weight-gradient side stream keeps the normal one),
+    # so that where both have workgroups ready the critical path's go first (A/B measurement; default: the caller's stream as is)
+    main_stream = None
+    if os.environ.get("VCG_MAIN_PRIORITY") == "high":
+        main_stream = torch.cuda.Stream(device=dev, priority=-1)
+        main_stream.wait_stream(torch.cuda.current_stream(dev))
+        torch.cuda.set_stream(main_stream)
     for i in range(args.warmup):
         model.training_step(pool[i % len(pool)])
     # a full collection of Python's cyclic GC walks every long-lived object (modules, parameters, ctypes tables): ~30 ms

@@ -113,18 +113,28 @@ __global__ __launch_bounds__(256, 2) void k_conv_slab(SlabP p) {
   const uint32_t fb = (uint32_t)(brow * 64);
   const int sb = (brow >> 2) & 3;
 
-  sl_u32x4 vb[BQ];
-  auto load_b = [&](int chunk, int tap) {
+  // Weight tiles are fetched PD (chunk, tap) steps ahead into a ring of register sets (round 4).  With one step of look-ahead
+  // (round 2) a step's MFMAs — 12 per wave, ~400 cycles — hid a fraction of the ~1 us an L2 / Infinity-Cache read takes, and the
+  // layers with one or two channel chunks (U4: 9 steps in all) spent most of their time waiting for 8 KB weight tiles:
+  // SQ_WAIT_ANY 54 % of the wave cycles (gpurun_out/thinin_pmc.txt).  PD divides the tap count, so the ring slot tap % PD is static.
+  constexpr int PD = NTAP % 3 == 0 ? 3 : NTAP;
+  sl_u32x4 vb[PD][BQ];
+  const int total = p.nchunks * NTAP;
+  auto load_b = [&](sl_u32x4 (&dst)[BQ], int step) {                  // step = chunk * NTAP + tap
+    const int chunk = step / NTAP, tap = step - chunk * NTAP;
     const uint32_t t = (uint32_t)(p.tap_flip ? NTAP - 1 - tap : tap);
     const uint32_t o = t * p.tap_stride + (uint32_t)chunk * (uint32_t)VCG_PBYTES;
 #pragma unroll
-    for (int j = 0; j < BQ; ++j) vb[j] = __builtin_amdgcn_raw_buffer_load_b128(rb, (int)(boff[j] != SL_OOB ? boff[j] + o : SL_OOB), 0, 0);
+    for (int j = 0; j < BQ; ++j) dst[j] = __builtin_amdgcn_raw_buffer_load_b128(rb, (int)(boff[j] != SL_OOB ? boff[j] + o : SL_OOB), 0, 0);
   };
-  auto store_b = [&](int buf) {
+  auto store_b = [&](const sl_u32x4 (&src)[BQ], int buf) {
 #pragma unroll
     for (int j = 0; j < BQ; ++j)
-      if (bsoff[j] != SL_OOB) *reinterpret_cast<sl_u32x4*>(&Bs[buf][bpc[j]][bsoff[j]]) = vb[j];
+      if (bsoff[j] != SL_OOB) *reinterpret_cast<sl_u32x4*>(&Bs[buf][bpc[j]][bsoff[j]]) = src[j];
   };
+#pragma unroll
+  for (int k = 0; k < PD; ++k)
+    if (k < total) load_b(vb[k], k);
 
   int s = 0;                                              // linear (chunk, tap) step: B buffer = s & 1
   for (int chunk = 0; chunk < p.nchunks; ++chunk) {
@@ -136,7 +146,6 @@ __global__ __launch_bounds__(256, 2) void k_conv_slab(SlabP p) {
         const sl_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(ra, (int)(goff[a] != SL_OOB ? goff[a] + (uint32_t)chunk * 128u : SL_OOB), 0, 0);
         va[a] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
       }
-      if (chunk == 0) load_b(0, 0);
       if (chunk > 0) __syncthreads();                     // every wave is done reading the previous slab
 #pragma unroll
       for (int a = 0; a < AQ; ++a) {
@@ -146,13 +155,15 @@ __global__ __launch_bounds__(256, 2) void k_conv_slab(SlabP p) {
         *reinterpret_cast<uint2*>(&As[0][soff[a]]) = h;
         *reinterpret_cast<uint2*>(&As[1][soff[a]]) = l;
       }
-      if (chunk == 0) store_b(0);
+      if (chunk == 0) {
+        store_b(vb[0], 0);
+        if (PD < total) load_b(vb[0], PD);
+      }
       __syncthreads();
     }
+#pragma unroll
     for (int tap = 0; tap < NTAP; ++tap, ++s) {
       const int buf = s & 1;
-      const bool more = tap < NTAP - 1 || chunk + 1 < p.nchunks;
-      if (more) load_b(tap < NTAP - 1 ? chunk : chunk + 1, tap < NTAP - 1 ? tap + 1 : 0);
       const int kh = tap / KW, kw = tap - kh * KW;
       uint32_t fa[2];
       int sa[2];
@@ -180,7 +191,19 @@ __global__ __launch_bounds__(256, 2) void k_conv_slab(SlabP p) {
           acc[i] = VCG_MFMA(a[0][i], b[0], acc[i]);
         }
       }
-      if (more) store_b(buf ^ 1);                         // the buffer tap s - 1 read: every wave passed the barrier after it
+      // the next step's tile (fetched PD steps ago) goes into the buffer step s - 1 read — every wave passed the barrier after it —
+      // and its register set is handed to the fetch of step s + 1 + PD
+      if (s + 1 < total) {
+        constexpr int slot = 0;                            // (placeholder: the static slot is chosen by the switch below)
+        (void)slot;
+        const int nslot = (tap + 1) % PD;
+#pragma unroll
+        for (int k = 0; k < PD; ++k)
+          if (k == nslot) {
+            store_b(vb[k], buf ^ 1);
+            if (s + 1 + PD < total) load_b(vb[k], s + 1 + PD);
+          }
+      }
       __syncthreads();
     }
   }
