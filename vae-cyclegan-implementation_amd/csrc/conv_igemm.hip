@@ -1346,8 +1346,12 @@ __global__ __launch_bounds__(256, 2) void k_conv_wgrad_split(ConvP p) {
   constexpr int WR = NT / 128;                                 // wave rows (x 2 wave columns)
   constexpr int MI = BM / (32 * WR), NI = BN / 64;
   constexpr int RQ = BM / 4, PS = NT / RQ, AP = BK / PS, BE = (BK * BN / 4) / NT;
-  __shared__ __attribute__((aligned(16))) unsigned char Xs[VCG_NP][BK * BM * 2];   // [piece][32 pixels][128 rows of dW] fp16
-  __shared__ __attribute__((aligned(16))) unsigned char Ds[VCG_NP][BK * BN * 2];   // [piece][32 pixels][128 columns] fp16
+  // TWO images of each tile (round 4: 64 KB per workgroup at BN = 128, two workgroups per CU): tile kt + 1 is split and stored into
+  // the other image right behind the issue of tile kt's MFMAs — VALU and LDS stores run under the matrix pipe — and ONE barrier
+  // per K' step publishes it; with one image the stores waited behind a barrier for every wave's MFMAs to drain and a second
+  // barrier followed them (SQ_WAIT_ANY 55 % of the wave cycles, matrix pipe 22 % busy: gpurun_out/r04a_pmc_step.txt)
+  __shared__ __attribute__((aligned(16))) unsigned char Xs[2][VCG_NP][BK * BM * 2];   // [image][piece][32 pixels][128 rows of dW] fp16
+  __shared__ __attribute__((aligned(16))) unsigned char Ds[2][VCG_NP][BK * BN * 2];   // [image][piece][32 pixels][128 columns] fp16
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid >> 1, wn = wid & 1, l31 = lane & 31, lh = lane >> 5;
   const SplitScales sc = split_scales(p);
@@ -1481,7 +1485,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_wgrad_split(ConvP p) {
       if (boff[e] != VCG_OOB) boff[e] += bstep;
     }
   };
-  auto store_tiles = [&]() {
+  auto store_tiles = [&](int img) {
 #pragma unroll
     for (int a = 0; a < AP; ++a) {
       uint2 h, l;
@@ -1492,8 +1496,8 @@ __global__ __launch_bounds__(256, 2) void k_conv_wgrad_split(ConvP p) {
         split4h(va[a], sc.inv_a, h, l);
       }
       const uint32_t o = tr_off<BM>(ps + PS * a, rq * 4);
-      *reinterpret_cast<uint2*>(&Xs[0][o]) = h;
-      *reinterpret_cast<uint2*>(&Xs[1][o]) = l;
+      *reinterpret_cast<uint2*>(&Xs[img][0][o]) = h;
+      *reinterpret_cast<uint2*>(&Xs[img][1][o]) = l;
     }
 #pragma unroll
     for (int e = 0; e < BE; ++e) {
@@ -1502,8 +1506,8 @@ __global__ __launch_bounds__(256, 2) void k_conv_wgrad_split(ConvP p) {
       uint2 h, l;
       split4h(vb[e], sc.inv_b, h, l);
       const uint32_t o = tr_off<BN>(pp, j4 * 4);
-      *reinterpret_cast<uint2*>(&Ds[0][o]) = h;
-      *reinterpret_cast<uint2*>(&Ds[1][o]) = l;
+      *reinterpret_cast<uint2*>(&Ds[img][0][o]) = h;
+      *reinterpret_cast<uint2*>(&Ds[img][1][o]) = l;
     }
   };
   // transposing fragment reads: 16-lane group g = lane >> 4 handles columns 16 (g & 1) .. +15 of a 32-wide MFMA tile and
@@ -1512,11 +1516,12 @@ __global__ __launch_bounds__(256, 2) void k_conv_wgrad_split(ConvP p) {
 
   if (kt_begin < kt_end) {
     load_tiles(kt_begin);
-    store_tiles();
+    store_tiles(0);
   }
   __syncthreads();
   VCG_STAMP_AT(1);
   for (int kt = kt_begin; kt < kt_end; ++kt) {
+    const int img = (kt - kt_begin) & 1;
     if (kt + 1 < kt_end) load_tiles(kt + 1);
 #pragma unroll
     for (int s2 = 0; s2 < 2; ++s2) {
@@ -1525,9 +1530,9 @@ __global__ __launch_bounds__(256, 2) void k_conv_wgrad_split(ConvP p) {
 #pragma unroll
       for (int pc = 0; pc < VCG_NP; ++pc) {
 #pragma unroll
-        for (int i = 0; i < MI; ++i) af[pc][i] = tr_frag<BM>(Xs[pc], row0, wm * (BM / WR) + i * 32 + tcol);
+        for (int i = 0; i < MI; ++i) af[pc][i] = tr_frag<BM>(Xs[img][pc], row0, wm * (BM / WR) + i * 32 + tcol);
 #pragma unroll
-        for (int j = 0; j < NI; ++j) bfr[pc][j] = tr_frag<BN>(Ds[pc], row0, wn * (BN / 2) + j * 32 + tcol);
+        for (int j = 0; j < NI; ++j) bfr[pc][j] = tr_frag<BN>(Ds[img][pc], row0, wn * (BN / 2) + j * 32 + tcol);
       }
 #pragma unroll
       for (int i = 0; i < MI; ++i)
@@ -1540,11 +1545,9 @@ __global__ __launch_bounds__(256, 2) void k_conv_wgrad_split(ConvP p) {
           acc[i][j] = VCG_MFMA(af[0][i], bfr[0][j], acc[i][j]);
         }
     }
+    // the other image was last read in step kt - 1, and every wave has passed the barrier that ended it
+    if (kt + 1 < kt_end) store_tiles(img ^ 1);
     __syncthreads();
-    if (kt + 1 < kt_end) {
-      store_tiles();
-      __syncthreads();
-    }
   }
 #pragma unroll
   for (int i = 0; i < MI; ++i)
@@ -1568,7 +1571,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_wgrad_split(ConvP p) {
     }
   }
   unit += kt_end - kt_begin;
-  if (unit < unit_end) __syncthreads();           // the next segment's prologue overwrites LDS half 0
+  if (unit < unit_end) __syncthreads();           // the next segment's prologue overwrites LDS image 0
   }
   VCG_STAMP_AT(3);
 }
