@@ -207,6 +207,14 @@ int vcg_pixel_shuffle(const float* src, float* dst, int N, int H, int W, int C, 
 int vcg_act_bwd(const float* g, const float* t, float* dt, size_t n, int act, void* stream);
 int vcg_act_bwd_h(const float* g, const float* t, float* dt, size_t n, int act, uint64_t* dt_amax, void* stream);
 
+/* Helpers of the fused mu / logvar convolution (Networks.py:219-222: both convolutions read one map — they run as ONE
+   convolution with 2 x latent output channels).  NHWC rows of ca + cb floats <-> rows of ca and rows of cb (multiples of 4;
+   vcg_chan_cat: a NULL source reads as zeros); vcg_add_into: dst += src, src = 0 (n a multiple of 4, 16-byte aligned) — the
+   fused kernel's weight gradient handed to the two parameters' own gradient buffers. */
+int vcg_chan_split(const float* src, float* a, float* b, size_t rows, int ca, int cb, void* stream);
+int vcg_chan_cat(const float* a, const float* b, float* dst, size_t rows, int ca, int cb, void* stream);
+int vcg_add_into(float* dst, float* src, size_t n, void* stream);
+
 /* VariationalEncoderBlock.forward — Networks.py:219-227 -------------------- */
 /* lvc = clamp(lv,-10,10); z = mu + eps*exp(0.5*lvc). eps==NULL: eps is drawn
    on device (Philox4x32-10 + Box-Muller, (seed, offset)) and written to eps_out. */

@@ -209,9 +209,21 @@ class VariationalEncoderBlock(nn.Module):
         self.muConv = L(in_channels, latent_dim)
         self.logvarConv = nn.Sequential(S(in_channels, latent_dim), S(latent_dim, latent_dim))
         self.latent_dim = latent_dim
+        # mu and the first logvar convolution read the same map: one convolution with 2 x latent outputs (ops.FusedConvPair;
+        # the parameters, state_dict names and optimizer entries stay the reference's)
+        self._pair = None
+        if latent_dim % 4 == 0:
+            object.__setattr__(self, "_pair", ops.FusedConvPair(self.muConv.conv, self.logvarConv[0].conv,
+                                                                ops.ConvSpec(in_channels, 2 * latent_dim, 3, 1, 1, True, 1)))
 
     def forward(self, x):
         x = ops.to_nhwc(x)
+        if ops.FUSE_MU_LOGVAR and self._pair is not None and x.is_cuda:
+            mu, lv0 = ops.conv_pair(x, self._pair)
+            logvar = self.logvarConv[1](lv0)
+            eps = ops.next_eps(mu.shape, mu.device)
+            z, logvar = ops.reparameterize(mu, logvar, eps)
+            return z, mu, logvar
         mu = self.muConv(x)
         logvar = self.logvarConv(x)
         eps = ops.next_eps(mu.shape, mu.device)

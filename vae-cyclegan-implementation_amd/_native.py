@@ -64,6 +64,9 @@ SIGNATURES = {
     "vcg_in_bwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _Z, _P]),
     "vcg_act_bwd": (_I, [_P, _P, _P, _Z, _I, _P]),
     "vcg_pixel_shuffle": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
+    "vcg_chan_split": (_I, [_P, _P, _P, _Z, _I, _I, _P]),
+    "vcg_chan_cat": (_I, [_P, _P, _P, _Z, _I, _I, _P]),
+    "vcg_add_into": (_I, [_P, _P, _Z, _P]),
     "vcg_reparam_fwd": (_I, [_P, _P, _P, _P, _P, _P, _Z, _U64, _U64, _P]),
     "vcg_reparam_bwd": (_I, [_P, _P, _P, _P, _P, _P, _Z, _P]),
     "vcg_randn": (_I, [_P, _Z, _U64, _U64, _P]),

@@ -851,3 +851,63 @@ extern "C" int vcg_act_bwd_h(const float* g, const float* t, float* dt, size_t n
   if (dt_amax) *dt_amax = rc ? 0 : h;
   return rc;
 }
+
+// ---------------------------------------------------------------- channel split / concatenation and in-place accumulation (round 4)
+// The mu convolution and the first logvar convolution of the VAE bottleneck read the same map (/root/reference/Networks.py:219-222):
+// they run as ONE convolution with 2 x latent output channels, whose NHWC output is split into the two tensors the reference
+// returns; the backward concatenates the two gradients again, and the weight gradient of the fused kernel is added into the two
+// parameters' own gradient buffers.
+__global__ __launch_bounds__(256) void k_chan_split(const float4* __restrict__ src, float4* __restrict__ a, float4* __restrict__ b, size_t rows,
+                                                    int ca4, int cb4) {
+  const int c4 = ca4 + cb4;
+  const size_t total = rows * c4;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t r = i / c4;
+    const int c = (int)(i - r * c4);
+    const float4 v = src[i];
+    if (c < ca4) a[r * ca4 + c] = v;
+    else b[r * cb4 + (c - ca4)] = v;
+  }
+}
+__global__ __launch_bounds__(256) void k_chan_cat(const float4* __restrict__ a, const float4* __restrict__ b, float4* __restrict__ dst, size_t rows,
+                                                  int ca4, int cb4) {
+  const int c4 = ca4 + cb4;
+  const size_t total = rows * c4;
+  const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t r = i / c4;
+    const int c = (int)(i - r * c4);
+    dst[i] = c < ca4 ? (a ? a[r * ca4 + c] : z) : (b ? b[r * cb4 + (c - ca4)] : z);
+  }
+}
+extern "C" int vcg_chan_split(const float* src, float* a, float* b, size_t rows, int ca, int cb, void* stream) {
+  VCG_CHECK_ARG(src && a && b && rows > 0 && ca > 0 && cb > 0 && ca % 4 == 0 && cb % 4 == 0, "vcg_chan_split: bad arguments");
+  hipLaunchKernelGGL(k_chan_split, dim3(ew_blocks(rows * (ca + cb) / 4)), dim3(256), 0, (hipStream_t)stream, (const float4*)src, (float4*)a,
+                     (float4*)b, rows, ca / 4, cb / 4);
+  VCG_LAUNCH_CHECK("vcg_chan_split");
+  return 0;
+}
+extern "C" int vcg_chan_cat(const float* a, const float* b, float* dst, size_t rows, int ca, int cb, void* stream) {
+  VCG_CHECK_ARG(dst && rows > 0 && ca > 0 && cb > 0 && ca % 4 == 0 && cb % 4 == 0, "vcg_chan_cat: bad arguments");
+  hipLaunchKernelGGL(k_chan_cat, dim3(ew_blocks(rows * (ca + cb) / 4)), dim3(256), 0, (hipStream_t)stream, (const float4*)a, (const float4*)b,
+                     (float4*)dst, rows, ca / 4, cb / 4);
+  VCG_LAUNCH_CHECK("vcg_chan_cat");
+  return 0;
+}
+// dst[i] += src[i]; src[i] = 0  (n a multiple of 4, both 16-byte aligned): hands a scratch gradient over to its owner and
+// leaves the scratch ready for the next accumulation
+__global__ __launch_bounds__(256) void k_add_into(float4* __restrict__ dst, float4* __restrict__ src, size_t n4) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    float4 d = dst[i];
+    const float4 s = src[i];
+    d.x += s.x; d.y += s.y; d.z += s.z; d.w += s.w;
+    dst[i] = d;
+    src[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+}
+extern "C" int vcg_add_into(float* dst, float* src, size_t n, void* stream) {
+  VCG_CHECK_ARG(dst && src && n > 0 && n % 4 == 0 && (((uintptr_t)dst | (uintptr_t)src) & 15) == 0, "vcg_add_into: bad arguments");
+  hipLaunchKernelGGL(k_add_into, dim3(ew_blocks(n / 4)), dim3(256), 0, (hipStream_t)stream, (float4*)dst, (float4*)src, n / 4);
+  VCG_LAUNCH_CHECK("vcg_add_into");
+  return 0;
+}

@@ -235,7 +235,7 @@ class DeviceInputPipeline:
     on the event recorded behind those kernels."""
 
     def __init__(self, source, batch_size, image_size, device, recipe="summer2winter", shuffle=True, drop_last=False, seed=0,
-                 num_workers=4, same_xy=False, arena_bytes=None, rank=0, world=1):
+                 num_workers=4, same_xy=False, arena_bytes=None, rank=0, world=1, even_shards=None):
         """`rank` / `world`: data parallelism — every rank draws the SAME per-epoch permutation (from `seed`, which must then
         be equal on all ranks) and takes every world-th sample of it, truncated to equal length, so an epoch passes over the
         data once and no sample appears twice in a global batch; the augmentation draws come from a per-rank stream."""
@@ -247,7 +247,16 @@ class DeviceInputPipeline:
         self.rng = np.random.RandomState((seed * 64 + self.rank) % (2 ** 31 - 1)) if self.world > 1 else self.order_rng
         self.pool = ThreadPoolExecutor(max_workers=max(1, num_workers))
         self.prep = ThreadPoolExecutor(max_workers=1)                     # runs _prepare one batch ahead; its Future carries exceptions
-        n = len(source) // self.world
+        # even_shards (default: for shuffled = training loaders): every rank gets len // world samples, so that all ranks take the
+        # same number of steps (each step ends in a gradient exchange).  A validation loader (shuffle=False) has no collective
+        # inside its steps: it covers the WHOLE set — rank r takes samples r, r + world, ... — and `train.validate` weights the
+        # ranks by what they saw (up to world - 1 test samples used to be dropped, and a test split smaller than
+        # `world` gave every rank an empty loader and a division by zero)
+        self.even_shards = bool(shuffle) if even_shards is None else bool(even_shards)
+        if self.world > 1 and not self.even_shards:
+            n = len(range(self.rank, len(source), self.world))
+        else:
+            n = len(source) // self.world
         self.nbatches = n // batch_size if drop_last else (n + batch_size - 1) // batch_size
         self.arena_bytes = arena_bytes or max(2 * batch_size * 1024 * 1024 * 3, 1 << 22)   # grown on demand
         self.slots = [self._make_slot() for _ in range(2)]
@@ -363,7 +372,7 @@ class DeviceInputPipeline:
         n = len(self.src)
         order = self.order_rng.permutation(n) if self.shuffle else np.arange(n)
         if self.world > 1:                                         # this rank's shard: every world-th sample, equal length on all ranks
-            order = order[:n - n % self.world][self.rank::self.world]
+            order = (order[:n - n % self.world] if self.even_shards else order)[self.rank::self.world]
         batches = [order[i * self.b:(i + 1) * self.b] for i in range(self.nbatches)]
         if not batches:
             return

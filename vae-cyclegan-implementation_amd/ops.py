@@ -415,7 +415,6 @@ def _grad_buffer(param):
 # conv_block consumer is correct either way, and nothing else may be handed a deferred tensor (Networks.py defers only between
 # the blocks of one Encoder / inside R).  VCG_DEFER_NORM=0: never defer (A/B measurements).
 DEFER_NORM = os.environ.get("VCG_DEFER_NORM", "1") != "0"
-_PRE_OK = {}
 
 
 def _lazy_of(x):
@@ -451,13 +450,13 @@ def consumer_takes_deferred(spec, n, h, w, needs_wgrad=True):
     caller before deferring: a deferral the consumer cannot use costs nothing but buys nothing.)"""
     if not DEFER_NORM:
         return False
-    key = (id(spec), n, h, w)
-    ok = _PRE_OK.get(key)
+    cache = spec.__dict__.setdefault("_pre_ok", {})        # on the spec itself: an id()-keyed table outlives its specs
+    ok = cache.get((n, h, w))
     if ok is None:
         lib = _native.lib()
         cd = spec.desc(n, h, w)
         ok = bool(lib.vcg_conv_pre_ok(cd)), int(lib.vcg_conv_saved_floats(cd)) > 0
-        _PRE_OK[key] = ok
+        cache[(n, h, w)] = ok
     return ok[0] and (ok[1] and KEEP_FORWARD_STATE or not needs_wgrad)
 
 
@@ -642,7 +641,21 @@ class _ConvBlockFn(torch.autograd.Function):
             else:
                 run_wgrad()
                 wstream = torch.cuda.current_stream(dev)
-            if GRAD_READY_HOOK[0] is not None:
+            members = getattr(wparam, "_vcg_members", None)
+            if members is not None:
+                # a fused kernel (FusedConvPair): its gradient was accumulated into scratch; hand the slices to the members'
+                # own gradient buffers on the stream the weight gradient ran on, and report THEM to the data-parallel reducer
+                with torch.cuda.stream(wstream):
+                    for (mw, mb), (wlo, whi), (blo, bhi) in members:
+                        _native.check(lib.vcg_add_into(_ptr(_grad_buffer(mw)), ctypes.c_void_p(gw.data_ptr() + 4 * wlo), whi - wlo,
+                                                       _stream()), "vcg_add_into")
+                        if gb is not None and mb is not None:
+                            _native.check(lib.vcg_add_into(_ptr(_grad_buffer(mb)), ctypes.c_void_p(gb.data_ptr() + 4 * blo), bhi - blo,
+                                                           _stream()), "vcg_add_into")
+                if GRAD_READY_HOOK[0] is not None:
+                    for (mw, mb), _, _ in members:
+                        GRAD_READY_HOOK[0](mw, mb, wstream)
+            elif GRAD_READY_HOOK[0] is not None:
                 if gb_here is not None:      # the bias gradient came from the main stream, the weight gradient from `wstream`
                     GRAD_READY_HOOK[0](None, bparam, torch.cuda.current_stream(dev))
                     GRAD_READY_HOOK[0](wparam, None, wstream)
@@ -664,6 +677,89 @@ def conv_block(x, weight, bias, spec, residual=None, defer=False):
     result whose sole consumer is another conv_block."""
     _require_gpu(x, "conv_block")
     return _ConvBlockFn.apply(x, weight, bias, residual, spec, weight, bias, bool(defer and DEFER_NORM and spec.norm))
+
+
+# ------------------------------------------------------------------ two convolutions of one input as one (VAE bottleneck: mu and logvar.0)
+# VCG_FUSE_MU_LOGVAR=0: two separate convolutions, as in round 3 (A/B measurements)
+FUSE_MU_LOGVAR = os.environ.get("VCG_FUSE_MU_LOGVAR", "1") != "0"
+
+
+class FusedConvPair:
+    """Two nn.Conv2d of identical geometry that read the SAME input (reference Networks.py:219-222: muConv and logvarConv[0])
+    run as one convolution with the output channels concatenated.  The parameters stay what the reference has (state_dict
+    names, optimizer entries); this object keeps a concatenated copy of the weights (refreshed when the members change: one
+    device-to-device copy each per optimizer step) and scratch gradient buffers whose slices the backward adds into the
+    members' own gradients (`_ConvBlockFn.backward`, `_vcg_members`)."""
+
+    def __init__(self, conv_a, conv_b, spec):
+        self.a, self.b, self.spec = conv_a, conv_b, spec
+        self.w = self.bias = None
+        self.key = None
+        self.epoch = [0]
+
+    def tensors(self):
+        wa, wb, ba, bb = self.a.weight, self.b.weight, self.a.bias, self.b.bias
+
+        def k(t):
+            ep = getattr(t, "_vcg_epoch", None)
+            return (ep[0] if ep is not None else PARAM_EPOCH[0], id(ep), t._version, t.data_ptr())
+        key = (k(wa), k(wb), k(ba), k(bb), wa.device)
+        if self.w is None or self.w.device != wa.device:
+            dev = wa.device
+            self.w = torch.nn.Parameter(torch.empty((wa.shape[0] + wb.shape[0],) + tuple(wa.shape[1:]), dtype=torch.float32, device=dev))
+            self.bias = torch.nn.Parameter(torch.empty(ba.shape[0] + bb.shape[0], dtype=torch.float32, device=dev))
+            self.w.grad = torch.zeros_like(self.w)
+            self.bias.grad = torch.zeros_like(self.bias)
+            self.w._vcg_epoch = self.epoch
+            na, nb = wa.numel(), wb.numel()
+            self.w._vcg_members = [((wa, ba), (0, na), (0, ba.numel())), ((wb, bb), (na, na + nb), (ba.numel(), ba.numel() + bb.numel()))]
+            self.key = None
+        if key != self.key:
+            with torch.no_grad():
+                ca = wa.shape[0]
+                self.w.data[:ca].copy_(wa.data)
+                self.w.data[ca:].copy_(wb.data)
+                self.bias.data[:ca].copy_(ba.data)
+                self.bias.data[ca:].copy_(bb.data)
+            self.epoch[0] += 1
+            self.key = key
+        rg = wa.requires_grad or wb.requires_grad
+        self.w.requires_grad_(rg)
+        self.bias.requires_grad_(rg)
+        return self.w, self.bias
+
+
+class _ChanSplitFn(torch.autograd.Function):
+    """(N, Ca + Cb, H, W) -> (N, Ca, H, W), (N, Cb, H, W), each its own NHWC tensor."""
+
+    @staticmethod
+    def forward(ctx, y, ca):
+        yp = as_phys(y)
+        n, h, w, c = yp.shape
+        cb = c - ca
+        a = torch.empty((n, h, w, ca), dtype=torch.float32, device=y.device)
+        b = torch.empty((n, h, w, cb), dtype=torch.float32, device=y.device)
+        _native.check(_native.lib().vcg_chan_split(_ptr(yp), _ptr(a), _ptr(b), n * h * w, ca, cb, _stream()), "vcg_chan_split")
+        ctx.dims = (n, h, w, ca, cb)
+        return logical_of(a, ca), logical_of(b, cb)
+
+    @staticmethod
+    def backward(ctx, ga, gb):
+        n, h, w, ca, cb = ctx.dims
+        gap = as_phys(ga) if ga is not None else None
+        gbp = as_phys(gb) if gb is not None else None
+        dev = (ga if ga is not None else gb).device
+        g = torch.empty((n, h, w, ca + cb), dtype=torch.float32, device=dev)
+        _native.check(_native.lib().vcg_chan_cat(_ptr(gap), _ptr(gbp), _ptr(g), n * h * w, ca, cb, _stream()), "vcg_chan_cat")
+        return logical_of(g, ca + cb), None
+
+
+def conv_pair(x, pair):
+    """Both convolutions of `pair` (a FusedConvPair) applied to x: (y_a, y_b)."""
+    _require_gpu(x, "conv_pair")
+    w, b = pair.tensors()
+    y = _ConvBlockFn.apply(x, w, b, None, pair.spec, w, b, False)
+    return _ChanSplitFn.apply(y, pair.a.weight.shape[0])
 
 
 class _PixelShuffleFn(torch.autograd.Function):

@@ -162,13 +162,23 @@ def validate(model, dataloader, device, args):
                 loss_components[key] = loss_components.get(key, 0.0) + value
             last_Gx, last_Fy, last_x, last_y = Gx, Fy, batch["x"], batch["y"]
     n = len(dataloader)
-    avg_loss, avg = total_loss / n, {k: v / n for k, v in loss_components.items()}
     red = getattr(model, "grad_reducer", None)
-    if red is not None:                               # data parallel: each rank validated its shard of the test set
-        keys = sorted(avg)
-        vec = torch.tensor([avg_loss] + [avg[k] for k in keys], dtype=torch.float32, device=device)
-        vec = red.average_metrics(vec).tolist()
-        avg_loss, avg = vec[0], dict(zip(keys, vec[1:]))
+    if red is not None:
+        # data parallel: each rank validated its shard of the test set.  Shards may differ by one batch (or be empty: a test
+        # split smaller than the world size), so the ranks pool their per-batch SUMS and batch counts — the same batch-weighted
+        # mean the single-process loop computes — instead of averaging per-rank means
+        import torch.distributed as dist
+        pooled = [None] * red.world
+        dist.all_gather_object(pooled, (n, total_loss, loss_components), group=red.group)
+        n = sum(p[0] for p in pooled)
+        total_loss = sum(p[1] for p in pooled)
+        loss_components = {}
+        for _, _, comp in pooled:
+            for k, v in comp.items():
+                loss_components[k] = loss_components.get(k, 0.0) + v
+    if n == 0:
+        raise ValueError("validate(): the test set is empty (no batch on any rank): lower --test_split or skip validation")
+    avg_loss, avg = total_loss / n, {k: v / n for k, v in loss_components.items()}
     return avg_loss, avg, last_Gx, last_Fy, last_x, last_y
 
 
