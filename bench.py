@@ -185,7 +185,7 @@ def main():
         "dtype": "f32", "data": "synthetic",
         "arithmetic": "fp32 in, fp32 out, fp32 accumulate; GEMM products as 2 x fp16 split operands scaled by a per-tensor power of two "
                       "(3 fp16 MFMAs per fp32 multiply-add), rounding error 1.3-4.1e-7 against float64 where PyTorch-CPU fp32 has 1.0-10e-7 "
-                      "(profiles/r03_conv_accuracy.txt)",
+                      "(profiles/r04_conv_accuracy.txt)",
         "config": {"workload": WORKLOADS[wl] if (S == 256) else f"{wl} {S}x{S} batch {B}", "per_gpu_batch": B, "global_batch": B * world,
                    "image_size": S, "latent_dim": latent, "parallelism": f"dp{world}", "init": "random (reference init statistics)"},
     }
@@ -228,7 +228,7 @@ def main():
         dist.destroy_process_group()
 
 
-PROFILE_ROUND = "r03"          # profiles/<round>_pmc_*.json: the committed PMC passes `traffic` and `mfma_pipe_util` are quoted from
+PROFILE_ROUND = "r04"          # profiles/<round>_pmc_*.json: the committed PMC passes `traffic` and `mfma_pipe_util` are quoted from
 
 
 def read_kernel_profile(lib):
