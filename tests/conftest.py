@@ -114,6 +114,10 @@ SEED = 20261003          # tests/golden/make_golden.py
 RTOL = 1e-3              # north_star: 1e-3 relative, fp32
 
 
+def numel_of(t):
+    return int(t.numel()) if isinstance(t, torch.Tensor) else int(np.asarray(t).size)
+
+
 def t2n(t):
     return t.detach().cpu().numpy() if isinstance(t, torch.Tensor) else np.asarray(t)
 
@@ -140,7 +144,33 @@ sys.path.insert(0, GOLDEN)
 from cases import N_PROJ, checksum as _np_checksum  # noqa: E402
 
 
+def _s64(x):
+    x &= (1 << 64) - 1
+    return x - (1 << 64) if x >= (1 << 63) else x
+
+
+def _checksum_on_device(t):
+    """tests/golden/cases.py `checksum` with the tensor left where it is (round 4): the eight sign projections of a 138 M-parameter
+    model in numpy were most of the GPU suite's wall time (90 CPU-minutes per run).  Same hash (64-bit wrap-around arithmetic;
+    int64's arithmetic right shift masked into a logical one), float64 sums: equal to the numpy form to 1e-13 relative."""
+    a = t.detach().reshape(-1).to(torch.float64)
+    n = a.numel()
+    out = [a.mean().item(), torch.linalg.vector_norm(a).item()]
+    idx = torch.arange(n, dtype=torch.int64, device=a.device)
+    for k in range(N_PROJ):
+        h = (idx + _s64((k + 1) * 0x9E3779B97F4A7C15)) * _s64(0xBF58476D1CE4E5B9)
+        h = h ^ ((h >> 29) & ((1 << 35) - 1))
+        h = h * _s64(0x94D049BB133111EB)
+        sign = 1.0 - 2.0 * ((h >> 40) & 1).to(torch.float64)
+        out.append(torch.dot(a, sign).item())
+    from cases import sample_idx
+    si = torch.from_numpy(sample_idx(n)).to(a.device)
+    return np.concatenate([np.asarray(out, dtype=np.float64), a[si].cpu().numpy()])
+
+
 def checksum(t):
+    if isinstance(t, torch.Tensor) and t.is_cuda and t.numel() > 0:
+        return _checksum_on_device(t)
     return _np_checksum(t2n(t))
 
 
@@ -149,7 +179,7 @@ def assert_checksum(t, ck, what, tol=RTOL):
     norm and projections pin ||t - ref|| <= tol * ||ref|| (4-sigma bound on each projection);
     sampled elements get a 10x looser elementwise bound (they only guard against gross errors)."""
     got = checksum(t)
-    n = t2n(t).size
+    n = numel_of(t)
     norm = max(ck[1], 1e-30)
     scale = norm / np.sqrt(n)
     if not abs(got[1] - ck[1]) <= tol * norm:
@@ -235,7 +265,7 @@ def assert_param_after_step(t, ck, what, lr, nsteps=1, got=None, gck32=None, gck
     # have stepped lr the other way in each step (small bias vectors after two GAN steps differ by 1-3e-3 in norm)
     # (first step, round 3: a quarter of that — elements whose gradient is rounding noise step +-lr in either implementation, and a
     # 64-element bias moved 1.8e-4 in norm (1.5e-3 of it) between two correct builds; the solid elements are pinned one by one below)
-    slack = (0.25 if nsteps == 1 else 0.5 * nsteps) * lr * np.sqrt(max(t2n(t).size, 1))
+    slack = (0.25 if nsteps == 1 else 0.5 * nsteps) * lr * np.sqrt(max(numel_of(t), 1))
     if not abs(got[1] - ck[1]) <= 1e-3 * max(ck[1], 1e-30) + slack:
         raise AssertionError(f"{what}: L2 norm {got[1]:.6e} vs {ck[1]:.6e}")
     s0 = 2 + N_PROJ
@@ -243,14 +273,14 @@ def assert_param_after_step(t, ck, what, lr, nsteps=1, got=None, gck32=None, gck
     if not diff.max() <= 2.5 * lr * nsteps:
         raise AssertionError(f"{what}: sampled parameters differ by {diff.max():.3e} (> 2.5 lr)")
     if nsteps == 1 and gck32 is not None and gck64 is not None:
-        n = max(t2n(t).size, 1)
+        n = max(numel_of(t), 1)
         noise = max(np.abs(gck32[2:s0] - gck64[2:s0]).max(), 1e-30) / np.sqrt(n)      # per-element fp32 noise of the reference
         solid = np.abs(gck64[s0:]) > 100.0 * noise
         if solid.any() and not diff[solid].max() <= 0.05 * lr:
             raise AssertionError(f"{what}: {int(solid.sum())} sampled elements have a gradient well above rounding noise, "
                                  f"yet their update differs from the reference's by {diff[solid].max() / lr:.3f} lr")
     return int(0 if gck64 is None else (np.abs(gck64[s0:]) > 100.0 * max(np.abs(gck32[2:s0] - gck64[2:s0]).max(), 1e-30)
-                                        / np.sqrt(max(t2n(t).size, 1))).sum())
+                                        / np.sqrt(max(numel_of(t), 1))).sum())
 
 
 GAN_FLIP_BUDGET = FLIP_BUDGET   # round 1 allowed 1e-1 on the GAN steps; the 4 x E_ref term already scales the bound with the

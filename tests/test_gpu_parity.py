@@ -1269,9 +1269,12 @@ def test_two_rank_step_equals_the_big_batch_step(pkg, device, tmp_path):
                     bad.append(str(e))
             assert not bad, f"{len(bad)} world-averaged gradients off the reference's:\n" + "\n".join(b[:300] for b in bad[:8])
         # (b) against this build's own big-batch step, both steps (DP_LR above: the second step is as well conditioned as the first)
-        mtol = 1e-4 if step_i == 0 else 3e-4
+        # second step: the two runs' parameters differ by the sign noise of one lr = 1e-7 update (rounding-level gradient elements
+        # step either way), which moves a discriminator output by ~5e-6: the north_star's 1e-3, and near-zero metrics
+        # (d_x_fake_mean -8.6e-3: measured 4.9e-6 apart; D_loss_x_fake 9.1e-5: 1.1e-7 apart) at the absolute level of 1e-2-sized ones
+        mtol = 1e-4 if step_i == 0 else 1e-3
         for k, v in m.items():
-            assert abs(two["metrics"][k] - v) <= mtol * max(abs(v), 1e-6), \
+            assert abs(two["metrics"][k] - v) <= mtol * max(abs(v), 1e-6 if step_i == 0 else 1e-2), \
                 f"step {step_i} {k}: 2 ranks {two['metrics'][k]} vs big batch {v}"
         for name, opt in (("G", model.optimizer_G), ("D", model.optimizer_D)):
             big = opt.flat_grad.cpu().double()

@@ -195,14 +195,20 @@ __global__ __launch_bounds__(256, 2) void k_conv_thinin(ThinInP p) {
 }
 
 // ------------------------------------------------------------------------------------------------------------- host side
-// VCG_THININ=0: the generic implicit-GEMM kernel for these layers, as in round 3 (A/B measurements)
-static bool thinin_on() {
-  static const int on = [] { const char* e = getenv("VCG_THININ"); return e ? atoi(e) : 1; }();
-  return on != 0;
+// VCG_THININ: 0 = the generic implicit-GEMM kernel for both layers, as in round 3; 1 (default) = the discriminators' first layer
+// only; 2 = the stem as well.  The stem variant is as accurate as the kernel it replaces (tests/test_gpu_fullsize.py holds both to
+// 2e-6 against float64) and 144 -> 110 us per call, but it rounds differently, and on the batch-1 GAN fixture that moved ONE
+// gradient tensor (G.encoder.model.5.conv1.weight, whose reference fp32-vs-fp64 error is unusually small: 6.1e-3) from under
+// to over its fixture-calibrated bound — 2.84e-2 against 4 x 6.1e-3 = 2.43e-2, the ReLU-flip floor of that step being ~3e-2 on
+// its neighbours.  Rather than widen the bound for 0.14 ms per step, the stem keeps the round-3 kernel by default.
+static int thinin_mode() {
+  static const int m = [] { const char* e = getenv("VCG_THININ"); return e ? atoi(e) : 1; }();
+  return m;
 }
 bool vcg_thinin_fwd_ok(const ConvGeom& g) {
-  if (!thinin_on()) return false;
-  const bool stem = g.KH == 7 && g.KW == 7 && g.stride == 1 && g.pad == 3;
+  const int mode = thinin_mode();
+  if (mode <= 0) return false;
+  const bool stem = g.KH == 7 && g.KW == 7 && g.stride == 1 && g.pad == 3 && mode >= 2;
   const bool disc = g.KH == 4 && g.KW == 4 && g.stride == 2 && g.pad == 1;
   return (stem || disc) && g.ups == 1 && g.Cin == 4 && g.Cout == 64 && g.Ho % 16 == 0 && g.Wo % 16 == 0 && g.Ho > 0 && g.Wo > 0 &&
          (!g.reflect || (g.H > g.pad + 8 && g.W > g.pad + 8));
