@@ -61,10 +61,20 @@ def main():
     ap.add_argument("--latent", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--eager-child", action="store_true", help=argparse.SUPPRESS)      # internal: the rocm_eager_baseline child process
     ap.add_argument("--no-eager-baseline", action="store_true",
                     help="skip the stock PyTorch-ROCm (MIOpen / rocBLAS eager) run of the same step beside cpu_baseline")
     args = ap.parse_args()
 
+    if args.eager_child:
+        # a process of its own (spawned by rocm_eager_baseline below): a MIOpen fault or hang there cannot take the bench line with it
+        pkg = importlib.import_module("vae-cyclegan-implementation_amd")
+        wl = args.workload
+        B = args.batch or (16 if wl in SAME_XY else 8)
+        latent = args.latent or (1024 if wl == "vae" else 64)
+        torch.cuda.set_device(0)
+        print(json.dumps(_eager_baseline_run(pkg, wl, B, args.size, latent, torch.device("cuda", 0))), flush=True)
+        return
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -219,7 +229,7 @@ def main():
         gc.unfreeze()
         gc.collect()
         torch.cuda.empty_cache()
-        out["rocm_eager_baseline"] = rocm_eager_baseline(pkg, wl, B, S, latent, dev)
+        out["rocm_eager_baseline"] = rocm_eager_baseline(wl, B, S, latent)
     if world > 1:
         dist.barrier()
     if rank == 0:
@@ -429,7 +439,30 @@ def cpu_baseline(pkg, wl, S, latent):
                                                        "(BASELINE.md §2); not re-measured in this run"}}
 
 
-def rocm_eager_baseline(pkg, wl, B, S, latent, dev):
+def rocm_eager_baseline(wl, B, S, latent, timeout=240):
+    """`_eager_baseline_run` in a CHILD process (this script with --eager-child), after this process has measured and freed its own
+    model: whatever stock MIOpen / ATen do on this box — a fault, an exhaustive search that never ends — the measured line above
+    is already complete and is printed regardless.  (A child process, not an exec: the parent has initialised the GPU.)"""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--eager-child", "--workload", wl, "--batch", str(B), "--size", str(S), "--latent", str(latent)]
+    env = dict(os.environ)
+    env.setdefault("MIOPEN_FIND_MODE", "FAST")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    try:
+        res = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env)
+    except subprocess.TimeoutExpired:
+        return {"value": None, "error": f"the stock-PyTorch child did not finish within {timeout} s"}
+    for line in reversed(res.stdout.splitlines()):
+        if line.startswith("{"):
+            try:
+                return json.loads(line)
+            except ValueError:
+                break
+    return {"value": None, "error": f"child exited with {res.returncode}: {(res.stderr or res.stdout)[-300:]}"}
+
+
+def _eager_baseline_run(pkg, wl, B, S, latent, dev):
     """The same step on the same GPU through stock PyTorch-ROCm eager ops (MIOpen convolutions, ATen instance_norm / losses,
     autograd): the oracle's functional restatement — the reference's algorithm as written, six VAE forwards and the
     discriminator re-forward included — with its tensors on cuda:0 at the bench's batch size.  Outside the timed region, after
