@@ -482,6 +482,43 @@ def test_deferred_instance_norm_equals_the_materialised_path(pkg, oracle, device
     assert_close(dx1, xr.grad, "D -> D -> R input gradient", l2=1e-2, mx=1e-1)
 
 
+def test_fused_mu_logvar_convolution_equals_the_two_convolutions(pkg, device):
+    """ops.FusedConvPair (reference Networks.py:219-222: muConv and logvarConv[0] read one map): one convolution with the output
+    channels concatenated gives the two outputs, the input gradient and BOTH parameters' gradients of the two separate
+    convolutions — to fp32 rounding (other tiles / split-K plans) — and follows the members when they change."""
+    ops, N = pkg.ops, pkg.Networks
+    torch.manual_seed(11)
+    veb = N.VariationalEncoderBlock(256, 64).to(device)
+    x0 = torch.randn(2, 256, 16, 16, device=device)
+    eps = torch.randn(2, 64, 16, 16)
+    gz = torch.randn(2, 64, 16, 16, device=device)
+
+    def run(fused):
+        prev = ops.FUSE_MU_LOGVAR
+        ops.FUSE_MU_LOGVAR = fused
+        try:
+            for p_ in veb.parameters():
+                p_.grad = None
+            x = ops.to_nhwc(x0).requires_grad_(True)
+            ops.inject_eps([eps])
+            z, mu, lv = veb(x)
+            z.backward(ops.to_nhwc(gz))
+            return nchw(z), nchw(mu), nchw(lv), nchw(x.grad), {k: v.grad.detach().cpu().clone() for k, v in veb.named_parameters()}
+        finally:
+            ops.FUSE_MU_LOGVAR = prev
+
+    a, b = run(True), run(False)
+    for u, v, what in zip(a[:4], b[:4], ("z", "mu", "logvar", "dx")):
+        assert rel_l2(u, v) <= 2e-6, (what, rel_l2(u, v))
+    for k in b[4]:
+        assert rel_l2(a[4][k], b[4][k]) <= 2e-6, (k, rel_l2(a[4][k], b[4][k]))
+    # the concatenated copy follows the members: change one weight in place and the fused path sees it
+    with torch.no_grad():
+        veb.muConv.conv.weight.mul_(2.0)
+    a2, b2 = run(True), run(False)
+    assert rel_l2(a2[1], b2[1]) <= 2e-6 and rel_l2(a2[1], a[1]) > 0.1
+
+
 def test_in_place_writes_drop_the_amax_handle(pkg, device):
     """VERDICT r3 weak #8 / ADVICE r3: the handle a block leaves on its output describes the tensor's contents when it was
     written.  `h = block(x); h.mul_(2**10); block2(h)` must not scale h by the stale amax (the fp16 split has 2-4x of headroom:
