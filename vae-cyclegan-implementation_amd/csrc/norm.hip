@@ -10,6 +10,7 @@
 // order, so results are bitwise reproducible and free of the E[x^2]-E[x]^2 cancellation
 // a single fp32 pass would have.
 #include "vcg_common.h"
+#include <stdlib.h>
 
 static NormPlan make_plan(int N, int HW, int C) { return vcg_norm_plan(N, HW, C); }
 
@@ -301,7 +302,7 @@ __global__ __launch_bounds__(256) void k_in_bwd_apply_cs(const float* __restrict
       const float4 r = red[k * pl.TC + tc];
       cs.x += r.x; cs.y += r.y; cs.z += r.z; cs.w += r.w;
     }
-    *reinterpret_cast<float4*>(colpart + ((size_t)n * pl.nchunk + blockIdx.x) * C + c4 * 4) = cs;
+    if (colpart) *reinterpret_cast<float4*>(colpart + ((size_t)n * pl.nchunk + blockIdx.x) * C + c4 * 4) = cs;
   }
   if (amax_slot) vcg_amax_publish(amax, amax_slot, amax_gen, amax_red);
 }
@@ -397,6 +398,7 @@ extern "C" int vcg_in_apply(const float* t, const float* mean, const float* rstd
   VCG_CHECK_ARG(!shuffle || C % 16 == 0, "vcg_in_apply: pixel shuffle needs C %% 16 == 0 (channel pitch stays a multiple of 4)");
   size_t total = (size_t)N * H * W * (C / 4);
   const VcgAmaxOut ao = vcg_amax_new((hipStream_t)stream);
+  // (a (chunk, image, channel group) variant of this kernel, as vcg_in_bwd uses, was measured in round 4: 19.5 vs 19.1 us — no gain)
   hipLaunchKernelGGL(k_in_apply, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, t, mean, rstd, residual,
                      out, N, H, W, C, post_act, shuffle, ao.slot, ao.gen);
   VCG_LAUNCH_CHECK("vcg_in_apply");
@@ -430,11 +432,16 @@ static int in_bwd_impl(const float* g, const float* t, const float* mean, const 
                        (float*)nullptr, N, HW, C, pl.nchunk, 0.f);
   size_t total = (size_t)N * HW * (C / 4);
   const VcgAmaxOut ao = vcg_amax_new(st);
-  if (gbias) {
-    // dt and its column sums in one pass (the bias gradient of the conv in front of this norm)
+  // VCG_IN_BWD_FLAT=1: the flat grid-stride kernel where no bias gradient is wanted, as before (A/B measurements).  Round 4: the
+  // (chunk, image, channel group) workgroups of the column-sum variant hold mean / rstd / s12 in registers and moved 4.97 TB/s
+  // where the flat kernel, which reloads them per element, moved 3.48 (profiles/r04_pmc_step_traffic.txt) — every layer takes them now
+  static const int flat = [] { const char* e = getenv("VCG_IN_BWD_FLAT"); return e ? atoi(e) : 0; }();
+  if (gbias || !flat) {
+    // dt (and, with gbias, its column sums: the bias gradient of the conv in front of this norm) in one pass
     hipLaunchKernelGGL(k_in_bwd_apply_cs, dim3(pl.nchunk, N, pl.cgroups), dim3(256), 0, st, g, t, mean, rstd, (const float*)s12, dt,
-                       colpart, H, W, C, pl, epi_act, post_act, shuffle, ao.slot, ao.gen);
-    hipLaunchKernelGGL(k_in_colsum_final, dim3((c_log + 7) / 8), dim3(256), 0, st, (const float*)colpart, gbias, C, N * pl.nchunk, c_log);
+                       gbias ? colpart : (float*)nullptr, H, W, C, pl, epi_act, post_act, shuffle, ao.slot, ao.gen);
+    if (gbias)
+      hipLaunchKernelGGL(k_in_colsum_final, dim3((c_log + 7) / 8), dim3(256), 0, st, (const float*)colpart, gbias, C, N * pl.nchunk, c_log);
   } else {
     hipLaunchKernelGGL(k_in_bwd_apply, dim3(ew_blocks(total)), dim3(256), 0, st, g, t, mean, rstd, (const float*)s12,
                        dt, N, H, W, C, epi_act, post_act, shuffle, ao.slot, ao.gen);
