@@ -80,6 +80,14 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    # VCG_FORCE_DIST=1: a ONE-rank process group (the only RCCL run a one-GPU box allows): the step takes the whole data-parallel
+    # path — bucket launches from inside the backward on the reporting stream, RCCL's own stream, the waits before the optimizers,
+    # the metric average — with nothing to exchange; the line then carries process_group / exchange like an N > 1 line
+    dist_on = world > 1 or os.environ.get("VCG_FORCE_DIST") == "1"
+    if dist_on and world == 1:
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+        os.environ.setdefault("MASTER_PORT", "29531")
     # VCG_DIST_BACKEND=gloo + VCG_ONE_DEVICE=1: rehearsal of the N>1 path on a one-GPU box (all ranks on cuda:0,
     # exchange through the host); the driver's runs use the default: one rank per GPU, nccl (= RCCL over xGMI)
     backend = os.environ.get("VCG_DIST_BACKEND", "nccl")
@@ -90,7 +98,7 @@ def main():
         os.environ.setdefault("VCG_WGRAD_OVERLAP", "0")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    if dist_on:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
@@ -104,7 +112,7 @@ def main():
     # hipcc runs.  The decision is rank 0's alone and every rank takes the same collectives whatever it sees on disk (a rank
     # that started late and found the file rank 0 had just linked used to skip the barrier rank 0 was sitting in); the
     # link goes to a temporary name and is renamed into place (_native.build), so no rank maps a half-written file.
-    if world > 1:
+    if dist_on:
         flag = torch.tensor([0 if os.path.exists(pkg._native.LIB_PATH) else 1], dtype=torch.int32, device=dev if backend == "nccl" else "cpu")
         dist.broadcast(flag, src=0)
         if int(flag.item()) and rank == 0:
@@ -128,7 +136,7 @@ def main():
     model.configure_optimizers(lr=2e-4)
     model.configure_loss(lambda_kl=1e-5, lambda_gan=1.0, lambda_identity=5.0, lambda_cycle=10.0, lambda_recon=1.0)
     red = None
-    if world > 1:
+    if dist_on:
         red = pkg.parallel.attach(model)
         pkg.parallel.broadcast_parameters(model)
     ops.manual_seed(4321 + rank)
@@ -143,7 +151,7 @@ def main():
         pool.append({"x": x, "y": x if wl in SAME_XY else y})
 
     def barrier():
-        if world > 1:
+        if dist_on:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -173,7 +181,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     exposed_ms = None
-    if world > 1:
+    if dist_on:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = tt.item()
@@ -200,7 +208,7 @@ def main():
                    "image_size": S, "latent_dim": latent, "parallelism": f"dp{world}", "init": "random (reference init statistics)"},
     }
 
-    if world > 1:
+    if dist_on:
         st = red.stats
         out["exchange_exposed_ms"] = round(exposed_ms, 3)
         # what the process group actually saw: the first SCALE record must show that RCCL ran over N ranks on N devices
@@ -222,19 +230,19 @@ def main():
         roof = measure_roofline(pkg, model, pool, wl, B, S, latent, ms_per_step, rank)
         if rank == 0:
             out.update(roof)
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and wl in ("cyclevaegan", "vae", "autoencoder"):
+    if rank == 0 and not dist_on and not args.no_cpu_baseline and wl in ("cyclevaegan", "vae", "autoencoder"):
         out["cpu_baseline"] = cpu_baseline(pkg, wl, S, latent)
-    if rank == 0 and world == 1 and not args.no_eager_baseline and wl in ("cyclevaegan", "vae", "autoencoder"):
+    if rank == 0 and not dist_on and not args.no_eager_baseline and wl in ("cyclevaegan", "vae", "autoencoder"):
         del model, pool
         gc.unfreeze()
         gc.collect()
         torch.cuda.empty_cache()
         out["rocm_eager_baseline"] = rocm_eager_baseline(wl, B, S, latent)
-    if world > 1:
+    if dist_on:
         dist.barrier()
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist_on:
         dist.destroy_process_group()
 
 

@@ -1328,3 +1328,86 @@ def test_two_rank_step_equals_the_big_batch_step(pkg, device, tmp_path):
             assert err <= gtol, f"step {step_i} optimizer_{name}: averaged shard gradients differ from the big-batch gradient by {err:.2e}"
             dp = (two["param" + name] - opt.flat_param.cpu()).abs().max().item()
             assert dp <= 2.5 * DP_LR * (step_i + 1), f"step {step_i} optimizer_{name}: parameters differ by {dp:.2e}"
+
+
+# ------------------------------------------------------------------ RCCL itself, as far as one card allows: a one-rank process group
+def _rccl_one_rank_worker(rank, port, outdir):
+    """The data-parallel step over the `nccl` backend (= RCCL on ROCm) with world size 1: everything an N-rank step does on the
+    device side runs — ncclCommInitRank, the bucket all-reduces launched from inside the backward under the reporting stream,
+    RCCL's own stream ordered after it, `work.wait()` before the optimizers, the metric average and the collective
+    skip-decision on device tensors — only the peers are missing (gloo, which the two-rank test uses, takes none of these)."""
+    import importlib
+    import torch.distributed as dist
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    os.environ["VCG_BUCKET_MB"] = "16"
+    os.environ["VCG_DP_FROM_BACKWARD"] = "1"
+    pkg = importlib.import_module("vae-cyclegan-implementation_amd")
+    from conftest import SEED as seed
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    from cases import LAMBDAS as lambdas, LR as lr, STEP_BIAS_STD as bstd
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=0, world_size=1, init_method=f"tcp://127.0.0.1:{port}", device_id=dev)
+    try:
+        model = pkg.Networks.CycleVAEGAN(latent_dim=64, paired=False)
+        shapes = {"dp." + k: tuple(v.shape) for k, v in model.state_dict().items()}
+        sd = pkg.synth.state_dict_like(shapes, seed, bias_std=bstd)
+        model.load_state_dict({k[3:]: torch.from_numpy(v) for k, v in sd.items()})
+        model = model.to(dev).train()
+        model.configure_optimizers(lr=lr)
+        model.configure_loss(**lambdas)
+        red = pkg.parallel.attach(model)
+        pkg.parallel.broadcast_parameters(model)
+        out = {"steps": [], "backend": dist.get_backend(), "world": dist.get_world_size()}
+        for step in (3, 4):
+            x, y = pkg.synth.batch(1, 256, seed, step=step)
+            pkg.ops.inject_eps([torch.from_numpy(e) for e in pkg.synth.eps_list(6, (1, 64, 16, 16), seed, step=step)])
+            n0 = len(red.log)
+            m = model.training_step({"x": torch.from_numpy(x).to(dev), "y": torch.from_numpy(y).to(dev)})
+            torch.cuda.synchronize()
+            out["steps"].append({"metrics": m, "gradG": model.optimizer_G.flat_grad.cpu(), "gradD": model.optimizer_D.flat_grad.cpu(),
+                                 "paramG": model.optimizer_G.flat_param.cpu(), "paramD": model.optimizer_D.flat_param.cpu(),
+                                 "log": list(red.log[n0:])})
+        out["scale"] = model.optimizer_G.grad_scale
+        out["exposed_ms"] = red.exposed_ms()
+        out["any_rank"] = (red.any_rank(False), red.any_rank(True))
+        torch.save(out, os.path.join(outdir, "rccl1.pt"))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rccl_one_rank_step_is_bitwise_the_plain_step(pkg, device, tmp_path):
+    """SURVEY.md §8e on the hardware this suite gets: the exchange over RCCL with one rank (a sum over one rank is the identity,
+    1/world = 1) must leave the step bit-for-bit what it is without a reducer — two steps, the second with its buckets launched
+    from inside the backward.  A bucket reduced before a producer stream had finished, a wait the compute stream skipped or a
+    slice RCCL wrote late would change bits here exactly as on eight ranks."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_rccl_one_rank_worker, args=(port, str(tmp_path)), nprocs=1, join=True)
+    got = torch.load(str(tmp_path / "rccl1.pt"), weights_only=False)
+    assert got["backend"] == "nccl" and got["world"] == 1 and got["scale"] == 1.0
+    assert got["any_rank"] == (False, True)
+    log2 = got["steps"][1]["log"]
+    assert log2 and all(w == "backward" for *_, w in log2), log2
+    assert len({b for tag, b, *_ in log2 if tag == "optimizer_G"}) >= 3
+    model = pkg.Networks.CycleVAEGAN(latent_dim=64, paired=False)
+    load_synth(pkg, model, "dp", STEP_BIAS_STD)
+    model = model.to(device).train()
+    model.configure_optimizers(lr=LR)
+    model.configure_loss(**LAMBDAS)
+    for step_i, step in enumerate((3, 4)):
+        x, y = pkg.synth.batch(1, 256, SEED, step=step)
+        pkg.ops.inject_eps([torch.from_numpy(e) for e in pkg.synth.eps_list(6, (1, 64, 16, 16), SEED, step=step)])
+        m = model.training_step({"x": torch.from_numpy(x).to(device), "y": torch.from_numpy(y).to(device)})
+        one = got["steps"][step_i]
+        assert one["metrics"] == m, f"step {step_i}: metrics over RCCL {one['metrics']} vs plain {m}"
+        for name, opt in (("G", model.optimizer_G), ("D", model.optimizer_D)):
+            assert torch.equal(one["grad" + name], opt.flat_grad.cpu()), f"step {step_i}: optimizer_{name} gradients changed under RCCL"
+            assert torch.equal(one["param" + name], opt.flat_param.cpu()), f"step {step_i}: optimizer_{name} parameters changed under RCCL"
+    print(f"one-rank RCCL: {len(log2)} buckets from inside the backward; compute stream waited {got['exposed_ms']:.3f} ms over two steps")

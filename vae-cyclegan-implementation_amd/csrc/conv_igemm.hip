@@ -1668,18 +1668,17 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ 
   const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int cinL = cin_log * U2;
   const int run = 8 * U2 * KK;                                   // OIHW elements per co in this block
-  for (int j = 0; j < 8; ++j) {
+  // a wave's 8 output channels x `run` elements as one flat index space (full trips of 64 lanes; see k_wino_wgrad_reduce)
+  for (int idx = lane; idx < 8 * run; idx += 64) {
+    const int j = idx / run, q = idx - j * run;
     const int colw = wid * 8 + j, co = co0 + colw;
-    if (co >= cout_log) continue;
-    for (int q = lane; q < run; q += 64) {
-      const int clq = q / KK, tap9 = q - clq * KK;                 // clq = c_local*U2 + phase
-      const int c_local = clq / U2, ph = clq - c_local * U2;
-      const int c = c0 + c_local;
-      if (c >= cin_log) continue;
-      const int t = tap9 * U2 + ph;
-      const size_t o = ((size_t)co * cinL + (size_t)c * U2 + ph) * KK + tap9;
-      gw[o] += tile[(t * 8 + c_local) * 33 + colw];
-    }
+    const int clq = q / KK, tap9 = q - clq * KK;                   // clq = c_local*U2 + phase
+    const int c_local = clq / U2, ph = clq - c_local * U2;
+    const int c = c0 + c_local;
+    if (co >= cout_log || c >= cin_log) continue;
+    const int t = tap9 * U2 + ph;
+    const size_t o = ((size_t)co * cinL + (size_t)c * U2 + ph) * KK + tap9;
+    gw[o] += tile[(t * 8 + c_local) * 33 + colw];
   }
 }
 
@@ -1739,15 +1738,15 @@ __global__ __launch_bounds__(256) void k_wino_wgrad_reduce(const float* __restri
   __syncthreads();
   const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int cinL = cin_log * U2;
-  for (int j = 0; j < 16; ++j) {
+  // a wave's 16 output channels x 72 (c, tap) elements as ONE flat index space: 18 full trips of 64 lanes (round 4; per channel
+  // the 72-element run took two trips with 8 lanes of the second one active)
+  for (int idx = lane; idx < 16 * 8 * KK; idx += 64) {
+    const int j = idx / (8 * KK), q = idx - j * (8 * KK);
     const int colw = wid * 16 + j, co = co0 + colw;
-    if (co >= cout_log) continue;
-    for (int q = lane; q < 8 * KK; q += 64) {
-      const int c_local = q / KK, tap9 = q - c_local * KK;
-      const int c = c0 + c_local;
-      if (c >= cin_log) continue;
-      gw[((size_t)co * cinL + (size_t)c * U2 + ph) * KK + tap9] += tile[(tap9 * 8 + c_local) * 65 + colw];
-    }
+    const int c_local = q / KK, tap9 = q - c_local * KK;
+    const int c = c0 + c_local;
+    if (co >= cout_log || c >= cin_log) continue;
+    gw[((size_t)co * cinL + (size_t)c * U2 + ph) * KK + tap9] += tile[(tap9 * 8 + c_local) * 65 + colw];
   }
 }
 
