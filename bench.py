@@ -20,6 +20,7 @@ import time
 
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # RCCL across processes needs dmabuf IPC on this driver
 os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")        # kernel arguments in device memory: shorter dispatch gaps (package __init__)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")            # one hardware queue per stream once RCCL has added its own (package __init__)
 
 import torch  # noqa: E402
 
@@ -138,6 +139,13 @@ def main():
     red = None
     if dist_on:
         red = pkg.parallel.attach(model)
+        if os.environ.get("VCG_DP_NULL_EXCHANGE") == "1":
+            # diagnostic (tools/dp_one_rank.sh): the reducer's bookkeeping and stream ordering with the collective itself left out
+            class _Done:
+                def wait(self):
+                    return True
+            _real = dist.all_reduce
+            dist.all_reduce = lambda t, *a, **k: _Done() if k.get("async_op") else _real(t, *a, **k)
         pkg.parallel.broadcast_parameters(model)
     ops.manual_seed(4321 + rank)
 
