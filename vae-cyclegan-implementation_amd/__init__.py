@@ -20,5 +20,6 @@ _os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 from . import _native, ops, optim, synth  # noqa: F401,E402
 from . import Losses, Networks, input_pipeline, parallel, utils  # noqa: F401,E402
+from . import custom_ops  # noqa: F401,E402  (registers torch.ops.vcg.*)
 
-__all__ = ["_native", "ops", "optim", "synth", "Losses", "Networks", "input_pipeline", "parallel", "utils"]
+__all__ = ["_native", "ops", "optim", "synth", "Losses", "Networks", "input_pipeline", "parallel", "utils", "custom_ops"]
