@@ -165,3 +165,23 @@ def test_two_blocks_under_torch_compile_aot_eager(device):
     assert torch.equal(eager, comp)
     for a, b in zip(ge, gc):
         assert _rel(a, b) <= 1e-6
+
+
+@pytest.mark.gpu
+def test_the_op_is_a_function_of_the_weight_values(device):
+    """No pack is cached across calls: a weight rewritten through `.data` (no version bump — what a hand-rolled optimizer or a
+    broadcast does) is seen by the next call, forward and backward."""
+    block = BLOCKS[4]
+    x, w, b, _ = _inputs(block, device)
+    kw = dict(stride=1, pad=1, epi_act=ops.ACT_NONE, norm=False)
+    o1 = cops.conv_block(x, w, None, None, **kw)
+    (dx1,) = torch.autograd.grad(o1, (x,), torch.ones_like(o1), retain_graph=True)
+    ver = w._version
+    w.data.mul_(2.0)
+    assert w._version == ver
+    o2 = cops.conv_block(x, w, None, None, **kw)
+    (dx2,) = torch.autograd.grad(o2, (x,), torch.ones_like(o2))
+    assert _rel(o2.detach(), 2.0 * o1.detach()) <= 1e-6 and _rel(dx2, 2.0 * dx1) <= 1e-6
+    # ... and the FIRST graph's backward, run now, sees the weight as it is now too (it is saved by reference, like any torch op's)
+    (dx1_late,) = torch.autograd.grad(o1, (x,), torch.ones_like(o1))
+    assert _rel(dx1_late, dx2) <= 1e-6

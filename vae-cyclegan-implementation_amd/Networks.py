@@ -543,26 +543,58 @@ class CycleVAEGAN(nn.Module):
         lat = vae.variational_encoder_block.latent_dim
         ops.next_eps((n, lat, h // 16, w // 16), ref_shape_src.device, skip=True)
 
-    def _generator_losses(self, x, y):
-        """Forward of both generators and everything G_loss needs (reference :1997-2018)."""
-        Gx, mu_x, lv_x = self.G(x)
-        if self.paired:
-            Gy, _, _ = self.G(y)
-        else:
-            Gy = None
-            self._skip_vae(y, self.G)
-        FGx, mu_FGx, lv_FGx = self.F(Gx)
-        Fy, mu_y, lv_y = self.F(y)
-        if self.paired:
-            Fx, _, _ = self.F(x)
-        else:
-            Fx = None
-            self._skip_vae(x, self.F)
-        GFy, mu_GFy, lv_GFy = self.G(Fy)
+    def _forward_two_streams(self, x, y):
+        """The unpaired forward with the two translation directions on two streams (ops.DirectionFork): x -> G -> F -> DY on the
+        caller's stream, y -> F -> G -> DX on the second one, issued interleaved so that both have work from the start.  Same
+        results bit for bit: the eps draws are reserved in the reference's call order (G(x), [G(y)], F(G(x)), F(y), [F(x)],
+        G(F(y))), each discriminator still sees its two inputs in the reference's order (spectral norm's power iteration
+        advances per call: DY: G(x) then y; DX: F(y) then x)."""
+        n, _, h, w = x.shape
+        shp = (n, self.G.variational_encoder_block.latent_dim, h // 16, w // 16)
+        tk = ops.eps_tickets([(shp, False), (shp, True), (shp, False), (shp, False), (shp, True), (shp, False)], x.device)
+        ops.premeasure(x)
+        ops.premeasure(y)
+        fork = ops.DirectionFork(x.device)
+        with ops.use_ticket(tk[0]):
+            Gx, mu_x, lv_x = self.G(x)
+        with fork.second(), ops.use_ticket(tk[3]):
+            Fy, mu_y, lv_y = self.F(y)
+        with ops.use_ticket(tk[2]):
+            FGx, mu_FGx, lv_FGx = self.F(Gx)
+        with fork.second(), ops.use_ticket(tk[5]):
+            GFy, mu_GFy, lv_GFy = self.G(Fy)
         DYGx = self.DY(Gx)
-        DXFy = self.DX(Fy)
-        DXx = self.DX(x)
+        with fork.second():
+            DXFy = self.DX(Fy)
+            DXx = self.DX(x)
         DYy = self.DY(y)
+        fork.join()
+        return (Gx, mu_x, lv_x, FGx, mu_FGx, lv_FGx, Fy, mu_y, lv_y, GFy, mu_GFy, lv_GFy, DYGx, DXFy, DXx, DYy)
+
+    def _generator_losses(self, x, y, two_streams=False):
+        """Forward of both generators and everything G_loss needs (reference :1997-2018).  `two_streams`: see
+        `_forward_two_streams` (training_step / validation_step ask for it when the weight gradients overlap too)."""
+        Gy = Fx = None
+        if two_streams and not self.paired and x.is_cuda:
+            (Gx, mu_x, lv_x, FGx, mu_FGx, lv_FGx, Fy, mu_y, lv_y, GFy, mu_GFy, lv_GFy, DYGx, DXFy, DXx,
+             DYy) = self._forward_two_streams(x, y)
+        else:
+            Gx, mu_x, lv_x = self.G(x)
+            if self.paired:
+                Gy, _, _ = self.G(y)
+            else:
+                self._skip_vae(y, self.G)
+            FGx, mu_FGx, lv_FGx = self.F(Gx)
+            Fy, mu_y, lv_y = self.F(y)
+            if self.paired:
+                Fx, _, _ = self.F(x)
+            else:
+                self._skip_vae(x, self.F)
+            GFy, mu_GFy, lv_GFy = self.G(Fy)
+            DYGx = self.DY(Gx)
+            DXFy = self.DX(Fy)
+            DXx = self.DX(x)
+            DYy = self.DY(y)
 
         t = {}
         t["loss_cycle"] = self.loss_cycle(x, y, FGx, GFy)
@@ -611,7 +643,7 @@ class CycleVAEGAN(nn.Module):
 
         red = self.grad_reducer
         self.optimizer_G.zero_grad()
-        t, _, _ = self._generator_losses(x, y)
+        t, _, _ = self._generator_losses(x, y, two_streams=ops.two_directions())
         if red is not None:
             red.begin(self.optimizer_G)          # F+G buckets are all-reduced from inside the backward as they complete
         # generator gradients reach F and G only (the discriminators contribute their data gradient)
@@ -703,16 +735,34 @@ class CycleAEGAN(CycleVAEGAN):
         if need_opt and (self.optimizer_G is None or self.optimizer_D is None):
             raise ValueError("Optimizers have not been configured yet.")
 
-    def _generator_losses(self, x, y):
-        """reference :1733-1753; G(y), F(x) feed only the identity loss and are skipped when unpaired."""
-        Gx = self.G(x)
-        FGx = self.F(Gx)
-        Fy = self.F(y)
-        GFy = self.G(Fy)
-        DYGx = self.DY(Gx)
-        DXFy = self.DX(Fy)
-        DXx = self.DX(x)
-        DYy = self.DY(y)
+    def _generator_losses(self, x, y, two_streams=False):
+        """reference :1733-1753; G(y), F(x) feed only the identity loss and are skipped when unpaired.  `two_streams`: the two
+        translation directions on two streams (CycleVAEGAN._forward_two_streams; no eps here)."""
+        if two_streams and not self.paired and x.is_cuda:
+            ops.premeasure(x)
+            ops.premeasure(y)
+            fork = ops.DirectionFork(x.device)
+            Gx = self.G(x)
+            with fork.second():
+                Fy = self.F(y)
+            FGx = self.F(Gx)
+            with fork.second():
+                GFy = self.G(Fy)
+            DYGx = self.DY(Gx)
+            with fork.second():
+                DXFy = self.DX(Fy)
+                DXx = self.DX(x)
+            DYy = self.DY(y)
+            fork.join()
+        else:
+            Gx = self.G(x)
+            FGx = self.F(Gx)
+            Fy = self.F(y)
+            GFy = self.G(Fy)
+            DYGx = self.DY(Gx)
+            DXFy = self.DX(Fy)
+            DXx = self.DX(x)
+            DYy = self.DY(y)
         t = {}
         t["loss_cycle"] = self.loss_cycle(x, y, FGx, GFy)
         t["loss_gan_g_x_fake"], t["d_x_fake_mean"] = ops.mse_const(DXFy, 1.0)

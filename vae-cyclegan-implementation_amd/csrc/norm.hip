@@ -327,7 +327,9 @@ __global__ __launch_bounds__(256) void k_in_colsum_final(const float* __restrict
   if (kl == 0 && c < c_log) {
     float s = red[0][il];
     for (int k = 1; k < 32; ++k) s += red[k][il];
-    out[c] += s;
+    // atomic: the two translation directions of a cycle model differentiate the SAME generator on two streams
+    // (ops.DirectionFork); with two contributions into a zeroed buffer the sum does not depend on their order
+    atomicAdd(out + c, s);
   }
 }
 

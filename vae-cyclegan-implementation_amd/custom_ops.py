@@ -10,7 +10,7 @@ module is the same block WITHOUT them, for every other caller:
     RETURNS dx / dweight / dbias — any optimizer, `torch.autograd.grad`, gradient checkers work;
   * registered with the dispatcher (`torch.library.custom_op`), with fake (shape-only) implementations and
     `register_autograd`, so `torch.compile` / `make_fx` trace through a model that uses it as one opaque node per block and
-    `torch.library.opcheck` can test the registration (tests/test_gpu_custom_ops.py);
+    `torch.library.opcheck` can test the registration (tests/test_custom_ops.py);
   * the same C-ABI entry points underneath (include/vcg.h: vcg_conv_fwd_in_h, vcg_in_apply_h, vcg_in_bwd_h, vcg_act_bwd_h,
     vcg_conv_wgrad_saved_h, vcg_conv_dgrad_h) — no second implementation, and no CPU path: a CPU tensor raises.
 
@@ -26,7 +26,7 @@ from torch import Tensor
 
 from . import _native, ops
 
-_SPECS = OrderedDict()          # (geometry, weight storage) -> ConvSpec: the packed-weight cache of a spec follows ONE weight tensor
+_SPECS = OrderedDict()          # geometry -> ConvSpec (descriptor builder only: nothing about a weight is cached here)
 _SPECS_MAX = 512
 
 
@@ -34,7 +34,7 @@ def _spec_for(weight, stride, pad, reflect, ups, epi_act, norm, post_act, shuffl
     cout, cin, k, k2 = weight.shape
     if k != k2:
         raise RuntimeError(f"vcg::conv_block: square kernels only, got {k} x {k2}")
-    key = (cin, cout, k, stride, pad, reflect, ups, epi_act, norm, post_act, shuffle, weight.data_ptr(), weight.device.index)
+    key = (cin, cout, k, stride, pad, reflect, ups, epi_act, norm, post_act, shuffle)
     sp = _SPECS.get(key)
     if sp is None:
         sp = ops.ConvSpec(cin, cout, k, stride, pad, reflect, ups, epi_act, norm, post_act, shuffle)
@@ -44,6 +44,17 @@ def _spec_for(weight, stride, pad, reflect, ups, epi_act, norm, post_act, shuffl
     else:
         _SPECS.move_to_end(key)
     return sp
+
+
+def _fresh_pack(spec, weight, geom):
+    """The packed form of `weight` (include/vcg.h, vcg_pack_weight), made for THIS call into a buffer of its own.  The training
+    path caches packs per parameter and optimizer step (`ConvSpec.packed`, keyed on torch's version counter); a functional op has
+    no such contract with its caller — a weight written through `.data`, or a new tensor that landed on a freed one's address,
+    looks unchanged to any key short of the contents — so the op pays one pack launch per call instead."""
+    spec._packed = spec._packed_key = None
+    wf = spec.packed(weight, geom)
+    spec._packed = spec._packed_key = None
+    return wf
 
 
 def _geometry(x, weight, stride, pad, ups, norm, shuffle):
@@ -83,7 +94,7 @@ def conv_block_op(x: Tensor, weight: Tensor, bias: Optional[Tensor], residual: O
     ho, wo = spec.out_hw(h, w)
     cd = spec.desc(n, h, w)
     dev = x.device
-    wf = spec.packed(weight, (n, h, w))
+    wf = _fresh_pack(spec, weight, (n, h, w))
     c = spec.cout_pitch
     t = torch.empty((n, ho, wo, c), dtype=torch.float32, device=dev)
     none = ctypes.c_void_p(0)
@@ -167,7 +178,7 @@ def conv_block_backward_op(g: Tensor, x: Tensor, weight: Tensor, out: Tensor, t:
         if need_db:
             db = gb
     if need_dx:
-        wf = spec.packed(weight, (n, h, w))
+        wf = _fresh_pack(spec, weight, (n, h, w))
         dxp = torch.empty_like(xp)
         ws = ops.workspace(lib.vcg_conv_dgrad_workspace(cd), dev)
         _native.check(lib.vcg_conv_dgrad_h(ops._ptr(dt), ops._ptr(wf), ops._ptr(dxp), cd, ops._ptr(ws), ws.numel() * 4, 0, ops._stream()),

@@ -105,6 +105,52 @@ def _side_stream(device):
 def join_side_streams():
     for st in _SIDE.values():
         torch.cuda.current_stream(st.device).wait_stream(st)
+    for st in _DIR.values():
+        torch.cuda.current_stream(st.device).wait_stream(st)
+
+
+# ------------------------------------------------------------------ the two translation directions of a cycle model on two streams
+# x -> G(x) -> F(G(x)) -> DY and y -> F(y) -> G(F(y)) -> DX share no activation: `DirectionFork` runs the second chain on a stream
+# of its own (forward of both directions + discriminators at batch 8: 10.35 -> 8.74 ms, tools/fwd_overlap_probe.py).  Autograd
+# runs every backward node on the stream its forward ran on and orders the edges between them, so the two data-gradient chains
+# overlap as well; weight gradients of BOTH chains go to the one weight-gradient stream (they accumulate into the same buffers:
+# G and F are used by both chains), which is why this needs `wgrad_overlap` — `two_directions()` is false without it — and the
+# one accumulation that stays on a chain's stream (bias gradients out of vcg_in_bwd_bias) is atomic.  What the second chain reads
+# that is produced after the fork and is not an autograd edge must be ordered by hand: weight packs and the fused mu / logvar
+# weights carry events (`ConvSpec.packed`, `FusedConvPair.tensors`), the images' magnitudes are measured before the fork
+# (`premeasure`).  VCG_DIR_STREAMS=0: one chain after the other, as in rounds 1-3.
+DIRECTION_STREAMS = os.environ.get("VCG_DIR_STREAMS", "1") != "0"
+_DIR = {}
+
+
+def two_directions():
+    return DIRECTION_STREAMS and OVERLAP_ENABLED
+
+
+class DirectionFork:
+    def __init__(self, device):
+        idx = device.index if device.index is not None else torch.cuda.current_device()
+        st = _DIR.get(idx)
+        if st is None:
+            st = torch.cuda.Stream(device=device)
+            _DIR[idx] = st
+        self.second_stream = st
+        self.main = torch.cuda.current_stream(device)
+        st.wait_stream(self.main)                # everything issued so far (inputs, zeroed gradients, the optimizer's writes)
+
+    def second(self):
+        """Context: issue on the second chain's stream (no wait: the chains are independent after the fork)."""
+        return torch.cuda.stream(self.second_stream)
+
+    def join(self):
+        self.main.wait_stream(self.second_stream)
+
+
+def premeasure(t):
+    """Publish the largest magnitude of `t` now, on the current stream, unless a valid handle is already on it: a tensor that
+    two streams will read must not be measured by one of them after they have forked."""
+    if AMAX_HANDLES and t.is_cuda and not _amax_of(t):
+        _amax_tag(t, _measured_amax(as_phys(t)))
 
 
 class wgrad_overlap:
@@ -696,6 +742,7 @@ class FusedConvPair:
         self.w = self.bias = None
         self.key = None
         self.epoch = [0]
+        self._stream = self._event = None          # where / when the concatenated copy was last refreshed
 
     def tensors(self):
         wa, wb, ba, bb = self.a.weight, self.b.weight, self.a.bias, self.b.bias
@@ -723,6 +770,13 @@ class FusedConvPair:
                 self.bias.data[ca:].copy_(bb.data)
             self.epoch[0] += 1
             self.key = key
+            self._stream = torch.cuda.current_stream(wa.device)
+            self._event = torch.cuda.Event()
+            self._event.record(self._stream)
+        elif self._event is not None:
+            cur = torch.cuda.current_stream(wa.device)
+            if cur != self._stream:               # refreshed by the other direction's chain (DirectionFork): order after it
+                cur.wait_event(self._event)
         rg = wa.requires_grad or wb.requires_grad
         self.w.requires_grad_(rg)
         self.bias.requires_grad_(rg)
@@ -819,9 +873,63 @@ def inject_eps(tensors):
     _EPS_QUEUE.extend(tensors)
 
 
+_TICKETS = []          # draw positions handed out ahead of time (eps_tickets), consumed by the next reparameterisations in call order
+_FORCED_OFFSETS = []
+
+
+def eps_tickets(plan, device):
+    """Reserve the eps draws of several reparameterisations in the REFERENCE's call order, to be used in another one (the two
+    directions of a cycle model are issued interleaved on two streams).  `plan`: [(shape, skip)]; returns one ticket per entry
+    (None for skipped ones) for `use_ticket`."""
+    out = []
+    for shape, skip in plan:
+        if _EPS_QUEUE:
+            e = _EPS_QUEUE.pop(0)
+            if skip:
+                out.append(None)
+                continue
+            if tuple(e.shape) != tuple(shape):
+                raise RuntimeError(f"injected eps has shape {tuple(e.shape)}, expected {tuple(shape)}")
+            out.append(("tensor", e))
+        else:
+            n = 1
+            for s_ in shape:
+                n *= s_
+            off = _RNG["offset"]
+            _RNG["offset"] += (n + 3) // 4
+            out.append(None if skip else ("offset", off))
+    return out
+
+
+class use_ticket:
+    """The next reparameterisation inside this block draws at the reserved position."""
+
+    def __init__(self, ticket):
+        self.ticket = ticket
+
+    def __enter__(self):
+        _TICKETS.append(self.ticket)
+
+    def __exit__(self, *exc):
+        left = [i for i, t in enumerate(_TICKETS) if t is self.ticket]
+        if left:
+            del _TICKETS[left[0]]
+            if not exc or exc[0] is None:
+                raise RuntimeError("an eps ticket was not consumed: the block ran no reparameterisation")
+        return False
+
+
 def next_eps(shape, device, skip=False):
     """Either the next injected eps (as an nhwc view) or None (draw on device).  `skip` consumes
     the stream position of a forward the caller does not compute."""
+    if _TICKETS:
+        kind, val = _TICKETS.pop(0)
+        if skip:
+            raise RuntimeError("a reserved eps draw cannot be skipped")
+        if kind == "tensor":
+            return to_nhwc(val.to(device))
+        _FORCED_OFFSETS.append(val)
+        return None
     if _EPS_QUEUE:
         e = _EPS_QUEUE.pop(0)
         if skip:
@@ -853,8 +961,11 @@ class _ReparamFn(torch.autograd.Function):
                                               _stream()), "vcg_reparam_fwd")
         else:
             epsp = torch.empty_like(mup)
-            off = _RNG["offset"]
-            _RNG["offset"] += (n_el + 3) // 4
+            if _FORCED_OFFSETS:
+                off = _FORCED_OFFSETS.pop(0)      # reserved by eps_tickets (the counter has already moved past it)
+            else:
+                off = _RNG["offset"]
+                _RNG["offset"] += (n_el + 3) // 4
             _native.check(lib.vcg_reparam_fwd(_ptr(mup), _ptr(lvp), None, _ptr(epsp), _ptr(z), _ptr(lvc), n_el,
                                               _RNG["seed"], off, _stream()), "vcg_reparam_fwd")
         ctx.save_for_backward(epsp, lvp)
