@@ -1411,3 +1411,48 @@ def test_rccl_one_rank_step_is_bitwise_the_plain_step(pkg, device, tmp_path):
             assert torch.equal(one["grad" + name], opt.flat_grad.cpu()), f"step {step_i}: optimizer_{name} gradients changed under RCCL"
             assert torch.equal(one["param" + name], opt.flat_param.cpu()), f"step {step_i}: optimizer_{name} parameters changed under RCCL"
     print(f"one-rank RCCL: {len(log2)} buckets from inside the backward; compute stream waited {got['exposed_ms']:.3f} ms over two steps")
+
+
+# ------------------------------------------------------------------ the two translation directions on two streams
+@pytest.mark.parametrize("arch", ["cyclevaegan", "cycleaegan", "cyclevae", "cycleae", "doubleae", "doublevae"])
+def test_two_direction_streams_change_no_bit(arch, pkg, device):
+    """ops.DirectionFork: the second direction's chain (forward, and through autograd's stream semantics its backward) on a
+    stream of its own must leave two training steps bit for bit what they are on one stream — metrics, gradients, parameters.
+    What could differ if the ordering by hand were wrong: eps positions (drawn on device: the tickets reserve them in the
+    reference's call order), a weight pack or fused mu / logvar weight refreshed by the other chain and read too early (second
+    step), an image's magnitude measured by one chain after the fork, the accumulation order into the gradients of the
+    generators both chains use (one weight-gradient stream; the bias sums are atomic with two commutative contributions)."""
+    N = pkg.Networks
+    make = {"cyclevaegan": lambda: N.CycleVAEGAN(latent_dim=64, paired=False), "cycleaegan": lambda: N.CycleAEGAN(paired=False),
+            "cyclevae": lambda: N.CycleVAE(latent_dim=64, paired=True), "cycleae": lambda: N.CycleAE(paired=False),
+            "doubleae": N.DoubleAutoencoder, "doublevae": lambda: N.DoubleVariationalAutoencoder(latent_dim=64)}[arch]
+    S, B = (256, 1) if arch.endswith("gan") else (64, 2)      # the discriminator's full-map head fixes 256 x 256 images
+
+    def run(flag):
+        saved = pkg.ops.DIRECTION_STREAMS
+        pkg.ops.DIRECTION_STREAMS = flag
+        try:
+            model = make()
+            load_synth(pkg, model, "dir", STEP_BIAS_STD)
+            model = model.to(device).train()
+            model.configure_optimizers(lr=LR)
+            model.configure_loss(**LAMBDAS)
+            pkg.ops.manual_seed(11)
+            out = []
+            for step in range(2):
+                x, y = pkg.synth.batch(B, S, SEED, step=step)
+                m = model.training_step({"x": torch.from_numpy(x).to(device), "y": torch.from_numpy(y).to(device)})
+                opts = [getattr(model, n) for n in ("optimizer", "optimizer_G", "optimizer_D") if getattr(model, n, None) is not None]
+                torch.cuda.synchronize()
+                out.append((m, [o.flat_grad.clone() for o in opts], [o.flat_param.clone() for o in opts]))
+            return out
+        finally:
+            pkg.ops.DIRECTION_STREAMS = saved
+
+    assert pkg.ops.OVERLAP_ENABLED, "the direction streams need the weight-gradient stream (VCG_WGRAD_OVERLAP=0 is set)"
+    one, two = run(False), run(True)
+    assert pkg.ops._DIR, "the second-direction stream was never created: the two-stream path did not run"
+    for step, ((m1, g1, p1), (m2, g2, p2)) in enumerate(zip(one, two)):
+        assert m1 == m2, f"{arch} step {step}: metrics {m1} vs {m2}"
+        for a, b in zip(g1 + p1, g2 + p2):
+            assert torch.equal(a, b), f"{arch} step {step}: a gradient or parameter buffer differs by {(a - b).abs().max().item():.3e}"

@@ -816,7 +816,7 @@ class _CycleNoGAN(_OptimizerStatesMixin, nn.Module):
 
     def _losses(self, batch):
         x, y = ops.to_nhwc(batch["x"]), ops.to_nhwc(batch["y"])
-        fw = self(x, y)
+        fw = self._fwd(x, y, ops.two_directions())     # (a bare model(x, y) stays on one stream: its caller may use a plain backward)
         Gx, FGx, Fy, GFy = fw[:4]
         t = {"loss_cycle": self.loss_cycle(x, y, FGx, GFy)}
         terms, weights = [t["loss_cycle"]], [self.lambda_cycle]
@@ -872,7 +872,22 @@ class CycleAE(_CycleNoGAN):
         self._init_common(paired)
 
     def forward(self, x, y):
+        return self._fwd(x, y, False)
+
+    def _fwd(self, x, y, two_streams):
         x, y = ops.to_nhwc(x), ops.to_nhwc(y)
+        if two_streams and x.is_cuda:            # the two translation directions on two streams (CycleVAEGAN._forward_two_streams)
+            ops.premeasure(x)
+            ops.premeasure(y)
+            fork = ops.DirectionFork(x.device)
+            Gx = self.G(x)
+            with fork.second():
+                Fy = self.F(y)
+            FGx = self.F(Gx)
+            with fork.second():
+                GFy = self.G(Fy)
+            fork.join()
+            return Gx, FGx, Fy, GFy
         Gx = self.G(x)
         FGx = self.F(Gx)
         Fy = self.F(y)
@@ -897,7 +912,27 @@ class CycleVAE(_CycleNoGAN):
         self._init_common(paired)
 
     def forward(self, x, y):
+        return self._fwd(x, y, False)
+
+    def _fwd(self, x, y, two_streams):
         x, y = ops.to_nhwc(x), ops.to_nhwc(y)
+        if two_streams and x.is_cuda:            # as CycleVAEGAN._forward_two_streams; eps reserved in the order G(x), F(G(x)), F(y), G(F(y))
+            n, _, h, w = x.shape
+            shp = (n, self.G.variational_encoder_block.latent_dim, h // 16, w // 16)
+            tk = ops.eps_tickets([(shp, False)] * 4, x.device)
+            ops.premeasure(x)
+            ops.premeasure(y)
+            fork = ops.DirectionFork(x.device)
+            with ops.use_ticket(tk[0]):
+                Gx, mu_x, logvar_x = self.G(x)
+            with fork.second(), ops.use_ticket(tk[2]):
+                Fy, mu_y, logvar_y = self.F(y)
+            with ops.use_ticket(tk[1]):
+                FGx, mu_FGx, logvar_FGx = self.F(Gx)
+            with fork.second(), ops.use_ticket(tk[3]):
+                GFy, mu_GFy, logvar_GFy = self.G(Fy)
+            fork.join()
+            return Gx, FGx, Fy, GFy, mu_x, logvar_x, mu_FGx, logvar_FGx, mu_y, logvar_y, mu_GFy, logvar_GFy
         Gx, mu_x, logvar_x = self.G(x)
         FGx, mu_FGx, logvar_FGx = self.F(Gx)
         Fy, mu_y, logvar_y = self.F(y)
@@ -928,7 +963,19 @@ class DoubleAutoencoder(_OptimizerStatesMixin, nn.Module):
         self.loss_fn = None
 
     def forward(self, x, y):
+        return self._fwd(x, y, False)
+
+    def _fwd(self, x, y, two_streams):
         x, y = ops.to_nhwc(x), ops.to_nhwc(y)
+        if two_streams and x.is_cuda:            # the two modalities on two streams (ops.DirectionFork; the shared encoder's
+            ops.premeasure(x)                    # gradients meet on the one weight-gradient stream)
+            ops.premeasure(y)
+            fork = ops.DirectionFork(x.device)
+            a = self.decoder_A(self.encoder(x))
+            with fork.second():
+                b = self.decoder_B(self.encoder(y))
+            fork.join()
+            return a, b
         return self.decoder_A(self.encoder(x)), self.decoder_B(self.encoder(y))
 
     def translate_A_to_B(self, x):
@@ -955,7 +1002,7 @@ class DoubleAutoencoder(_OptimizerStatesMixin, nn.Module):
 
     def _losses(self, batch):
         x, y = ops.to_nhwc(batch["x"]), ops.to_nhwc(batch["y"])
-        Gx, Gy = self(x, y)
+        Gx, Gy = self._fwd(x, y, ops.two_directions())
         t = {"loss_recon_A": self.loss_fn(Gx, x), "loss_recon_B": self.loss_fn(Gy, y)}
         t["G_loss"] = ops.weighted_sum([t["loss_recon_A"], t["loss_recon_B"]], [1.0, 1.0])
         return t, x, y
@@ -1005,7 +1052,26 @@ class DoubleVariationalAutoencoder(_OptimizerStatesMixin, nn.Module):
         _kaiming_relu_init(module)
 
     def forward(self, x, y):
+        return self._fwd(x, y, False)
+
+    def _fwd(self, x, y, two_streams):
         x, y = ops.to_nhwc(x), ops.to_nhwc(y)
+        if two_streams and x.is_cuda:            # the two modalities on two streams; eps: block A's draw, then block B's
+            n, _, h, w = x.shape
+            shp = (n, self.vae_encoder_block_A.latent_dim, h // 16, w // 16)
+            tk = ops.eps_tickets([(shp, False)] * 2, x.device)
+            ops.premeasure(x)
+            ops.premeasure(y)
+            fork = ops.DirectionFork(x.device)
+            with ops.use_ticket(tk[0]):
+                z_x, mu_x, logvar_x = self.vae_encoder_block_A(self.encoder(x))
+            Gx = self.decoder_A(self.vae_decoder_block_A(z_x))
+            with fork.second():
+                with ops.use_ticket(tk[1]):
+                    z_y, mu_y, logvar_y = self.vae_encoder_block_B(self.encoder(y))
+                Gy = self.decoder_B(self.vae_decoder_block_B(z_y))
+            fork.join()
+            return Gx, Gy, mu_x, logvar_x, mu_y, logvar_y
         encoded_x = self.encoder(x)
         encoded_y = self.encoder(y)
         z_x, mu_x, logvar_x = self.vae_encoder_block_A(encoded_x)
@@ -1043,7 +1109,7 @@ class DoubleVariationalAutoencoder(_OptimizerStatesMixin, nn.Module):
 
     def _losses(self, batch):
         x, y = ops.to_nhwc(batch["x"]), ops.to_nhwc(batch["y"])
-        Gx, Gy, mu_x, logvar_x, mu_y, logvar_y = self(x, y)
+        Gx, Gy, mu_x, logvar_x, mu_y, logvar_y = self._fwd(x, y, ops.two_directions())
         t = {"loss_recon_A": self.loss_trans_fn(Gx, x), "loss_recon_B": self.loss_trans_fn(Gy, y),
              "loss_kl_A": self.loss_kl_fn(mu_x, logvar_x), "loss_kl_B": self.loss_kl_fn(mu_y, logvar_y)}
         t["loss_kl"] = ops.weighted_sum([t["loss_kl_A"], t["loss_kl_B"]], [1.0, 1.0])
