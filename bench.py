@@ -99,6 +99,9 @@ def main():
         os.environ.setdefault("VCG_WGRAD_OVERLAP", "0")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    pkg = importlib.import_module("vae-cyclegan-implementation_amd")
+    if os.path.exists(pkg._native.LIB_PATH) and os.environ.get("VCG_PRECREATE", "0") == "1":
+        pkg.ops.create_streams(dev)            # diagnostic only (tools/dp_variants.sh): measured 42.8 ms against 34.3 without — see ops.create_streams
     if dist_on:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -109,7 +112,7 @@ def main():
         os.dup2(2, 1)
         try:
             if backend == "nccl":
-                dist.init_process_group("nccl", device_id=dev)
+                dist.init_process_group("nccl", device_id=dev, pg_options=pkg.parallel.nccl_options())     # default priority unless VCG_NCCL_PRIORITY=high
                 dist.barrier()
             else:
                 dist.init_process_group(backend)
@@ -118,7 +121,6 @@ def main():
             os.dup2(saved_out, 1)
             os.close(saved_out)
 
-    pkg = importlib.import_module("vae-cyclegan-implementation_amd")
     ops, N = pkg.ops, pkg.Networks
     # A tree without the built library (it normally travels with it): rank 0 builds, the others wait — never N concurrent
     # hipcc runs.  The decision is rank 0's alone and every rank takes the same collectives whatever it sees on disk (a rank

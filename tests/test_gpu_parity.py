@@ -1348,7 +1348,8 @@ def _rccl_one_rank_worker(rank, port, outdir):
     from cases import LAMBDAS as lambdas, LR as lr, STEP_BIAS_STD as bstd
     dev = torch.device("cuda:0")
     torch.cuda.set_device(dev)
-    dist.init_process_group("nccl", rank=0, world_size=1, init_method=f"tcp://127.0.0.1:{port}", device_id=dev)
+    dist.init_process_group("nccl", rank=0, world_size=1, init_method=f"tcp://127.0.0.1:{port}", device_id=dev,
+                            pg_options=pkg.parallel.nccl_options())
     try:
         model = pkg.Networks.CycleVAEGAN(latent_dim=64, paired=False)
         shapes = {"dp." + k: tuple(v.shape) for k, v in model.state_dict().items()}

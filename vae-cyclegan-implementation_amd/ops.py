@@ -146,6 +146,31 @@ class DirectionFork:
         self.main.wait_stream(self.second_stream)
 
 
+_LAUNCH = {}
+
+
+def launch_stream(device):
+    """The stream parallel.GradReducer issues its collectives under (it waits for a bucket's producer streams; nothing but RCCL
+    waits for it)."""
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    st = _LAUNCH.get(idx)
+    if st is None:
+        st = torch.cuda.Stream(device=device)
+        _LAUNCH[idx] = st
+    return st
+
+
+def create_streams(device):
+    """Create the step's auxiliary streams now instead of at first use.  DIAGNOSTIC ONLY (bench.py VCG_PRECREATE=1): creating
+    them before `init_process_group` looked like the way to give each a hardware queue of its own ahead of the dozens of
+    streams a process group brings — and measured 42.8 ms per step against 34.3 with lazy creation (one-rank RCCL group, three
+    alternations, profiles/r04_dp_one_rank.txt).  The runtime's stream-to-queue assignment is not something this package can
+    steer; what it does control is GPU_MAX_HW_QUEUES (package __init__)."""
+    _side_stream(device)
+    DirectionFork(device)
+    launch_stream(device)
+
+
 def premeasure(t):
     """Publish the largest magnitude of `t` now, on the current stream, unless a valid handle is already on it: a tensor that
     two streams will read must not be measured by one of them after they have forked."""

@@ -163,7 +163,8 @@ class GradReducer:
         backward, a discriminator's full-map layer) the data-gradient chain stood still until the weight-gradient stream had
         caught up, at every bucket: a one-rank RCCL run of the bench step measured 40.4 ms against 34.8 without a reducer."""
         if self._lstream is None:
-            self._lstream = torch.cuda.Stream(device=device)
+            from . import ops
+            self._lstream = ops.launch_stream(device)      # created early by ops.create_streams where the caller did that
         return self._lstream
 
     def _order_after(self, b, stream, others, is_cuda):
@@ -237,6 +238,16 @@ class GradReducer:
                          device="cuda" if dist.get_backend(self.group) == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
         return bool(t.item() > 0)
+
+
+def nccl_options():
+    """`pg_options` for `init_process_group("nccl", ...)`.  VCG_NCCL_PRIORITY=high takes the collectives' stream from PyTorch's
+    high-priority pool (separate hardware queues from every normal-priority stream); measured on a one-rank RCCL group it makes no
+    difference to the step (34.3 ms either way against 32.5 without a process group, profiles/r04_dp_one_rank.txt), so the
+    default stays PyTorch's; the knob is for the first multi-GPU measurements."""
+    opts = dist.ProcessGroupNCCL.Options()
+    opts.is_high_priority_stream = os.environ.get("VCG_NCCL_PRIORITY", "normal") == "high"
+    return opts
 
 
 def broadcast_parameters(model, src=0, group=None):

@@ -289,7 +289,7 @@ def main(args):
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        dist.init_process_group("nccl", device_id=device, pg_options=parallel.nccl_options())
 
     # reference train.py:395-411: a resumed run continues in its checkpoint's directory, a new one gets
     # <architecture>_<timestamp>_<source>_to_<target>_<dataset> and writes its args.json there
