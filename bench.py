@@ -159,6 +159,24 @@ def main():
                     return True
             _real = dist.all_reduce
             dist.all_reduce = lambda t, *a, **k: _Done() if k.get("async_op") else _real(t, *a, **k)
+        busy = int(os.environ.get("VCG_DP_EMULATE_BUSY", "0"))
+        if busy > 0 and world == 1:
+            # diagnostic (tools/dp_variants.sh): a ONE-rank all_reduce moves nothing, so RCCL's stream is idle; make it as busy as an
+            # N-rank exchange would — `busy` device copies of the bucket on the collectives' stream (a one-rank all_gather is a copy)
+            # behind every asynchronous all_reduce — to see what a busy collective stream does to the step's other streams
+            _real2 = dist.all_reduce
+            _scratch = {}
+
+            def _busy_all_reduce(t, *a, **k):
+                w = _real2(t, *a, **k)
+                if k.get("async_op"):
+                    buf = _scratch.get(t.numel())
+                    if buf is None:
+                        buf = _scratch[t.numel()] = torch.empty_like(t)
+                    for _ in range(busy):
+                        w = dist.all_gather_into_tensor(buf, t, async_op=True)
+                return w
+            dist.all_reduce = _busy_all_reduce
         pkg.parallel.broadcast_parameters(model)
     ops.manual_seed(4321 + rank)
 

@@ -4,9 +4,8 @@ run() { echo "== $*"; env "$@" timeout -k 10 300 python bench.py --steps 10 --wa
 for i in 1 2; do
 run VCG_X=0
 run VCG_FORCE_DIST=1
-run VCG_FORCE_DIST=1 VCG_DP_FROM_BACKWARD=0
-run VCG_FORCE_DIST=1 VCG_DP_NULL_EXCHANGE=1
-run VCG_FORCE_DIST=1 VCG_BUCKET_MB=4096
-run VCG_FORCE_DIST=1 VCG_DIR_STREAMS=0
-run VCG_DIR_STREAMS=0
+run VCG_FORCE_DIST=1 VCG_DP_EMULATE_BUSY=8
+run VCG_FORCE_DIST=1 VCG_DP_EMULATE_BUSY=8 VCG_DIR_STREAMS=0
+run VCG_FORCE_DIST=1 VCG_DP_EMULATE_BUSY=24
+run VCG_FORCE_DIST=1 VCG_DP_EMULATE_BUSY=24 VCG_DIR_STREAMS=0
 done
