@@ -444,6 +444,48 @@ class VariationalAutoencoder(_OptimizerStatesMixin, nn.Module):
             return m
 
 
+def _vae_pair(vae_a, a, ticket_a, vae_b, b, ticket_b, fork):
+    """vae_a(a) on the caller's stream and vae_b(b) on `fork`'s second stream, issued alternately in half-generator pieces
+    (encoder | bottleneck + decoder): the second stream has work after a quarter of the host time a whole generator takes to
+    issue, and — autograd replays in reverse issue order — the backward alternates between the two chains at the same
+    granularity instead of one whole generator at a time (CycleVAEGAN step 32.54 -> 31.89 ms; block by block, through generator
+    coroutines, measured no better: 32.4 vs 32.3).  VCG_DIR_INTERLEAVE=0: whole generators."""
+    def tail(vae, enc, ticket):                  # VariationalAutoencoder.forward after its encoder
+        with ops.use_ticket(ticket):
+            z, mu, lv = vae.variational_encoder_block(enc)
+        return vae.decoder(vae.variational_decoder_block(z)), mu, lv
+
+    if not ops.DIR_INTERLEAVE:
+        with ops.use_ticket(ticket_a):
+            ra = vae_a(a)
+        with fork.second(), ops.use_ticket(ticket_b):
+            rb = vae_b(b)
+        return ra, rb
+    ea = vae_a.encoder(a)
+    with fork.second():
+        eb = vae_b.encoder(b)
+    ra = tail(vae_a, ea, ticket_a)
+    with fork.second():
+        rb = tail(vae_b, eb, ticket_b)
+    return ra, rb
+
+
+def _ae_pair(ae_a, a, ae_b, b, fork):
+    """The same for two plain autoencoders."""
+    if not ops.DIR_INTERLEAVE:
+        ra = ae_a(a)
+        with fork.second():
+            rb = ae_b(b)
+        return ra, rb
+    ea = ae_a.encoder(a)
+    with fork.second():
+        eb = ae_b.encoder(b)
+    ra = ae_a.decoder(ea)
+    with fork.second():
+        rb = ae_b.decoder(eb)
+    return ra, rb
+
+
 class CycleVAEGAN(nn.Module):
     """Two VAEs (G: X->Y, F: Y->X) + two discriminators; cycle + LSGAN + KL (+identity if paired);
     alternating G then D update  (reference Networks.py:1872-2150).
@@ -555,14 +597,8 @@ class CycleVAEGAN(nn.Module):
         ops.premeasure(x)
         ops.premeasure(y)
         fork = ops.DirectionFork(x.device)
-        with ops.use_ticket(tk[0]):
-            Gx, mu_x, lv_x = self.G(x)
-        with fork.second(), ops.use_ticket(tk[3]):
-            Fy, mu_y, lv_y = self.F(y)
-        with ops.use_ticket(tk[2]):
-            FGx, mu_FGx, lv_FGx = self.F(Gx)
-        with fork.second(), ops.use_ticket(tk[5]):
-            GFy, mu_GFy, lv_GFy = self.G(Fy)
+        (Gx, mu_x, lv_x), (Fy, mu_y, lv_y) = _vae_pair(self.G, x, tk[0], self.F, y, tk[3], fork)
+        (FGx, mu_FGx, lv_FGx), (GFy, mu_GFy, lv_GFy) = _vae_pair(self.F, Gx, tk[2], self.G, Fy, tk[5], fork)
         DYGx = self.DY(Gx)
         with fork.second():
             DXFy = self.DX(Fy)
@@ -742,12 +778,8 @@ class CycleAEGAN(CycleVAEGAN):
             ops.premeasure(x)
             ops.premeasure(y)
             fork = ops.DirectionFork(x.device)
-            Gx = self.G(x)
-            with fork.second():
-                Fy = self.F(y)
-            FGx = self.F(Gx)
-            with fork.second():
-                GFy = self.G(Fy)
+            Gx, Fy = _ae_pair(self.G, x, self.F, y, fork)
+            FGx, GFy = _ae_pair(self.F, Gx, self.G, Fy, fork)
             DYGx = self.DY(Gx)
             with fork.second():
                 DXFy = self.DX(Fy)
@@ -880,12 +912,8 @@ class CycleAE(_CycleNoGAN):
             ops.premeasure(x)
             ops.premeasure(y)
             fork = ops.DirectionFork(x.device)
-            Gx = self.G(x)
-            with fork.second():
-                Fy = self.F(y)
-            FGx = self.F(Gx)
-            with fork.second():
-                GFy = self.G(Fy)
+            Gx, Fy = _ae_pair(self.G, x, self.F, y, fork)
+            FGx, GFy = _ae_pair(self.F, Gx, self.G, Fy, fork)
             fork.join()
             return Gx, FGx, Fy, GFy
         Gx = self.G(x)
@@ -923,14 +951,8 @@ class CycleVAE(_CycleNoGAN):
             ops.premeasure(x)
             ops.premeasure(y)
             fork = ops.DirectionFork(x.device)
-            with ops.use_ticket(tk[0]):
-                Gx, mu_x, logvar_x = self.G(x)
-            with fork.second(), ops.use_ticket(tk[2]):
-                Fy, mu_y, logvar_y = self.F(y)
-            with ops.use_ticket(tk[1]):
-                FGx, mu_FGx, logvar_FGx = self.F(Gx)
-            with fork.second(), ops.use_ticket(tk[3]):
-                GFy, mu_GFy, logvar_GFy = self.G(Fy)
+            (Gx, mu_x, logvar_x), (Fy, mu_y, logvar_y) = _vae_pair(self.G, x, tk[0], self.F, y, tk[2], fork)
+            (FGx, mu_FGx, logvar_FGx), (GFy, mu_GFy, logvar_GFy) = _vae_pair(self.F, Gx, tk[1], self.G, Fy, tk[3], fork)
             fork.join()
             return Gx, FGx, Fy, GFy, mu_x, logvar_x, mu_FGx, logvar_FGx, mu_y, logvar_y, mu_GFy, logvar_GFy
         Gx, mu_x, logvar_x = self.G(x)

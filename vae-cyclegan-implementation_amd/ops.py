@@ -120,6 +120,7 @@ def join_side_streams():
 # weights carry events (`ConvSpec.packed`, `FusedConvPair.tensors`), the images' magnitudes are measured before the fork
 # (`premeasure`).  VCG_DIR_STREAMS=0: one chain after the other, as in rounds 1-3.
 DIRECTION_STREAMS = os.environ.get("VCG_DIR_STREAMS", "1") != "0"
+DIR_INTERLEAVE = os.environ.get("VCG_DIR_INTERLEAVE", "1") != "0"       # 0: whole generators alternate between the two streams (A/B)
 _DIR = {}
 
 
