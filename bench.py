@@ -159,6 +159,22 @@ def main():
                     return True
             _real = dist.all_reduce
             dist.all_reduce = lambda t, *a, **k: _Done() if k.get("async_op") else _real(t, *a, **k)
+        if os.environ.get("VCG_DP_TIME_CALLS") == "1":
+            # diagnostic: host time spent inside the asynchronous all_reduce calls (they are issued from the autograd thread)
+            _real3 = dist.all_reduce
+            _host = {"n": 0, "s": 0.0}
+
+            def _timed_all_reduce(t, *a, **k):
+                if not k.get("async_op"):
+                    return _real3(t, *a, **k)
+                t0_ = time.perf_counter()
+                w = _real3(t, *a, **k)
+                _host["s"] += time.perf_counter() - t0_
+                _host["n"] += 1
+                return w
+            dist.all_reduce = _timed_all_reduce
+            import atexit
+            atexit.register(lambda: sys.stderr.write(f"async all_reduce calls: {_host['n']}, mean host time {1e6 * _host['s'] / max(_host['n'], 1):.1f} us\n"))
         busy = int(os.environ.get("VCG_DP_EMULATE_BUSY", "0"))
         if busy > 0 and world == 1:
             # diagnostic (tools/dp_variants.sh): a ONE-rank all_reduce moves nothing, so RCCL's stream is idle; make it as busy as an
