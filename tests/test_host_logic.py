@@ -725,3 +725,38 @@ def test_eight_ranks_of_batch_one_equal_the_reference_at_batch_eight(pkg, tmp_pa
         except AssertionError as e:
             bad.append(str(e))
     assert seen >= 78 and not bad, f"{len(bad)} of {seen} world-averaged gradients off the reference's batch-8 step:\n" + "\n".join(b[:300] for b in bad[:8])
+
+
+# ------------------------------------------------------------------ eps draws reserved ahead of time (two directions on two streams)
+def test_eps_tickets_keep_the_reference_draw_order(pkg):
+    """ops.eps_tickets / use_ticket (Networks.CycleVAEGAN._forward_two_streams): the two translation directions are issued
+    interleaved, G(x), F(y), F(G(x)), G(F(y)), but every reparameterisation must draw what it draws in the reference's call order
+    G(x), [G(y)], F(G(x)), F(y), [F(x)], G(F(y)) (/root/reference/Networks.py:1997-2006) — injected tensors (parity runs) and
+    positions of the on-device Philox stream alike; skipped forwards still consume theirs."""
+    ops = pkg.ops
+    shp = (2, 64, 4, 4)
+    n4 = (2 * 64 * 4 * 4 + 3) // 4
+    plan = [(shp, False), (shp, True), (shp, False), (shp, False), (shp, True), (shp, False)]
+    # injected mode: the queue holds six tensors in the reference's order
+    inj = [torch.full(shp, float(i)) for i in range(6)]
+    ops.inject_eps(list(inj))
+    tk = ops.eps_tickets(plan, torch.device("cpu"))
+    assert tk[1] is None and tk[4] is None and not ops._EPS_QUEUE
+    assert [float(tk[i][1].flatten()[0]) for i in (0, 2, 3, 5)] == [0.0, 2.0, 3.0, 5.0]
+    # RNG mode: positions are reserved in plan order, whatever order they are used in
+    ops.manual_seed(77)
+    tk = ops.eps_tickets(plan, torch.device("cpu"))
+    assert [tk[i] for i in (0, 2, 3, 5)] == [("offset", 0), ("offset", 2 * n4), ("offset", 3 * n4), ("offset", 5 * n4)]
+    assert ops._RNG["offset"] == 6 * n4
+    order = []
+    for i in (0, 3, 2, 5):                       # the issue order of the two-stream forward
+        with ops.use_ticket(tk[i]):
+            assert ops.next_eps(shp, torch.device("cpu")) is None      # "draw on device" ...
+            order.append(ops._FORCED_OFFSETS.pop(0))                   # ... at the reserved position (what _ReparamFn.forward pops)
+    assert order == [0, 3 * n4, 2 * n4, 5 * n4] and not ops._TICKETS
+    # a block that runs no reparameterisation leaves its ticket unconsumed: that is an error, not a silent shift of the stream
+    with pytest.raises(RuntimeError, match="not consumed"):
+        with ops.use_ticket(("offset", 123)):
+            pass
+    assert not ops._TICKETS
+    ops.manual_seed(0)
