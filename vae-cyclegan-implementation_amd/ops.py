@@ -907,6 +907,7 @@ def eps_tickets(plan, device):
     """Reserve the eps draws of several reparameterisations in the REFERENCE's call order, to be used in another one (the two
     directions of a cycle model are issued interleaved on two streams).  `plan`: [(shape, skip)]; returns one ticket per entry
     (None for skipped ones) for `use_ticket`."""
+    del _TICKETS[:], _FORCED_OFFSETS[:]          # leftovers of a forward that raised half way must not shift this one's draws
     out = []
     for shape, skip in plan:
         if _EPS_QUEUE:
