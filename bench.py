@@ -20,6 +20,10 @@ import time
 
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # RCCL across processes needs dmabuf IPC on this driver
 os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")        # kernel arguments in device memory: shorter dispatch gaps (package __init__)
+if os.environ.get("VCG_ONE_DEVICE") == "1":
+    # the gloo rehearsal puts SEVERAL processes on one card: with 8 hardware queues each the card's queue slots are oversubscribed
+    # and the second step never finishes (both ranks wait in GradReducer.finish for a bucket; with 4 it takes 3 s) — measured, round 4
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "4")
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")            # one hardware queue per stream once RCCL has added its own (package __init__)
 
 import torch  # noqa: E402
@@ -78,6 +82,16 @@ def main():
         return
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
+    trace_on = os.environ.get("VCG_BENCH_TRACE") == "1"
+    t_trace = time.perf_counter()
+    if trace_on:
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ.get("VCG_BENCH_TRACE_AFTER", "90")), exit=False)     # where every thread is, if it stalls
+
+    def trace(what):
+        if trace_on:
+            sys.stderr.write(f"[bench rank {rank} +{time.perf_counter() - t_trace:7.2f}s] {what}\n")
+            sys.stderr.flush()
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
@@ -135,6 +149,7 @@ def main():
     elif not os.path.exists(pkg._native.LIB_PATH):
         pkg._native.build(verbose=False)
     pkg._native.lib()                      # fail loudly if the HIP extension is missing
+    trace("process group and library ready")
 
     wl = args.workload
     B = args.batch or (16 if wl in SAME_XY else 8)
@@ -194,6 +209,7 @@ def main():
                 return w
             dist.all_reduce = _busy_all_reduce
         pkg.parallel.broadcast_parameters(model)
+    trace("model built, parameters broadcast")
     ops.manual_seed(4321 + rank)
 
     # synthetic batches resident in HBM: x, y ~ U[0,1), distinct per rank and per pool slot
@@ -219,6 +235,7 @@ def main():
         torch.cuda.set_stream(main_stream)
     for i in range(args.warmup):
         model.training_step(pool[i % len(pool)])
+        trace(f"warm-up step {i} issued")
     # a full collection of Python's cyclic GC walks every long-lived object (modules, parameters, ctypes tables): ~30 ms
     # on the host, and since each step ends with a metric read-back the GPU idles for all of it.  Collect once now and
     # move the survivors out of the collector's way; the GC stays on for what the steps allocate.
@@ -233,6 +250,7 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         last = model.training_step(pool[i % len(pool)])
+        trace(f"timed step {i} done")
     barrier()
     elapsed = time.perf_counter() - t0
     exposed_ms = None

@@ -1185,6 +1185,10 @@ def _dp_gpu_worker(rank, world, port, outdir, from_backward=True):
     import torch.distributed as dist
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    # two processes share the one card here: 4 hardware queues each, not the package's 8 — with 2 x 8 the card's queue slots
+    # are oversubscribed, and bench.py's two-rank rehearsal (batch 8) was seen to hang in that state (this process has not
+    # initialised HIP yet, so the setting takes)
+    os.environ["GPU_MAX_HW_QUEUES"] = "4"
     os.environ["VCG_BUCKET_MB"] = "16"                       # several buckets per optimizer, D's slices included
     os.environ["VCG_DP_FROM_BACKWARD"] = "1" if from_backward else "0"
     pkg = importlib.import_module("vae-cyclegan-implementation_amd")

@@ -15,7 +15,8 @@ _os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
 # reducer's launch stream), and with 4 queues the weight-gradient stream then shares a queue with the main stream: the two
 # serialise and the overlap is gone — a ONE-rank RCCL run of the bench step measured 42.7 ms against 36.7 without a process
 # group, with not one collective waited for (profiles/r04_dp_one_rank.txt); with 8 queues 36.3 against 35.9.  Same rule as
-# above: in the environment before the first HIP call; an explicit value wins.
+# above: in the environment before the first HIP call; an explicit value wins.  (SEVERAL processes on one card — a rehearsal, never
+# the deployment — want 4: 2 x 8 queues oversubscribe the card's queue slots and a two-rank step was seen to hang.)
 _os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 from . import _native, ops, optim, synth  # noqa: F401,E402

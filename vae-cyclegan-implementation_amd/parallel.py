@@ -36,6 +36,7 @@ import torch.distributed as dist
 # VCG_DP_FROM_BACKWARD=0: every bucket is exchanged after the backward (at `start`), none from inside it — the reference point of
 # tests/test_gpu_parity.py::test_two_rank_step_equals_the_big_batch_step, which requires the in-backward launches to change no bit
 FROM_BACKWARD = os.environ.get("VCG_DP_FROM_BACKWARD", "1") != "0"
+USE_LAUNCH_STREAM = os.environ.get("VCG_DP_LAUNCH_STREAM", "1") != "0"       # 0: collectives issued under the last reporter's stream (A/B)
 
 
 def default_bucket_bytes():
@@ -174,7 +175,10 @@ class GradReducer:
         still accumulating into it.  Returns the stream to issue the collective under."""
         waited = [s for s in others if not (s is stream or s == stream)]
         launch = stream
-        if is_cuda:
+        if is_cuda and not USE_LAUNCH_STREAM:
+            for s in waited:                     # round 3's form (diagnostic): the last reporter's stream waits for the others
+                stream.wait_stream(s)
+        elif is_cuda:
             launch = self._launch_stream(stream.device)
             launch.wait_stream(stream)
             for s in waited:
