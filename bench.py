@@ -291,7 +291,7 @@ def main():
         out["process_group"] = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "rank0_device_count": torch.cuda.device_count(),
                                 "device_of_rank": [int(t.item()) for t in dlist],
                                 "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY"),
-                                "VCG_BUCKET_MB": os.environ.get("VCG_BUCKET_MB", "64 (default)")}
+                                "VCG_BUCKET_MB": os.environ.get("VCG_BUCKET_MB", "128 (default)")}
         out["exchange"] = {"buckets_launched_from_inside_backward": st["buckets_from_backward"], "buckets_launched_after_backward": st["buckets_at_start"],
                            "buckets_ordered_after_a_second_stream": sum(1 for _, _, w in red.wait_log if w),
                            "bucket_bytes": red.bucket_elems * 4, "is": "sum-all-reduce (RCCL) of contiguous slices of each optimizer's flat "

@@ -23,7 +23,7 @@ buckets that are launched FROM INSIDE the backward pass as they complete:
   * gradients the generator phase deposits on the discriminators as a by-product are never produced here
     (`ops.no_wgrad`), so nothing spurious is reduced.
 
-xGMI is point-to-point (7 links x ~153 GB/s per GPU): buckets are large (default 64 MiB) so that every RCCL launch can
+xGMI is point-to-point (7 links x ~153 GB/s per GPU): buckets are large (default 128 MiB) so that every RCCL launch can
 keep all links busy.  `stats` accumulates what the step still waits for (HIP events around `finish`): bench.py prints it
 as `exchange_exposed_ms` for N > 1.
 """
@@ -40,8 +40,11 @@ USE_LAUNCH_STREAM = os.environ.get("VCG_DP_LAUNCH_STREAM", "1") != "0"       # 0
 
 
 def default_bucket_bytes():
-    """VCG_BUCKET_MB: size at which a gradient bucket closes (default 64 MiB; xGMI is point-to-point, few large collectives)."""
-    return max(1, int(float(os.environ.get("VCG_BUCKET_MB", "64")) * (1 << 20)))
+    """VCG_BUCKET_MB: size at which a gradient bucket closes.  Default 128 MiB: xGMI is point-to-point (few large collectives),
+    and every collective issued from inside the backward costs the step 0.2 - 0.3 ms whatever its size (one-rank RCCL runs of
+    the bench step, profiles/r04_dp_one_rank.txt: 64 MiB = 8 launches +1.9 ms, 128 MiB = 5 launches +1.4 ms over the step
+    without a process group)."""
+    return max(1, int(float(os.environ.get("VCG_BUCKET_MB", "128")) * (1 << 20)))
 
 
 class _Plan:
